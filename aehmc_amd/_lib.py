@@ -1,0 +1,68 @@
+"""ctypes binding of libaehmc_hip.so (include/aehmc_hip.h).  Fails loudly when the HIP
+library is missing: there is no CPU path in this package."""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaehmc_hip.so")
+_lib = None
+
+
+class CTarget(ct.Structure):
+    _fields_ = [("kind", ct.c_int32), ("reserved", ct.c_int32), ("D", ct.c_int64),
+                ("mu", ct.c_void_p), ("sigma", ct.c_void_p), ("prec", ct.c_void_p),
+                ("X", ct.c_void_p), ("y", ct.c_void_p), ("N", ct.c_int64)]
+
+
+class CMetric(ct.Structure):
+    _fields_ = [("ndim", ct.c_int32), ("reserved", ct.c_int32), ("D", ct.c_int64),
+                ("imm", ct.c_void_p), ("sqrt_mass", ct.c_void_p)]
+
+
+class CDiagnostics(ct.Structure):
+    _fields_ = [("momentum", ct.c_void_p), ("acceptance_probability", ct.c_void_p),
+                ("num_doublings", ct.c_void_p), ("is_turning", ct.c_void_p),
+                ("is_diverging", ct.c_void_p), ("n_leapfrog", ct.c_void_p)]
+
+
+# every symbol include/aehmc_hip.h declares: name -> (restype, argtypes)
+_P, _I64, _D, _I = ct.c_void_p, ct.c_int64, ct.c_double, ct.c_int
+SYMBOLS = {
+    "aehmc_create": (_I, [ct.POINTER(_P), _I]),
+    "aehmc_destroy": (_I, [_P]),
+    "aehmc_last_error": (ct.c_char_p, [_P]),
+    "aehmc_set_target": (_I, [_P, ct.POINTER(CTarget)]),
+    "aehmc_set_metric": (_I, [_P, ct.POINTER(CMetric)]),
+    "aehmc_set_option": (_I, [_P, ct.c_char_p, _I64]),
+    "aehmc_workspace_bytes": (_I64, [_P, _I64, _I64]),
+    "aehmc_set_workspace": (_I, [_P, _P, _I64]),
+    "aehmc_new_state": (_I, [_P, _I64, _P, _P, _P, _P]),
+    "aehmc_hmc_step": (_I, [_P, _I64, _P, _D, _I64, _D, _P, _P, _P, ct.POINTER(CDiagnostics), _P]),
+    "aehmc_nuts_step": (_I, [_P, _I64, _P, _D, _I64, _D, _P, _P, _P, ct.POINTER(CDiagnostics), _P]),
+    "aehmc_leapfrog": (_I, [_P, _I64, _D, _I64, _P, _P, _P, _P, _P]),
+    "aehmc_kinetic_energy": (_I, [_P, _I64, _P, _P, _P]),
+    "aehmc_is_turning": (_I, [_P, _I64, _P, _P, _P, _P, _P]),
+    "aehmc_rng_normals": (_I, [_P, _I64, _P, _I64, _P, _P]),
+    "aehmc_rng_bernoulli": (_I, [_P, _I64, _P, _I64, _P, _P, _P]),
+    "aehmc_gemm_nt": (_I, [_P, _I64, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P]),
+    "aehmc_profile_enable": (_I, [_P, _I]),
+    "aehmc_profile_read": (_I, [_P, ct.POINTER(_D), ct.POINTER(_I64)]),
+}
+
+
+def load():
+    """Load the HIP library; raise (never fall back) if it is absent or incomplete."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C aehmc_amd/csrc`); aehmc_amd has no CPU fallback")
+        lib = ct.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib

@@ -1,0 +1,649 @@
+// Device side of the lock-step many-chain HMC/NUTS engine (gfx950, wave64).
+//
+// One wavefront owns one chain.  Vectors are rows of chain-major [C,D] fp64 arrays in
+// HBM (coalesced 512 B per wave access); per-chain scalars live in a ChainCtl record.
+// A NUTS transition is a per-chain state machine advanced by one leapfrog per launch
+// ("lock-step"): chains at different tree depths / directions share each launch, and
+// with a dense metric or dense target the mat-vecs of all chains become one fp64 MFMA
+// GEMM between the stages (gemm_f64.cuh).
+//
+// Reference semantics restated here (file:line under /root/reference/aehmc):
+//   leapfrog stages S1..S3   integrators.py:54-73
+//   kinetic energy / U-turn   metrics.py:70-104
+//   proposal scalars          proposals.py:19-62, 72-174
+//   checkpoint bookkeeping    termination.py:85-235
+//   sub-trajectory loop       trajectory.py:154-374
+//   expansion loop            trajectory.py:428-714, nuts.py:56-153
+//   HMC accept/reject         hmc.py:157-204
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/aehmc_hip.h"
+#include "rng.cuh"
+
+namespace aehmc {
+
+#define AEHMC_LOG_SQRT_2PI 0.91893853320467267
+
+struct ChainCtl {
+  double H0;                        // initial energy of the transition
+  double prop_E, prop_w, prop_slpa; // main proposal scalars (proposals.py:11-15)
+  double sub_E, sub_w, sub_slpa;    // sub-trajectory proposal scalars
+  double U_cur, U_end[2], U_slot[2];
+  double acc_prob;
+  long long nleap;
+  int j, step, dir, length;         // expansion, step in sub-trajectory, 1 = right, length
+  int tmin, tmax;                   // termination.py:12-16 indices (carried, never reset)
+  int done, phantom;                // phantom: first step diverged, scan still runs (trajectory.py:336)
+  int prop_slot;                    // which of the two proposal buffers is the main proposal
+  int ndoubl, out_div, out_turn;
+  int hmc_accept;
+};
+
+struct EngineArgs {
+  long long C, D;
+  double eps, thr;
+  int max_exp;
+  // metric (metrics.py:44-63)
+  int met_ndim;
+  const double *imm, *sqrt_mass;
+  // target
+  int tkind;
+  const double *mu, *sigma, *log_sigma;
+  // per-chain RNG [C, nsites, 4]
+  uint64_t *rng;
+  int nsites;
+  // work vectors [C,D]
+  double *cur_q, *cur_p, *cur_g, *cur_v;
+  double *end_q[2], *end_p[2], *end_g[2], *end_v[2];
+  double *slot_q[2], *slot_p[2], *slot_g[2];
+  double *psum, *psub;
+  double *ckp, *cks, *ckv;          // [max_exp][C][D]
+  double *vhalf, *rbuf, *zbuf;
+  ChainCtl *ctl;
+  // caller state / outputs
+  double *q, *U, *g;
+  aehmc_diagnostics out;
+};
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+  return x;
+}
+
+__device__ __forceinline__ double np_logaddexp(double x, double y) {  // numpy npy_logaddexp
+  if (x == y) return x + 0.693147180559945309417232121458176568;
+  double tmp = x - y;
+  if (tmp > 0) return x + log1p(exp(-tmp));
+  if (tmp <= 0) return y + log1p(exp(tmp));
+  return tmp;
+}
+
+// coordinate-wise targets: contribution to U and dU/dq_i
+__device__ __forceinline__ void target_elem(const EngineArgs &a, long long i, double q,
+                                            double &u, double &g) {
+  switch (a.tkind) {
+    case AEHMC_T_STD_NORMAL:
+      u = 0.5 * (q * q) + AEHMC_LOG_SQRT_2PI;
+      g = q;
+      break;
+    case AEHMC_T_ISO_GAUSSIAN:
+      u = q * q;  // U = 0.5 * sum
+      g = q;
+      break;
+    default: {  // AEHMC_T_DIAG_GAUSSIAN
+      double s = a.sigma[i];
+      double z = (q - a.mu[i]) / s;
+      u = 0.5 * (z * z) + a.log_sigma[i] + AEHMC_LOG_SQRT_2PI;
+      g = z / s;
+    }
+  }
+}
+__device__ __forceinline__ double target_finish(const EngineArgs &a, double usum) {
+  return (a.tkind == AEHMC_T_ISO_GAUSSIAN || a.tkind == AEHMC_T_DENSE_MVN) ? 0.5 * usum : usum;
+}
+__device__ __forceinline__ bool target_is_elem(int k) {
+  return k == AEHMC_T_STD_NORMAL || k == AEHMC_T_ISO_GAUSSIAN || k == AEHMC_T_DIAG_GAUSSIAN;
+}
+// diagonal / scalar velocity imm o p (metrics.py:47,51,71)
+__device__ __forceinline__ double vel_diag(const EngineArgs &a, long long i, double p) {
+  return (a.met_ndim == 0 ? a.imm[0] : a.imm[i]) * p;
+}
+
+// ---------------------------------------------------------------------------------
+// Leapfrog stages (integrators.py:54-73).  DO1: p_half = p - (0.5 eps) g.
+// DO2: q' = q + (1 eps) v_half, then the target at q' (coordinate-wise targets inline;
+// dense target: r = q' - mu is staged for the GEMM).  DO3: p' = p_half - (0.5 eps) g'.
+// ---------------------------------------------------------------------------------
+// Returns true (and the new potential energy in U_out, on every lane) when the target
+// value was completed by this stage set.
+template <bool DO1, bool DO2, bool DO3, bool MET_DENSE>
+__device__ __forceinline__ bool leap_stages(const EngineArgs &a, long long c, int lane, int dir,
+                                            double &U_out) {
+  const double step_size = (dir ? 1.0 : -1.0) * a.eps;
+  const double b = 0.5 * step_size, aa = 1 * step_size;
+  const size_t row = (size_t)c * a.D;
+  const bool elem = target_is_elem(a.tkind);
+  const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
+  double usum = 0.0;
+  for (long long i = lane; i < a.D; i += 64) {
+    double p = a.cur_p[row + i];
+    double gnew = 0.0;
+    if (DO1) p = p - b * a.cur_g[row + i];
+    if (DO2) {
+      double v = MET_DENSE ? a.vhalf[row + i] : vel_diag(a, i, p);
+      double q = a.cur_q[row + i] + aa * v;
+      a.cur_q[row + i] = q;
+      if (elem) {
+        double u;
+        target_elem(a, i, q, u, gnew);
+        usum += u;
+        a.cur_g[row + i] = gnew;
+      } else if (tdense) {
+        a.rbuf[row + i] = q - a.mu[i];
+      }
+    }
+    if (DO3) {
+      double gi = (DO2 && elem) ? gnew : a.cur_g[row + i];
+      if (tdense) usum += a.rbuf[row + i] * gi;
+      p = p - b * gi;
+    }
+    if (DO1 || DO3) a.cur_p[row + i] = p;
+  }
+  if ((DO2 && elem) || (DO3 && tdense)) {
+    U_out = target_finish(a, wave_sum(usum));
+    return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------
+// NUTS bookkeeping after one leapfrog of the chain's moving end (cur_*).
+// ---------------------------------------------------------------------------------
+template <bool MET_DENSE>
+__device__ __forceinline__ void copy_cur_to_slot(const EngineArgs &a, size_t row, int lane,
+                                                 int slot) {
+  for (long long i = lane; i < a.D; i += 64) {
+    a.slot_q[slot][row + i] = a.cur_q[row + i];
+    a.slot_p[slot][row + i] = a.cur_p[row + i];
+    a.slot_g[slot][row + i] = a.cur_g[row + i];
+  }
+}
+
+template <bool MET_DENSE>
+__device__ inline void nuts_begin_expansion(const EngineArgs &a, long long c, int lane,
+                                            ChainCtl &ct, int prev_dir) {
+  Pcg64 g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
+  int go_right = rng_bernoulli(g2, 0.5);  // trajectory.py:516
+  if (lane == 0) pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
+  ct.dir = go_right;
+  ct.step = 0;
+  if (prev_dir >= 0 && prev_dir != go_right) {  // cur <- the other end (trajectory.py:518)
+    const size_t row = (size_t)c * a.D;
+    for (long long i = lane; i < a.D; i += 64) {
+      a.cur_q[row + i] = a.end_q[go_right][row + i];
+      a.cur_p[row + i] = a.end_p[go_right][row + i];
+      a.cur_g[row + i] = a.end_g[go_right][row + i];
+      if (MET_DENSE) a.cur_v[row + i] = a.end_v[go_right][row + i];
+    }
+    ct.U_cur = ct.U_end[go_right];
+  }
+}
+
+__device__ inline void nuts_write_outputs(const EngineArgs &a, long long c, int lane,
+                                          const ChainCtl &ct) {
+  const size_t row = (size_t)c * a.D;
+  const int s = ct.prop_slot;
+  for (long long i = lane; i < a.D; i += 64) {
+    a.q[row + i] = a.slot_q[s][row + i];
+    a.g[row + i] = a.slot_g[s][row + i];
+    if (a.out.momentum) a.out.momentum[row + i] = a.slot_p[s][row + i];
+  }
+  if (lane == 0) {
+    a.U[c] = ct.U_slot[s];
+    a.out.acceptance_probability[c] = ct.acc_prob;
+    if (a.out.num_doublings) a.out.num_doublings[c] = ct.ndoubl;
+    if (a.out.is_turning) a.out.is_turning[c] = ct.out_turn;
+    a.out.is_diverging[c] = ct.out_div;
+    if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
+  }
+}
+
+// expand_once after integrate() returned: trajectory.py:537-608
+template <bool MET_DENSE>
+__device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c, int lane,
+                                               ChainCtl &ct, bool is_div, bool has_term) {
+  const size_t row = (size_t)c * a.D;
+  const int dir = ct.dir, oth = 1 - dir;
+  // one pass: moving end <- cur, psum += psub, whole-trajectory U-turn dots (metrics.py:75-104)
+  double d_l = 0.0, d_r = 0.0;
+  for (long long i = lane; i < a.D; i += 64) {
+    double pc = a.cur_p[row + i], po = a.end_p[oth][row + i];
+    double vc = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, pc);
+    double vo = MET_DENSE ? a.end_v[oth][row + i] : vel_diag(a, i, po);
+    double s = a.psum[row + i] + a.psub[row + i];
+    a.psum[row + i] = s;
+    double pl = dir ? po : pc, pr = dir ? pc : po;
+    double vl = dir ? vo : vc, vr = dir ? vc : vo;
+    double rho = s - (pr + pl) / 2;
+    d_l += vl * rho;
+    d_r += vr * rho;
+    a.end_q[dir][row + i] = a.cur_q[row + i];
+    a.end_p[dir][row + i] = pc;
+    a.end_g[dir][row + i] = a.cur_g[row + i];
+    if (MET_DENSE) a.end_v[dir][row + i] = vc;
+  }
+  d_l = wave_sum(d_l);
+  d_r = wave_sum(d_r);
+  const bool turning = (d_l <= 0) | (d_r <= 0);
+  ct.U_end[dir] = ct.U_cur;
+
+  ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;  // trajectory.py:551-553
+  double pb = exp(ct.sub_w - ct.prop_w);               // proposals.py:130 (always drawn)
+  if (pb > 1.0) pb = 1.0;
+  if (pb < 0.0) pb = 0.0;
+  Pcg64 g4 = pcg_load(a.rng + ((size_t)c * a.nsites + 3) * 4);
+  int acc_b = rng_bernoulli(g4, pb);
+  if (lane == 0) pcg_store(a.rng + ((size_t)c * a.nsites + 3) * 4, g4);
+  if (is_div || has_term) {
+    ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);  // trajectory.py:560-564
+  } else {
+    ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);           // proposals.py:141-144
+    ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
+    if (acc_b) {
+      ct.prop_slot ^= 1;
+      ct.prop_E = ct.sub_E;
+    }
+  }
+  ct.ndoubl = ct.j + 1;
+  ct.out_div = is_div;
+  ct.out_turn = turning;
+  const bool end_transition = is_div || turning || has_term || (ct.j + 1 == a.max_exp);
+  if (end_transition) {
+    nuts_write_outputs(a, c, lane, ct);
+    ct.done = 1;  // caller keeps the chain alive while a phantom scan is pending
+  } else {
+    ct.j += 1;
+    nuts_begin_expansion<MET_DENSE>(a, c, lane, ct, dir);
+  }
+}
+
+// dynamic_integration.integrate body, one step: trajectory.py:195-305
+template <bool MET_DENSE>
+__device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, ChainCtl ct) {
+  const size_t row = (size_t)c * a.D;
+  const int step = ct.step;
+  if (!ct.phantom) ct.nleap += 1;
+  int tmin, tmax;
+  if (step == 0) {  // termination.py:109-113: indices inherited from the previous sub-trajectory
+    tmin = ct.tmin;
+    tmax = ct.tmax;
+  } else {          // termination.py:192-235 in closed form
+    int n1 = __ffs(~step) - 1;
+    tmax = __popc(step >> 1);
+    tmin = tmax - n1 + 1;
+  }
+  const bool even = (step & 1) == 0;
+  double *ckp = a.ckp + ((size_t)tmax * a.C + c) * a.D;
+  double *cks = a.cks + ((size_t)tmax * a.C + c) * a.D;
+  double *ckv = MET_DENSE ? a.ckv + ((size_t)tmax * a.C + c) * a.D : nullptr;
+  double kd = 0.0;
+  for (long long i = lane; i < a.D; i += 64) {
+    double p = a.cur_p[row + i];
+    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, p);
+    kd += v * p;
+    double s = (step == 0) ? p : a.psub[row + i] + p;  // trajectory.py:278,243
+    a.psub[row + i] = s;
+    if (even) {  // termination.py:115-124
+      ckp[i] = p;
+      cks[i] = s;
+      if (MET_DENSE) ckv[i] = v;
+    }
+  }
+  kd = wave_sum(kd);
+  ct.tmin = tmin;
+  ct.tmax = tmax;
+  // proposals.py:19-62
+  const double E = ct.U_cur + 0.5 * kd;
+  double delta = ct.H0 - E;
+  if (isnan(delta)) delta = -INFINITY;
+  const bool div = fabs(delta) > a.thr;
+  const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
+  bool term = false;
+  if (step == 0) {
+    ct.sub_E = E;
+    ct.sub_w = np_w;
+    ct.sub_slpa = np_slpa;
+    ct.length = 1;
+    copy_cur_to_slot<MET_DENSE>(a, row, lane, ct.prop_slot ^ 1);
+    ct.U_slot[ct.prop_slot ^ 1] = ct.U_cur;
+  } else {
+    // progressive_uniform_sampling proposals.py:72-102
+    double pa = 1.0 / (1.0 + exp(-(np_w - ct.sub_w)));
+    if (isnan(pa)) pa = 0.0;
+    Pcg64 g3 = pcg_load(a.rng + ((size_t)c * a.nsites + 2) * 4);
+    int acc = rng_bernoulli(g3, pa);
+    if (lane == 0) pcg_store(a.rng + ((size_t)c * a.nsites + 2) * 4, g3);
+    ct.sub_w = np_logaddexp(ct.sub_w, np_w);
+    ct.sub_slpa = np_logaddexp(ct.sub_slpa, np_slpa);
+    if (acc) {
+      ct.sub_E = E;
+      if (!ct.phantom) {
+        copy_cur_to_slot<MET_DENSE>(a, row, lane, ct.prop_slot ^ 1);
+        ct.U_slot[ct.prop_slot ^ 1] = ct.U_cur;
+      }
+    }
+    ct.length += 1;
+    // is_iterative_turning termination.py:133-187
+    if (tmax >= tmin) {
+      int idx = tmax;
+      bool crit = false;
+      for (;;) {
+        const double *kp = a.ckp + ((size_t)idx * a.C + c) * a.D;
+        const double *ks = a.cks + ((size_t)idx * a.C + c) * a.D;
+        const double *kv = MET_DENSE ? a.ckv + ((size_t)idx * a.C + c) * a.D : nullptr;
+        double d_l = 0.0, d_r = 0.0;
+        for (long long i = lane; i < a.D; i += 64) {
+          double pl = kp[i], pr = a.cur_p[row + i];
+          double vl = MET_DENSE ? kv[i] : vel_diag(a, i, pl);
+          double vr = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, pr);
+          double sub = a.psub[row + i] - ks[i] + pl;
+          double rho = sub - (pr + pl) / 2;
+          d_l += vl * rho;
+          d_r += vr * rho;
+        }
+        d_l = wave_sum(d_l);
+        d_r = wave_sum(d_r);
+        crit = (d_l <= 0) | (d_r <= 0);
+        bool reached = (idx - 1) < tmin;
+        idx -= 1;
+        if (crit || reached) break;
+      }
+      term = crit;
+    }
+  }
+  if (step == 0 && div && !ct.phantom) {
+    // trajectory.py:336: integrate() returns the first-step tuple, yet the scan still
+    // executes (and draws from site #3): finalize now, keep stepping as a phantom.
+    nuts_finalize_expansion<MET_DENSE>(a, c, lane, ct, true, false);
+    ct.done = 0;
+    ct.phantom = 1;
+    ct.step = 1;
+  } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
+    if (ct.phantom) ct.done = 1;
+    else nuts_finalize_expansion<MET_DENSE>(a, c, lane, ct, div, term);
+  } else {
+    ct.step = step + 1;
+  }
+  if (lane == 0) a.ctl[c] = ct;
+}
+
+// nuts.py:113-125 after the momentum is in cur_p (and cur_v for a dense metric)
+template <bool MET_DENSE>
+__device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lane) {
+  const size_t row = (size_t)c * a.D;
+  double kd = 0.0;
+  for (long long i = lane; i < a.D; i += 64) {
+    double q = a.q[row + i], g = a.g[row + i], p = a.cur_p[row + i];
+    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, p);
+    kd += v * p;
+    a.cur_q[row + i] = q;
+    a.cur_g[row + i] = g;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      a.end_q[e][row + i] = q;
+      a.end_p[e][row + i] = p;
+      a.end_g[e][row + i] = g;
+      if (MET_DENSE) a.end_v[e][row + i] = v;
+    }
+    a.slot_q[0][row + i] = q;
+    a.slot_p[0][row + i] = p;
+    a.slot_g[0][row + i] = g;
+    a.psum[row + i] = p;
+  }
+  kd = wave_sum(kd);
+  ChainCtl ct;
+  const double U = a.U[c];
+  ct.H0 = U + 0.5 * kd;
+  ct.prop_E = ct.H0;
+  ct.prop_w = 0.0;
+  ct.prop_slpa = -INFINITY;
+  ct.sub_E = ct.sub_w = ct.sub_slpa = 0.0;
+  ct.U_cur = ct.U_end[0] = ct.U_end[1] = ct.U_slot[0] = ct.U_slot[1] = U;
+  ct.acc_prob = 0.0;
+  ct.nleap = 0;
+  ct.j = 0;
+  ct.length = 0;
+  ct.tmin = ct.tmax = 0;
+  ct.done = ct.phantom = 0;
+  ct.prop_slot = 0;
+  ct.ndoubl = ct.out_div = ct.out_turn = ct.hmc_accept = 0;
+  nuts_begin_expansion<MET_DENSE>(a, c, lane, ct, -1);
+  if (lane == 0) a.ctl[c] = ct;
+}
+
+// metrics.py:65-68: z ~ N(0, I) from site #1; diagonal metric scales in place,
+// dense metric stages z for the GEMM with L^-T.
+template <bool MET_DENSE>
+__device__ inline void draw_momentum(const EngineArgs &a, long long c, int lane) {
+  const size_t row = (size_t)c * a.D;
+  Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4);
+  double *dst = MET_DENSE ? a.zbuf : a.cur_p;
+  const double *sm = a.sqrt_mass;
+  const bool scalar = a.met_ndim == 0;
+  wave_normals(g1, a.D, [=](long long i, double z) {
+    dst[row + i] = MET_DENSE ? z : (scalar ? sm[0] : sm[i]) * z;
+  });
+  if (lane == 0) pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
+  __threadfence_block();  // elements were written by arbitrary lanes of this wave
+}
+
+// ------------------------------------------------------------------- kernels ------
+#define AEHMC_CHAIN_OF_WAVE()                                                   \
+  const int lane = threadIdx.x & 63;                                            \
+  const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+  if (c >= a.C) return;
+
+template <bool MET_DENSE>
+__global__ __launch_bounds__(256) void k_nuts_draw(EngineArgs a) {
+  AEHMC_CHAIN_OF_WAVE();
+  draw_momentum<MET_DENSE>(a, c, lane);
+}
+template <bool MET_DENSE>
+__global__ __launch_bounds__(256) void k_nuts_init(EngineArgs a) {
+  AEHMC_CHAIN_OF_WAVE();
+  nuts_init_chain<MET_DENSE>(a, c, lane);
+}
+__global__ __launch_bounds__(256) void k_nuts_begin_diag(EngineArgs a) {
+  AEHMC_CHAIN_OF_WAVE();
+  draw_momentum<false>(a, c, lane);
+  nuts_init_chain<false>(a, c, lane);
+}
+// MODE: stage set; BOOK: run the NUTS bookkeeping afterwards
+template <bool DO1, bool DO2, bool DO3, bool MET_DENSE, bool BOOK>
+__global__ __launch_bounds__(256) void k_step(EngineArgs a) {
+  AEHMC_CHAIN_OF_WAVE();
+  ChainCtl ct = a.ctl[c];
+  if (ct.done) return;
+  double U_new = 0.0;
+  bool has_U = false;
+  if (DO1 || DO2 || DO3) has_U = leap_stages<DO1, DO2, DO3, MET_DENSE>(a, c, lane, ct.dir, U_new);
+  if (BOOK) {
+    if (has_U) ct.U_cur = U_new;
+    nuts_book<MET_DENSE>(a, c, lane, ct);
+  } else if (has_U && lane == 0) {
+    a.ctl[c].U_cur = U_new;
+  }
+}
+
+__global__ void k_count_active(const ChainCtl *ctl, long long C, int *out) {
+  __shared__ int s;
+  if (threadIdx.x == 0) s = 0;
+  __syncthreads();
+  int n = 0;
+  for (long long c = threadIdx.x; c < C; c += blockDim.x) n += ctl[c].done ? 0 : 1;
+  atomicAdd(&s, n);
+  __syncthreads();
+  if (threadIdx.x == 0) *out = s;
+}
+
+// ---- HMC (hmc.py:77-124, 157-204; trajectory.py:31-107) ---------------------------
+template <bool MET_DENSE>
+__device__ inline void hmc_init_chain(const EngineArgs &a, long long c, int lane) {
+  const size_t row = (size_t)c * a.D;
+  double kd = 0.0;
+  for (long long i = lane; i < a.D; i += 64) {
+    double p = a.cur_p[row + i];
+    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, p);
+    kd += v * p;
+    a.cur_q[row + i] = a.q[row + i];
+    a.cur_g[row + i] = a.g[row + i];
+    a.slot_p[0][row + i] = p;  // initial momentum, returned on rejection
+  }
+  kd = wave_sum(kd);
+  ChainCtl ct = {};
+  ct.U_cur = a.U[c];
+  ct.H0 = ct.U_cur + 0.5 * kd;  // hmc.py:187
+  ct.dir = 1;
+  if (lane == 0) a.ctl[c] = ct;
+}
+template <bool MET_DENSE>
+__global__ __launch_bounds__(256) void k_hmc_init(EngineArgs a) {
+  AEHMC_CHAIN_OF_WAVE();
+  hmc_init_chain<MET_DENSE>(a, c, lane);
+}
+__global__ __launch_bounds__(256) void k_hmc_begin_diag(EngineArgs a) {
+  AEHMC_CHAIN_OF_WAVE();
+  draw_momentum<false>(a, c, lane);
+  hmc_init_chain<false>(a, c, lane);
+}
+template <bool MET_DENSE>
+__global__ __launch_bounds__(256) void k_hmc_end(EngineArgs a, long long L) {
+  AEHMC_CHAIN_OF_WAVE();
+  const size_t row = (size_t)c * a.D;
+  ChainCtl ct = a.ctl[c];
+  double kd = 0.0;
+  for (long long i = lane; i < a.D; i += 64) {
+    double p = -1.0 * a.cur_p[row + i];  // hmc.py:185 momentum flip
+    double v = MET_DENSE ? -1.0 * a.cur_v[row + i] : vel_diag(a, i, p);
+    kd += v * p;
+  }
+  kd = wave_sum(kd);
+  double new_energy = ct.U_cur + 0.5 * kd;
+  double delta = ct.H0 - new_energy;
+  if (isnan(delta)) delta = -INFINITY;
+  int is_div = fabs(delta) > a.thr;
+  double pa = exp(delta);
+  if (pa > 1.0) pa = 1.0;
+  if (pa < 0.0) pa = 0.0;
+  Pcg64 g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
+  int acc = rng_bernoulli(g2, pa);  // hmc.py:193-194
+  if (lane == 0) pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
+  for (long long i = lane; i < a.D; i += 64) {
+    if (acc) {
+      a.q[row + i] = a.cur_q[row + i];
+      a.g[row + i] = a.cur_g[row + i];
+      if (a.out.momentum) a.out.momentum[row + i] = -1.0 * a.cur_p[row + i];
+    } else if (a.out.momentum) {
+      a.out.momentum[row + i] = a.slot_p[0][row + i];
+    }
+  }
+  if (lane == 0) {
+    if (acc) a.U[c] = ct.U_cur;
+    a.out.acceptance_probability[c] = pa;
+    a.out.is_diverging[c] = is_div;
+    if (a.out.n_leapfrog) a.out.n_leapfrog[c] = L;
+    if (a.out.is_turning) a.out.is_turning[c] = acc;  // HMC: reused as the accept flag
+  }
+}
+
+// ---- new_state / stand-alone building blocks --------------------------------------
+__global__ __launch_bounds__(256) void k_new_state_elem(EngineArgs a) {
+  AEHMC_CHAIN_OF_WAVE();
+  const size_t row = (size_t)c * a.D;
+  double usum = 0.0;
+  for (long long i = lane; i < a.D; i += 64) {
+    double u, g;
+    target_elem(a, i, a.q[row + i], u, g);
+    usum += u;
+    a.g[row + i] = g;
+  }
+  usum = wave_sum(usum);
+  if (lane == 0) a.U[c] = target_finish(a, usum);
+}
+__global__ __launch_bounds__(256) void k_residual(EngineArgs a, const double *q, double *r) {
+  AEHMC_CHAIN_OF_WAVE();
+  const size_t row = (size_t)c * a.D;
+  for (long long i = lane; i < a.D; i += 64) r[row + i] = q[row + i] - a.mu[i];
+}
+__global__ __launch_bounds__(256) void k_half_dot(EngineArgs a, const double *x, const double *y,
+                                                  double *out) {
+  AEHMC_CHAIN_OF_WAVE();
+  const size_t row = (size_t)c * a.D;
+  double s = 0.0;
+  for (long long i = lane; i < a.D; i += 64) s += x[row + i] * y[row + i];
+  s = wave_sum(s);
+  if (lane == 0) out[c] = 0.5 * s;
+}
+__global__ __launch_bounds__(256) void k_vel_diag(EngineArgs a, const double *p, double *v) {
+  AEHMC_CHAIN_OF_WAVE();
+  const size_t row = (size_t)c * a.D;
+  for (long long i = lane; i < a.D; i += 64) v[row + i] = vel_diag(a, i, p[row + i]);
+}
+__global__ __launch_bounds__(256) void k_is_turning(EngineArgs a, const double *pl, const double *pr,
+                                                    const double *ps, const double *vl,
+                                                    const double *vr, int32_t *out) {
+  AEHMC_CHAIN_OF_WAVE();
+  const size_t row = (size_t)c * a.D;
+  double d_l = 0.0, d_r = 0.0;
+  for (long long i = lane; i < a.D; i += 64) {
+    double rho = ps[row + i] - (pr[row + i] + pl[row + i]) / 2;
+    d_l += vl[row + i] * rho;
+    d_r += vr[row + i] * rho;
+  }
+  d_l = wave_sum(d_l);
+  d_r = wave_sum(d_r);
+  if (lane == 0) out[c] = (d_l <= 0) | (d_r <= 0);
+}
+// leapfrog-only driver state: ctl.dir = 1, U in ctl
+__global__ __launch_bounds__(256) void k_ctl_set(EngineArgs a, const double *U) {
+  AEHMC_CHAIN_OF_WAVE();
+  if (lane == 0) {
+    ChainCtl ct = {};
+    ct.dir = 1;
+    ct.U_cur = U[c];
+    a.ctl[c] = ct;
+  }
+}
+__global__ __launch_bounds__(256) void k_ctl_get_U(EngineArgs a, double *U) {
+  AEHMC_CHAIN_OF_WAVE();
+  if (lane == 0) U[c] = a.ctl[c].U_cur;
+}
+__global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C, long long n,
+                                                     double *out) {
+  const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  Pcg64 g = pcg_load(rng + c * 4);
+  wave_normals(g, n, [=](long long i, double z) { out[c * n + i] = z; });
+  if ((threadIdx.x & 63) == 0) pcg_store(rng + c * 4, g);
+}
+__global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long C, long long n,
+                                                       const double *p, int32_t *out) {
+  const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  Pcg64 g = pcg_load(rng + c * 4);
+  for (long long i = 0; i < n; i++) {
+    int b = rng_bernoulli(g, p[c * n + i]);
+    if ((threadIdx.x & 63) == 0) out[c * n + i] = b;
+  }
+  if ((threadIdx.x & 63) == 0) pcg_store(rng + c * 4, g);
+}
+__global__ void k_log(const double *x, double *y, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = log(x[i]);
+}
+
+}  // namespace aehmc

@@ -1,0 +1,493 @@
+// Host side of libaehmc_hip.so: the C-ABI of include/aehmc_hip.h over the gfx950 kernels
+// in engine.cuh / gemm_f64.cuh / hmc_fused.cuh.  No torch types, no CPU fallback: every
+// entry point launches HIP kernels or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/aehmc_hip.h"
+#include "engine.cuh"
+#include "gemm_f64.cuh"
+#include "hmc_fused.cuh"
+
+using namespace aehmc;
+
+namespace {
+constexpr int NRING = 4;       // pinned "chains still active" slots
+constexpr int STEP_BATCH = 8;  // lock-step leapfrogs between two polls
+constexpr size_t PROF_POOL = 8192;
+}  // namespace
+
+struct aehmc_ctx {
+  int device = 0;
+  std::string err;
+  aehmc_target tgt{};
+  bool has_tgt = false;
+  aehmc_metric met{};
+  bool has_met = false;
+  double *log_sigma = nullptr;
+  void *ws = nullptr;
+  int64_t ws_bytes = 0;
+  int *h_active = nullptr;  // pinned, device-visible
+  int *d_active = nullptr;
+  hipEvent_t ev[NRING] = {};
+  bool opt_fused_hmc = true;
+  // profiling of the dominant (GEMM / fused) kernel with HIP events on the launch stream
+  bool prof = false;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
+  double prof_ms = 0.0;
+  int64_t prof_n = 0;
+};
+
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+      return -1;                                                                         \
+    }                                                                                    \
+  } while (0)
+#define FAIL(msg)        \
+  do {                   \
+    ctx->err = (msg);    \
+    return -2;           \
+  } while (0)
+
+static inline dim3 chain_grid(int64_t C) { return dim3((unsigned)((C + 3) / 4)); }
+
+// ------------------------------------------------------------------ ctx ------------
+extern "C" int aehmc_create(aehmc_ctx **out, int device) {
+  if (!out) return -2;
+  aehmc_ctx *ctx = new aehmc_ctx();
+  ctx->device = device;
+  *out = ctx;
+  HIPCHK(hipSetDevice(device));
+  // LCG jump-ahead table: state_{t+n} = A^n state_t + G_n inc  (rng.cuh)
+  uint64_t jump[64][4];
+  u128 A = 1, G = 0;
+  for (int k = 0; k < 64; k++) {
+    G = G * AEHMC_PCG_MULT + 1;  // G_{k+1} = A * G_k + 1
+    A = A * AEHMC_PCG_MULT;
+    jump[k][0] = (uint64_t)(A >> 64);
+    jump[k][1] = (uint64_t)A;
+    jump[k][2] = (uint64_t)(G >> 64);
+    jump[k][3] = (uint64_t)G;
+  }
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_pcg_jump), jump, sizeof(jump)));
+  HIPCHK(hipHostMalloc((void **)&ctx->h_active, NRING * sizeof(int), hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void **)&ctx->d_active, ctx->h_active, 0));
+  for (int i = 0; i < NRING; i++) HIPCHK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+  return 0;
+}
+
+extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
+  if (!ctx) return 0;
+  hipSetDevice(ctx->device);
+  if (ctx->log_sigma) hipFree(ctx->log_sigma);
+  if (ctx->h_active) hipHostFree(ctx->h_active);
+  for (int i = 0; i < NRING; i++)
+    if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+  for (auto e : ctx->prof_ev) hipEventDestroy(e);
+  delete ctx;
+  return 0;
+}
+
+extern "C" const char *aehmc_last_error(const aehmc_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *t) {
+  if (!ctx || !t) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (t->D <= 0) FAIL("target: D must be positive");
+  switch (t->kind) {
+    case AEHMC_T_STD_NORMAL:
+    case AEHMC_T_ISO_GAUSSIAN:
+      break;
+    case AEHMC_T_DIAG_GAUSSIAN:
+      if (!t->mu || !t->sigma) FAIL("diag gaussian target needs mu and sigma");
+      break;
+    case AEHMC_T_DENSE_MVN:
+      if (!t->mu || !t->prec) FAIL("dense MVN target needs mu and prec");
+      break;
+    case AEHMC_T_LINREG:
+      if (!t->X || !t->y || t->N <= 0 || t->D != 2) FAIL("linreg target needs X, y, N and D == 2");
+      break;
+    default:
+      FAIL("unknown target kind");
+  }
+  ctx->tgt = *t;
+  ctx->has_tgt = true;
+  if (ctx->log_sigma) {
+    HIPCHK(hipFree(ctx->log_sigma));
+    ctx->log_sigma = nullptr;
+  }
+  if (t->kind == AEHMC_T_DIAG_GAUSSIAN) {
+    HIPCHK(hipMalloc((void **)&ctx->log_sigma, t->D * sizeof(double)));
+    hipLaunchKernelGGL(k_log, dim3((unsigned)((t->D + 255) / 256)), dim3(256), 0, 0, t->sigma,
+                       ctx->log_sigma, (long long)t->D);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+  }
+  return 0;
+}
+
+extern "C" int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *m) {
+  if (!ctx || !m) return -2;
+  if (m->ndim < 0 || m->ndim > 2)  // metrics.py:60-63
+    FAIL("Expected a mass matrix of dimension 1 (diagonal) or 2, got " + std::to_string(m->ndim));
+  if (!m->imm || !m->sqrt_mass || m->D <= 0) FAIL("metric needs imm, sqrt_mass and D");
+  ctx->met = *m;
+  ctx->has_met = true;
+  return 0;
+}
+
+extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value) {
+  if (!ctx || !name) return -2;
+  if (!strcmp(name, "fused_hmc")) {
+    ctx->opt_fused_hmc = value != 0;
+    return 0;
+  }
+  FAIL(std::string("unknown option ") + name);
+}
+
+// ------------------------------------------------------------------ workspace ------
+static int64_t ws_layout(const aehmc_ctx *ctx, int64_t C, int64_t E, char *base, EngineArgs *a) {
+  const bool md = ctx->has_met && ctx->met.ndim == 2;
+  const int64_t D = ctx->has_tgt ? ctx->tgt.D : (ctx->has_met ? ctx->met.D : 0);
+  const size_t vec = (((size_t)C * D * sizeof(double)) + 255) & ~(size_t)255;
+  size_t off = 0;
+  auto take = [&](size_t n) -> double * {
+    double *p = base ? reinterpret_cast<double *>(base + off) : nullptr;
+    off += n;
+    return p;
+  };
+  EngineArgs tmp{};
+  EngineArgs &r = a ? *a : tmp;
+  r.cur_q = take(vec); r.cur_p = take(vec); r.cur_g = take(vec);
+  for (int e = 0; e < 2; e++) { r.end_q[e] = take(vec); r.end_p[e] = take(vec); r.end_g[e] = take(vec); }
+  for (int s = 0; s < 2; s++) { r.slot_q[s] = take(vec); r.slot_p[s] = take(vec); r.slot_g[s] = take(vec); }
+  r.psum = take(vec); r.psub = take(vec);
+  r.ckp = take(vec * E); r.cks = take(vec * E);
+  r.vhalf = take(vec); r.rbuf = take(vec); r.zbuf = take(vec);
+  if (md) {
+    r.cur_v = take(vec);
+    r.end_v[0] = take(vec); r.end_v[1] = take(vec);
+    r.ckv = take(vec * E);
+  }
+  r.ctl = reinterpret_cast<ChainCtl *>(take(((size_t)C * sizeof(ChainCtl) + 255) & ~(size_t)255));
+  return (int64_t)off;
+}
+
+extern "C" int64_t aehmc_workspace_bytes(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions) {
+  if (!ctx || !ctx->has_tgt || !ctx->has_met) return -2;
+  if (max_num_expansions < 1) max_num_expansions = 1;
+  return ws_layout(ctx, C, max_num_expansions, nullptr, nullptr);
+}
+extern "C" int aehmc_set_workspace(aehmc_ctx *ctx, void *ws, int64_t bytes) {
+  if (!ctx) return -2;
+  if (((uintptr_t)ws) % 256 != 0) FAIL("workspace must be 256-byte aligned");
+  ctx->ws = ws;
+  ctx->ws_bytes = bytes;
+  return 0;
+}
+
+static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a) {
+  if (!ctx->has_tgt || !ctx->has_met) FAIL("set_target and set_metric must be called first");
+  if (ctx->tgt.D != ctx->met.D) FAIL("target and metric dimensions differ");
+  if (C <= 0) FAIL("C must be positive");
+  memset(&a, 0, sizeof(a));
+  int64_t need = ws_layout(ctx, C, E, (char *)ctx->ws, &a);
+  if (!ctx->ws || need > ctx->ws_bytes)
+    FAIL("workspace too small: need " + std::to_string(need) + " bytes");
+  a.C = C;
+  a.D = ctx->tgt.D;
+  a.max_exp = (int)E;
+  a.met_ndim = ctx->met.ndim;
+  a.imm = ctx->met.imm;
+  a.sqrt_mass = ctx->met.sqrt_mass;
+  a.tkind = ctx->tgt.kind;
+  a.mu = ctx->tgt.mu;
+  a.sigma = ctx->tgt.sigma;
+  a.log_sigma = ctx->log_sigma;
+  return 0;
+}
+
+// ------------------------------------------------------------------ GEMM + profiling
+static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
+                const double *B, int64_t ldb, double *Cm, int64_t ldc, hipStream_t st) {
+  const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
+  if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+  HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st));
+  if (p) {
+    HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
+    ctx->prof_used += 2;
+  }
+  return 0;
+}
+
+extern "C" int aehmc_profile_enable(aehmc_ctx *ctx, int enable) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (enable && ctx->prof_ev.empty()) {
+    ctx->prof_ev.resize(PROF_POOL);
+    for (auto &e : ctx->prof_ev) HIPCHK(hipEventCreate(&e));
+  }
+  ctx->prof = enable != 0;
+  ctx->prof_used = 0;
+  ctx->prof_ms = 0.0;
+  ctx->prof_n = 0;
+  return 0;
+}
+extern "C" int aehmc_profile_read(aehmc_ctx *ctx, double *ms_total, int64_t *launches) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+    HIPCHK(hipEventSynchronize(ctx->prof_ev[i + 1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+    ctx->prof_ms += ms;
+    ctx->prof_n += 1;
+  }
+  ctx->prof_used = 0;
+  if (ms_total) *ms_total = ctx->prof_ms;
+  if (launches) *launches = ctx->prof_n;
+  return 0;
+}
+
+extern "C" int aehmc_gemm_nt(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A,
+                             int64_t lda, const double *B, int64_t ldb, double *Cm, int64_t ldc,
+                             void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  return gemm(ctx, M, N, K, A, lda, B, ldb, Cm, ldc, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ leapfrog driver
+#define LAUNCH(kern, C, st, ...)                                                      \
+  do {                                                                                \
+    hipLaunchKernelGGL(kern, chain_grid(C), dim3(256), 0, st, __VA_ARGS__);           \
+    HIPCHK(hipGetLastError());                                                        \
+  } while (0)
+
+// one lock-step leapfrog of every live chain (integrators.py:54-73); `book` appends the
+// NUTS bookkeeping; `need_v` says whether v' = imm p' must be formed (dense metric)
+static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool need_v, hipStream_t st) {
+  const bool md = a.met_ndim == 2;
+  const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
+  const int64_t C = a.C, D = a.D;
+  if (a.tkind == AEHMC_T_LINREG) FAIL("linreg target: not implemented on the lock-step path yet");
+  if (!md && !tdense) {
+    if (book) LAUNCH((k_step<true, true, true, false, true>), C, st, a);
+    else LAUNCH((k_step<true, true, true, false, false>), C, st, a);
+    return 0;
+  }
+  if (!md && tdense) {
+    LAUNCH((k_step<true, true, false, false, false>), C, st, a);
+    if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st)) return -1;
+    if (book) LAUNCH((k_step<false, false, true, false, true>), C, st, a);
+    else LAUNCH((k_step<false, false, true, false, false>), C, st, a);
+    return 0;
+  }
+  // dense metric
+  LAUNCH((k_step<true, false, false, true, false>), C, st, a);
+  if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.vhalf, D, st)) return -1;
+  if (!tdense) {
+    LAUNCH((k_step<false, true, true, true, false>), C, st, a);
+  } else {
+    LAUNCH((k_step<false, true, false, true, false>), C, st, a);
+    if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st)) return -1;
+    LAUNCH((k_step<false, false, true, true, false>), C, st, a);
+  }
+  if (need_v || book)
+    if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.cur_v, D, st)) return -1;
+  if (book) LAUNCH((k_step<false, false, false, true, true>), C, st, a);
+  return 0;
+}
+
+// momentum draw (metrics.py:65-68) + per-chain init, for both samplers
+static int launch_begin(aehmc_ctx *ctx, const EngineArgs &a, bool nuts, hipStream_t st) {
+  const bool md = a.met_ndim == 2;
+  const int64_t C = a.C, D = a.D;
+  if (!md) {
+    if (nuts) LAUNCH(k_nuts_begin_diag, C, st, a);
+    else LAUNCH(k_hmc_begin_diag, C, st, a);
+    return 0;
+  }
+  LAUNCH(k_nuts_draw<true>, C, st, a);
+  if (gemm(ctx, C, D, D, a.zbuf, D, ctx->met.sqrt_mass, D, a.cur_p, D, st)) return -1;  // p = L^-T z
+  if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.cur_v, D, st)) return -1;
+  if (nuts) LAUNCH(k_nuts_init<true>, C, st, a);
+  else LAUNCH(k_hmc_init<true>, C, st, a);
+  return 0;
+}
+
+// ------------------------------------------------------------------ API ------------
+extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, double *U, double *g,
+                               void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  EngineArgs a;
+  if (ctx->has_tgt && target_is_elem_host(ctx->tgt.kind)) {
+    if (!ctx->has_tgt) FAIL("set_target must be called first");
+    memset(&a, 0, sizeof(a));
+    a.C = C; a.D = ctx->tgt.D; a.tkind = ctx->tgt.kind;
+    a.mu = ctx->tgt.mu; a.sigma = ctx->tgt.sigma; a.log_sigma = ctx->log_sigma;
+    a.q = const_cast<double *>(q); a.U = U; a.g = g;
+    LAUNCH(k_new_state_elem, C, st, a);
+    return 0;
+  }
+  if (int rc = fill_args(ctx, C, 1, a)) return rc;
+  if (a.tkind == AEHMC_T_DENSE_MVN) {
+    LAUNCH(k_residual, C, st, a, q, a.rbuf);
+    if (gemm(ctx, C, a.D, a.D, a.rbuf, a.D, ctx->tgt.prec, a.D, g, a.D, st)) return -1;
+    LAUNCH(k_half_dot, C, st, a, (const double *)a.rbuf, (const double *)g, U);
+    return 0;
+  }
+  FAIL("new_state: target kind not implemented");
+}
+
+extern "C" int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                               int64_t max_num_expansions, double divergence_threshold, double *q,
+                               double *U, double *g, const aehmc_diagnostics *out, void *stream) {
+  if (!ctx || !out) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (max_num_expansions < 1 || max_num_expansions > 20) FAIL("max_num_expansions must be in [1, 20]");
+  if (!out->acceptance_probability || !out->is_diverging) FAIL("diagnostics arrays missing");
+  EngineArgs a;
+  if (int rc = fill_args(ctx, C, max_num_expansions, a)) return rc;
+  a.eps = step_size; a.thr = divergence_threshold;
+  a.rng = rng; a.nsites = 4;
+  a.q = q; a.U = U; a.g = g; a.out = *out;
+  if (int rc = launch_begin(ctx, a, true, st)) return rc;
+  long long maxsteps = 0;
+  for (int j = 0; j < max_num_expansions; j++) maxsteps += (1LL << j) + 1;  // 2**j + 1 per expansion
+  long long s = 0;
+  int batch = 0;
+  while (s < maxsteps) {
+    if (batch >= 2) {  // lagging poll: never drains the queue
+      int slot = (batch - 2) % NRING;
+      HIPCHK(hipEventSynchronize(ctx->ev[slot]));
+      if (ctx->h_active[slot] == 0) break;
+    }
+    for (int k = 0; k < STEP_BATCH && s < maxsteps; k++, s++)
+      if (int rc = launch_leapfrog(ctx, a, true, true, st)) return rc;
+    int slot = batch % NRING;
+    hipLaunchKernelGGL(k_count_active, dim3(1), dim3(1024), 0, st, (const ChainCtl *)a.ctl,
+                       (long long)C, ctx->d_active + slot);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[slot], st));
+    batch++;
+  }
+  return 0;
+}
+
+extern "C" int aehmc_hmc_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                              int64_t L, double divergence_threshold, double *q, double *U,
+                              double *g, const aehmc_diagnostics *out, void *stream) {
+  if (!ctx || !out) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (L < 0) FAIL("num_integration_steps must be >= 0");
+  if (!out->acceptance_probability || !out->is_diverging) FAIL("diagnostics arrays missing");
+  if (!ctx->has_tgt || !ctx->has_met) FAIL("set_target and set_metric must be called first");
+  // fused register-resident path (hmc_fused.cuh): diagonal/scalar metric, coordinate-wise target
+  if (ctx->opt_fused_hmc && hmc_fused_supported(ctx->tgt.kind, ctx->met.ndim, ctx->tgt.D)) {
+    HmcFusedArgs f{};
+    f.C = C; f.D = ctx->tgt.D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
+    f.met_ndim = ctx->met.ndim; f.imm = ctx->met.imm; f.sqrt_mass = ctx->met.sqrt_mass;
+    f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
+    f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
+    const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
+    if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+    HIPCHK(launch_hmc_fused(f, st));
+    if (p) {
+      HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
+      ctx->prof_used += 2;
+    }
+    return 0;
+  }
+  EngineArgs a;
+  if (int rc = fill_args(ctx, C, 1, a)) return rc;
+  a.eps = step_size; a.thr = divergence_threshold;
+  a.rng = rng; a.nsites = 2;
+  a.q = q; a.U = U; a.g = g; a.out = *out;
+  if (int rc = launch_begin(ctx, a, false, st)) return rc;
+  for (int64_t l = 0; l < L; l++)
+    if (int rc = launch_leapfrog(ctx, a, false, l == L - 1, st)) return rc;
+  if (a.met_ndim == 2) LAUNCH(k_hmc_end<true>, C, st, a, (long long)L);
+  else LAUNCH(k_hmc_end<false>, C, st, a, (long long)L);
+  return 0;
+}
+
+extern "C" int aehmc_leapfrog(aehmc_ctx *ctx, int64_t C, double step_size, int64_t nsteps, double *q,
+                              double *p, double *U, double *g, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  EngineArgs a;
+  if (int rc = fill_args(ctx, C, 1, a)) return rc;
+  a.eps = step_size;
+  a.cur_q = q; a.cur_p = p; a.cur_g = g;  // integrate the caller's arrays in place
+  LAUNCH(k_ctl_set, C, st, a, (const double *)U);
+  for (int64_t l = 0; l < nsteps; l++)
+    if (int rc = launch_leapfrog(ctx, a, false, false, st)) return rc;
+  LAUNCH(k_ctl_get_U, C, st, a, U);
+  return 0;
+}
+
+extern "C" int aehmc_kinetic_energy(aehmc_ctx *ctx, int64_t C, const double *p, double *K, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  EngineArgs a;
+  if (int rc = fill_args(ctx, C, 1, a)) return rc;
+  if (a.met_ndim == 2) {
+    if (gemm(ctx, C, a.D, a.D, p, a.D, ctx->met.imm, a.D, a.vhalf, a.D, st)) return -1;
+  } else {
+    LAUNCH(k_vel_diag, C, st, a, p, a.vhalf);
+  }
+  LAUNCH(k_half_dot, C, st, a, (const double *)a.vhalf, p, K);
+  return 0;
+}
+
+extern "C" int aehmc_is_turning(aehmc_ctx *ctx, int64_t C, const double *pl, const double *pr,
+                                const double *ps, int32_t *out, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  EngineArgs a;
+  if (int rc = fill_args(ctx, C, 1, a)) return rc;
+  if (a.met_ndim == 2) {
+    if (gemm(ctx, C, a.D, a.D, pl, a.D, ctx->met.imm, a.D, a.vhalf, a.D, st)) return -1;
+    if (gemm(ctx, C, a.D, a.D, pr, a.D, ctx->met.imm, a.D, a.zbuf, a.D, st)) return -1;
+  } else {
+    LAUNCH(k_vel_diag, C, st, a, pl, a.vhalf);
+    LAUNCH(k_vel_diag, C, st, a, pr, a.zbuf);
+  }
+  LAUNCH(k_is_turning, C, st, a, pl, pr, ps, (const double *)a.vhalf, (const double *)a.zbuf, out);
+  return 0;
+}
+
+extern "C" int aehmc_rng_normals(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t n, double *out,
+                                 void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_rng_normals, chain_grid(C), dim3(256), 0, (hipStream_t)stream, rng,
+                     (long long)C, (long long)n, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int aehmc_rng_bernoulli(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t n,
+                                   const double *p, int32_t *out, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_rng_bernoulli, chain_grid(C), dim3(256), 0, (hipStream_t)stream, rng,
+                     (long long)C, (long long)n, p, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

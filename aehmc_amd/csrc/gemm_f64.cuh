@@ -1,0 +1,180 @@
+// fp64 MFMA GEMM for the dense-metric / dense-precision path (gfx950).
+//
+//   Cmat[M,N] = A[M,K] * B[N,K]^T        (all row-major, K contiguous in both operands)
+//
+// This is the "p <- M^-1 p is a real GEMM" case of the north star: with a dense inverse
+// mass matrix the reference's per-chain gemv `at.dot(inverse_mass_matrix, momentum)`
+// (aehmc/metrics.py:71,95-96) and the dense target gradient become, over the chains of
+// one lock-step leapfrog, one [C,D] x [D,D] product.  Rows = chains, so every output
+// element's k-summation order is independent of how many chains are batched.
+//
+// Tiling (v_mfma_f64_16x16x4_f64, wave64): 128x128 block tile, BK = 16, 256 threads =
+// 4 waves in a 2x2 arrangement, each wave owning a 64x64 sub-tile = 4x4 MFMA tiles
+// (64 f64 accumulators / lane).  LDS rows are padded to 18 doubles so that the 32
+// lanes of a ds_read_b64 group (16 rows x 2 k) hit 32 distinct 8-byte slots.  Two LDS
+// stages, one barrier per K-tile; global loads for tile t+1 are issued before the MFMAs
+// of tile t.  Block ids are dealt to XCDs round-robin by the hardware, so each XCD is
+// given a contiguous run of column panels (all row tiles x 2 column tiles): a B panel is
+// then private to one XCD's L2 while the A panels are shared chip-wide through MALL.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aehmc {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16, GEMM_LDS = GEMM_BK + 2;
+constexpr int GEMM_PANEL_W = 2;
+
+struct GemmTileMap {
+  int tm, tn;
+  bool valid;
+};
+// block id -> tile; see header comment
+__device__ __forceinline__ GemmTileMap gemm_tile_of_block(int b, int Tm, int Tn) {
+  const int total = Tm * Tn;
+  const int chunk = (total + 7) / 8;
+  const int t = (b % 8) * chunk + (b / 8);
+  GemmTileMap r;
+  r.valid = (b / 8) < chunk && t < total;
+  const int per_panel = Tm * GEMM_PANEL_W;
+  const int nfull = Tn / GEMM_PANEL_W;
+  int panel = t / per_panel;
+  if (panel < nfull) {
+    int rr = t - panel * per_panel;
+    r.tn = panel * GEMM_PANEL_W + rr % GEMM_PANEL_W;
+    r.tm = rr / GEMM_PANEL_W;
+  } else {
+    int wlast = Tn - nfull * GEMM_PANEL_W;  // 1 when Tn is odd
+    int rr = t - nfull * per_panel;
+    if (wlast < 1) wlast = 1;
+    r.tn = nfull * GEMM_PANEL_W + rr % wlast;
+    r.tm = rr / wlast;
+  }
+  return r;
+}
+
+// loads this thread's 8 doubles of a 128 x 16 operand tile (row = tid/2, cols (tid&1)*8..+7)
+template <bool VEC>
+__device__ __forceinline__ void gemm_load_tile(const double *__restrict__ P, int64_t ld,
+                                               int64_t row0, int64_t nrows, int64_t k0,
+                                               int64_t K, int tid, double (&r)[8]) {
+  const int64_t row = row0 + (tid >> 1);
+  const int64_t k = k0 + (tid & 1) * 8;
+  if (row < nrows) {
+    const double *src = P + row * ld + k;
+    if (VEC && k + 8 <= K) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        d2_t v = *reinterpret_cast<const d2_t *>(src + 2 * i);
+        r[2 * i] = v[0];
+        r[2 * i + 1] = v[1];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) r[i] = (k + i < K) ? src[i] : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = 0.0;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
+    int64_t M, int64_t N, int64_t K, const double *__restrict__ A, int64_t lda,
+    const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][GEMM_BM][GEMM_LDS];  // [stage][A|B]
+  const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+  const GemmTileMap tile = gemm_tile_of_block(blockIdx.x, Tm, Tn);
+  if (!tile.valid) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)tile.tm * GEMM_BM, n0 = (int64_t)tile.tn * GEMM_BN;
+
+  d4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+  double ra[8], rb[8];
+  const int nk = (int)((K + GEMM_BK - 1) / GEMM_BK);
+  const int srow = tid >> 1, scol = (tid & 1) * 8;
+
+  gemm_load_tile<VEC>(A, lda, m0, M, 0, K, tid, ra);
+  gemm_load_tile<VEC>(B, ldb, n0, N, 0, K, tid, rb);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    *reinterpret_cast<d2_t *>(&lds[0][0][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
+    *reinterpret_cast<d2_t *>(&lds[0][1][srow][scol + 2 * i]) = (d2_t){rb[2 * i], rb[2 * i + 1]};
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int kt = 0; kt < nk; kt++) {
+    const int st = kt & 1;
+    if (kt + 1 < nk) {
+      gemm_load_tile<VEC>(A, lda, m0, M, (int64_t)(kt + 1) * GEMM_BK, K, tid, ra);
+      gemm_load_tile<VEC>(B, ldb, n0, N, (int64_t)(kt + 1) * GEMM_BK, K, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < GEMM_BK / 4; kk++) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = lds[st][0][wm * 64 + i * 16 + fr][kk * 4 + fk];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = lds[st][1][wn * 64 + j * 16 + fr][kk * 4 + fk];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        *reinterpret_cast<d2_t *>(&lds[st ^ 1][0][srow][scol + 2 * i]) =
+            (d2_t){ra[2 * i], ra[2 * i + 1]};
+        *reinterpret_cast<d2_t *>(&lds[st ^ 1][1][srow][scol + 2 * i]) =
+            (d2_t){rb[2 * i], rb[2 * i + 1]};
+      }
+    }
+    __syncthreads();
+  }
+
+  // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t col = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int64_t row = m0 + wm * 64 + i * 16 + fk + 4 * r;
+        if (row < M && col < N) Cm[row * ldc + col] = acc[i][j][r];
+      }
+    }
+}
+
+inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const double *A,
+                                     int64_t lda, const double *B, int64_t ldb, double *Cm,
+                                     int64_t ldc, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+  const int total = Tm * Tn;
+  const int grid = ((total + 7) / 8) * 8;
+  const bool vec = (lda % 2 == 0) && (ldb % 2 == 0) && ((uintptr_t)A % 16 == 0) &&
+                   ((uintptr_t)B % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL(gemm_nt_f64_kernel<true>, dim3(grid), dim3(256), 0, stream, M, N, K, A,
+                       lda, B, ldb, Cm, ldc);
+  else
+    hipLaunchKernelGGL(gemm_nt_f64_kernel<false>, dim3(grid), dim3(256), 0, stream, M, N, K, A,
+                       lda, B, ldb, Cm, ldc);
+  return hipGetLastError();
+}
+
+}  // namespace aehmc

@@ -1,0 +1,241 @@
+"""Host-side engine object: owns one C-ABI ctx on one GPU and the torch-allocated device
+buffers handed to it.  PyTorch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from . import _lib
+from .targets import Target
+
+
+def _dev_f64(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float64)), device=device)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    """One aehmc_ctx.  Not thread-safe (as the C-ABI)."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise EngineError("aehmc_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.lib = _lib.load()
+        ctx = ct.c_void_p()
+        rc = self.lib.aehmc_create(ct.byref(ctx), self.device.index or 0)
+        self.ctx = ctx
+        if rc:
+            raise EngineError(f"aehmc_create failed: {self._err()}")
+        self._target_key = None
+        self._metric_key = None
+        self._keep = {}
+        self._ws = None
+        self.D = None
+        self.metric_ndim = None
+        self.metric_D = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.aehmc_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    def _err(self):
+        return self.lib.aehmc_last_error(self.ctx).decode()
+
+    def _check(self, rc, what):
+        if rc:
+            raise EngineError(f"{what} failed ({rc}): {self._err()}")
+
+    @property
+    def stream(self):
+        return ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ binding
+    def set_target(self, target: Target, D: int):
+        key = (id(target), D)
+        if self._target_key == key:
+            return
+        p = {k: _dev_f64(v, self.device) for k, v in target.params().items()}
+        if target.dim is not None and target.dim != D:
+            raise ValueError(f"target has dimension {target.dim}, position has {D}")
+        c = _lib.CTarget(kind=target.kind, D=D, N=0)
+        for name in ("mu", "sigma", "prec", "X", "y"):
+            if name in p:
+                setattr(c, name, p[name].data_ptr())
+        if "X" in p:
+            c.N = p["X"].numel()
+        self._keep["target"] = (target, p)
+        self._check(self.lib.aehmc_set_target(self.ctx, ct.byref(c)), "aehmc_set_target")
+        self._target_key, self.D = key, D
+        self._ws = None
+
+    def set_metric(self, inverse_mass_matrix, D: int):
+        """gaussian_metric(inverse_mass_matrix) -- aehmc/metrics.py:44-63."""
+        imm = inverse_mass_matrix
+        ndim = imm.ndim if hasattr(imm, "ndim") else np.ndim(imm)
+        if ndim > 2:
+            raise ValueError(
+                f"Expected a mass matrix of dimension 1 (diagonal) or 2, got {ndim}")
+        if isinstance(imm, torch.Tensor):
+            key = (id(imm), imm._version, D)
+        else:  # numpy / python scalars may be mutated in place: key small ones by content
+            arr = np.asarray(imm, dtype=np.float64)
+            key = (id(imm), hash(arr.tobytes()) if arr.size <= 65536 else None, D)
+        if self._metric_key == key:
+            return
+        t = _dev_f64(imm, self.device)
+        if ndim == 2:
+            if t.shape != (D, D):
+                raise ValueError(f"dense inverse mass matrix must be [{D},{D}], got {tuple(t.shape)}")
+            if not torch.allclose(t, t.T, rtol=1e-12, atol=0):
+                raise ValueError("dense inverse mass matrix must be symmetric")
+            L = torch.linalg.cholesky(t)  # metrics.py:56
+            eye = torch.eye(D, dtype=torch.float64, device=self.device)
+            sqrt_mass = torch.linalg.solve_triangular(L.T.contiguous(), eye, upper=True).contiguous()
+        else:
+            t = t.reshape(-1)
+            if ndim == 1 and t.numel() != D:
+                raise ValueError(f"diagonal inverse mass matrix must have {D} entries")
+            sqrt_mass = torch.sqrt(torch.reciprocal(t))  # metrics.py:45,49
+        c = _lib.CMetric(ndim=ndim, D=D, imm=t.data_ptr(), sqrt_mass=sqrt_mass.data_ptr())
+        self._keep["metric"] = (imm, t, sqrt_mass)
+        self._check(self.lib.aehmc_set_metric(self.ctx, ct.byref(c)), "aehmc_set_metric")
+        if self.metric_ndim != ndim:
+            self._ws = None
+        self._metric_key, self.metric_ndim, self.metric_D = key, ndim, D
+
+    def ensure_workspace(self, C: int, max_exp: int):
+        need = self.lib.aehmc_workspace_bytes(self.ctx, C, max_exp)
+        if need < 0:
+            raise EngineError("aehmc_workspace_bytes: target/metric not set")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.aehmc_set_workspace(self.ctx, self._ws.data_ptr(), self._ws.numel()),
+                    "aehmc_set_workspace")
+
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.aehmc_set_option(self.ctx, name.encode(), int(value)), "aehmc_set_option")
+
+    # ------------------------------------------------------------------ calls
+    def new_state(self, q):
+        C, D = q.shape
+        U = torch.empty(C, dtype=torch.float64, device=self.device)
+        g = torch.empty_like(q)
+        self._check(self.lib.aehmc_new_state(self.ctx, C, q.data_ptr(), U.data_ptr(), g.data_ptr(),
+                                             self.stream), "aehmc_new_state")
+        return U, g
+
+    def _diag(self, C, D, nuts):
+        dev = self.device
+        out = dict(
+            momentum=torch.empty(C, D, dtype=torch.float64, device=dev),
+            acceptance_probability=torch.empty(C, dtype=torch.float64, device=dev),
+            num_doublings=torch.zeros(C, dtype=torch.int64, device=dev),
+            is_turning=torch.zeros(C, dtype=torch.int32, device=dev),
+            is_diverging=torch.zeros(C, dtype=torch.int32, device=dev),
+            n_leapfrog=torch.zeros(C, dtype=torch.int64, device=dev))
+        c = _lib.CDiagnostics(**{k: v.data_ptr() for k, v in out.items()})
+        return out, c
+
+    def hmc_step(self, rng, eps, L, thr, q, U, g):
+        C, D = q.shape
+        self.ensure_workspace(C, 1)
+        out, c = self._diag(C, D, False)
+        self._check(self.lib.aehmc_hmc_step(self.ctx, C, rng.data_ptr(), float(eps), int(L), float(thr),
+                                            q.data_ptr(), U.data_ptr(), g.data_ptr(), ct.byref(c),
+                                            self.stream), "aehmc_hmc_step")
+        return out
+
+    def nuts_step(self, rng, eps, max_exp, thr, q, U, g):
+        C, D = q.shape
+        self.ensure_workspace(C, max_exp)
+        out, c = self._diag(C, D, True)
+        self._check(self.lib.aehmc_nuts_step(self.ctx, C, rng.data_ptr(), float(eps), int(max_exp),
+                                             float(thr), q.data_ptr(), U.data_ptr(), g.data_ptr(),
+                                             ct.byref(c), self.stream), "aehmc_nuts_step")
+        return out
+
+    def leapfrog(self, eps, nsteps, q, p, U, g):
+        C, D = q.shape
+        self.ensure_workspace(C, 1)
+        self._check(self.lib.aehmc_leapfrog(self.ctx, C, float(eps), int(nsteps), q.data_ptr(),
+                                            p.data_ptr(), U.data_ptr(), g.data_ptr(), self.stream),
+                    "aehmc_leapfrog")
+
+    def kinetic_energy(self, p):
+        C, D = p.shape
+        self.ensure_workspace(C, 1)
+        K = torch.empty(C, dtype=torch.float64, device=self.device)
+        self._check(self.lib.aehmc_kinetic_energy(self.ctx, C, p.data_ptr(), K.data_ptr(), self.stream),
+                    "aehmc_kinetic_energy")
+        return K
+
+    def is_turning(self, pl, pr, ps):
+        C, D = pl.shape
+        self.ensure_workspace(C, 1)
+        out = torch.empty(C, dtype=torch.int32, device=self.device)
+        self._check(self.lib.aehmc_is_turning(self.ctx, C, pl.data_ptr(), pr.data_ptr(), ps.data_ptr(),
+                                              out.data_ptr(), self.stream), "aehmc_is_turning")
+        return out.bool()
+
+    def rng_normals(self, rng, n):
+        C = rng.shape[0]
+        out = torch.empty(C, n, dtype=torch.float64, device=self.device)
+        self._check(self.lib.aehmc_rng_normals(self.ctx, C, rng.data_ptr(), n, out.data_ptr(), self.stream),
+                    "aehmc_rng_normals")
+        return out
+
+    def rng_bernoulli(self, rng, p):
+        C, n = p.shape
+        out = torch.empty(C, n, dtype=torch.int32, device=self.device)
+        self._check(self.lib.aehmc_rng_bernoulli(self.ctx, C, rng.data_ptr(), n, p.data_ptr(),
+                                                 out.data_ptr(), self.stream), "aehmc_rng_bernoulli")
+        return out
+
+    def gemm_nt(self, A, B):
+        M, K = A.shape
+        N = B.shape[0]
+        out = torch.empty(M, N, dtype=torch.float64, device=self.device)
+        self._check(self.lib.aehmc_gemm_nt(self.ctx, M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(),
+                                           B.stride(0), out.data_ptr(), out.stride(0), self.stream),
+                    "aehmc_gemm_nt")
+        return out
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.aehmc_profile_enable(self.ctx, int(on)), "aehmc_profile_enable")
+
+    def profile_read(self):
+        ms, n = ct.c_double(), ct.c_int64()
+        self._check(self.lib.aehmc_profile_read(self.ctx, ct.byref(ms), ct.byref(n)), "aehmc_profile_read")
+        return ms.value, n.value
+
+
+_engines = {}
+
+
+def get_engine(device=None) -> Engine:
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}") \
+        if torch.cuda.is_available() else None
+    if dev is None:
+        return Engine(device)  # raises the loud error
+    if dev not in _engines:
+        _engines[dev] = Engine(dev)
+    return _engines[dev]
+
+
+def rng_to_device(sites: np.ndarray, device) -> torch.Tensor:
+    """uint64 [C,n,4] -> int64 device tensor with the same bits."""
+    return torch.from_numpy(np.ascontiguousarray(sites).view(np.int64)).to(device)

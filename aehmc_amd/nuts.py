@@ -1,0 +1,48 @@
+"""NUTS kernel -- thin wrapper over the HIP engine (reference: aehmc/nuts.py)."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Tuple
+
+from ._common import Layout, new_state as _new_state, state_rows
+from .engine import get_engine, rng_to_device
+from .integrators import IntegratorState
+from .random import RandomStream
+from .trajectory import Diagnostics
+
+new_state = _new_state  # reference: aehmc/nuts.py:14
+
+
+def new_kernel(srng: RandomStream, logprob_fn, max_num_expansions: int = 10,
+               divergence_threshold: int = 1000) -> Callable:
+    """Build an iterative NUTS kernel (reference: aehmc/nuts.py:17-155).
+
+    RNG call sites, in the reference's graph-construction order: momentum (nuts.py:113),
+    direction (trajectory.py:516), uniform progressive sampling (proposals.py:99), biased
+    progressive sampling (proposals.py:131)."""
+    rng_host = srng.sites(4)
+    holder = {}
+
+    def step(state: IntegratorState, step_size, inverse_mass_matrix) -> Tuple[Diagnostics, Dict]:
+        """One NUTS transition for every chain (reference: aehmc/nuts.py:56-153)."""
+        eng = get_engine()
+        shape = tuple(state.position.shape)
+        layout = Layout(shape, srng.batched, srng.num_chains)
+        if "rng" not in holder:
+            holder["rng"] = rng_to_device(rng_host, eng.device)
+        q, U, g = state_rows(state, layout, eng.device)
+        eng.set_target(logprob_fn, layout.D)
+        eng.set_metric(inverse_mass_matrix, layout.D)
+        out = eng.nuts_step(holder["rng"], float(step_size), int(max_num_expansions),
+                            float(divergence_threshold), q, U, g)
+        info = Diagnostics(
+            state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
+                                  potential_energy=layout.per_chain(U),
+                                  potential_energy_grad=layout.vec(g)),
+            acceptance_probability=layout.per_chain(out["acceptance_probability"]),
+            num_doublings=layout.per_chain(out["num_doublings"]),
+            is_turning=layout.per_chain(out["is_turning"].bool()),
+            is_diverging=layout.per_chain(out["is_diverging"].bool()),
+            n_leapfrog=layout.per_chain(out["n_leapfrog"]))
+        return info, {srng: holder["rng"]}
+
+    return step

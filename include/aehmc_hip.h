@@ -1,0 +1,141 @@
+/* aehmc_hip.h -- C-ABI of the MI355X (gfx950) many-chain HMC/NUTS trajectory engine.
+ *
+ * Drop-in boundary for the leapfrog hot path of aesara-devs/aehmc.  The
+ * reference has no FFI of its own: its boundary is the Python API
+ *     aehmc/hmc.py:16   new_state(q, logprob_fn)
+ *     aehmc/hmc.py:43   hmc.new_kernel(srng, logprob_fn, divergence_threshold)
+ *     aehmc/hmc.py:77   step(state, step_size, inverse_mass_matrix, num_integration_steps)
+ *     aehmc/nuts.py:17  nuts.new_kernel(srng, logprob_fn, max_num_expansions, divergence_threshold)
+ *     aehmc/nuts.py:56  step(state, step_size, inverse_mass_matrix)
+ * and everything those build symbolically (integrators.py, metrics.py, trajectory.py,
+ * termination.py, proposals.py).  The entry points below are what a ctypes binding of
+ * that path binds; aehmc_amd/{hmc,nuts}.py are thin wrappers.
+ *
+ * Conventions
+ *  - every call returns 0 on success, <0 on error (aehmc_last_error gives the text);
+ *    nothing throws across the ABI.  Numerical failure is data (is_diverging), not an
+ *    error (reference: proposals.py:43-45, hmc.py:189-191).
+ *  - all array arguments are DEVICE pointers owned by the caller (hipMalloc or a
+ *    torch-ROCm tensor's data_ptr); chain-major row layout [C, D], float64.  The
+ *    library owns only the ctx and the workspace the caller hands it.
+ *  - `stream` is a hipStream_t passed as void*; work is enqueued on it in order.  NUTS
+ *    polls a pinned "chains still active" word to stop launching early, so a NUTS call
+ *    may block the host for part of its duration; results are complete on `stream`.
+ *  - a ctx is not thread-safe; distinct ctxs are independent; no global state.
+ *  - RNG ("scheme A"): per chain, one PCG64 per RNG call site of the
+ *    reference graph, in graph-construction order; rng is uint64 [C, n_sites, 4] =
+ *    (state_hi, state_lo, inc_hi, inc_lo), advanced in place exactly as numpy's
+ *    Generator.normal / Generator.binomial(1, p) would advance it.
+ */
+#ifndef AEHMC_HIP_H
+#define AEHMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct aehmc_ctx aehmc_ctx;
+
+/* logprob_fn stand-ins (arbitrary Python callables cannot be compiled to HIP) */
+enum aehmc_target_kind {
+  AEHMC_T_STD_NORMAL = 0,   /* aeppl N(0,1) per coordinate: U = sum 0.5 q^2 + log sqrt(2 pi)  (README.md:27-36) */
+  AEHMC_T_ISO_GAUSSIAN = 1, /* U = 0.5 |q|^2 (tests/test_trajectory.py:150-151) */
+  AEHMC_T_DIAG_GAUSSIAN = 2,/* N(mu, diag sigma^2) */
+  AEHMC_T_DENSE_MVN = 3,    /* U = 0.5 (q-mu)^T P (q-mu), P dense symmetric [D,D] */
+  AEHMC_T_LINREG = 4        /* examples/LinearRegression.ipynb:126-166, q = [w, log n] */
+};
+
+typedef struct {
+  int32_t kind;          /* aehmc_target_kind */
+  int32_t reserved;
+  int64_t D;             /* position dimension */
+  const double *mu;      /* [D]   diag / dense */
+  const double *sigma;   /* [D]   diag */
+  const double *prec;    /* [D,D] dense, row-major */
+  const double *X;       /* [N]   linreg */
+  const double *y;       /* [N]   linreg */
+  int64_t N;
+} aehmc_target;
+
+/* gaussian_metric(inverse_mass_matrix) -- metrics.py:10-106.  ndim 0/1/2 = scalar /
+ * diagonal / dense exactly as metrics.py:44-63; sqrt_mass is sqrt(1/imm) (ndim<2) or
+ * L^-T with imm = L L^T (metrics.py:56-58).  Dense imm must be symmetric. */
+typedef struct {
+  int32_t ndim;
+  int32_t reserved;
+  int64_t D;
+  const double *imm;       /* [1] | [D] | [D,D] */
+  const double *sqrt_mass; /* [1] | [D] | [D,D] */
+} aehmc_metric;
+
+/* per-transition outputs == trajectory.py:379-384 Diagnostics (+ n_leapfrog) */
+typedef struct {
+  double *momentum;               /* [C,D] Diagnostics.state.momentum */
+  double *acceptance_probability; /* [C] */
+  int64_t *num_doublings;         /* [C] NUTS only (may be NULL for HMC) */
+  int32_t *is_turning;            /* [C] NUTS only (may be NULL for HMC) */
+  int32_t *is_diverging;          /* [C] */
+  int64_t *n_leapfrog;            /* [C] integrator calls that belong to the trajectory */
+} aehmc_diagnostics;
+
+int aehmc_create(aehmc_ctx **out, int device);
+int aehmc_destroy(aehmc_ctx *ctx);
+const char *aehmc_last_error(const aehmc_ctx *ctx);
+
+/* bind logprob_fn / inverse_mass_matrix (device buffers must outlive their use) */
+int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *target);
+int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
+
+/* engine options: "fused_hmc" (default 1: register-resident single-launch HMC when the
+ * metric is diagonal and the target coordinate-wise; 0 forces the lock-step path) */
+int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value);
+
+/* workspace the caller must provide to the step calls for C chains */
+int64_t aehmc_workspace_bytes(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions);
+int aehmc_set_workspace(aehmc_ctx *ctx, void *workspace, int64_t bytes);
+
+/* hmc.new_state -- hmc.py:16-40: U = -logprob(q), g = dU/dq */
+int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, double *U, double *g, void *stream);
+
+/* hmc.new_kernel(...)(state, step_size, imm, L) -- hmc.py:77-124,157-204, trajectory.py:31-107.
+ * rng [C,2,4]: site #1 momentum, #2 accept.  q,U,g updated in place. */
+int aehmc_hmc_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                   int64_t num_integration_steps, double divergence_threshold, double *q,
+                   double *U, double *g, const aehmc_diagnostics *out, void *stream);
+
+/* nuts.new_kernel(...)(state, step_size, imm) -- nuts.py:56-153, trajectory.py:154-374,428-714,
+ * termination.py:19-235, proposals.py.  rng [C,4,4]: #1 momentum, #2 direction,
+ * #3 uniform progressive, #4 biased progressive.  q,U,g updated in place. */
+int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                    int64_t max_num_expansions, double divergence_threshold, double *q,
+                    double *U, double *g, const aehmc_diagnostics *out, void *stream);
+
+/* ---- building blocks exported for known-answer tests / callers that want them ---- */
+
+/* integrators.py:54-73 applied nsteps times to C chains (state in place) */
+int aehmc_leapfrog(aehmc_ctx *ctx, int64_t C, double step_size, int64_t nsteps, double *q,
+                   double *p, double *U, double *g, void *stream);
+/* metrics.py:70-73 */
+int aehmc_kinetic_energy(aehmc_ctx *ctx, int64_t C, const double *p, double *K, void *stream);
+/* metrics.py:75-104 */
+int aehmc_is_turning(aehmc_ctx *ctx, int64_t C, const double *p_left, const double *p_right,
+                     const double *p_sum, int32_t *out, void *stream);
+/* RNG streams as numpy would produce them: n normals / bernoulli(p[i]) from rng [C,4] */
+int aehmc_rng_normals(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t n, double *out, void *stream);
+int aehmc_rng_bernoulli(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t n, const double *p,
+                        int32_t *out, void *stream);
+/* fp64 MFMA GEMM used by the dense-metric path: Cmat[M,N] = A[M,K] * B[N,K]^T (row-major) */
+int aehmc_gemm_nt(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
+                  const double *B, int64_t ldb, double *Cmat, int64_t ldc, void *stream);
+
+/* timing hooks for bench.py: HIP events around the last dominant-kernel launches */
+int aehmc_profile_enable(aehmc_ctx *ctx, int enable);
+int aehmc_profile_read(aehmc_ctx *ctx, double *kernel_ms_total, int64_t *kernel_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AEHMC_HIP_H */
