@@ -1,0 +1,82 @@
+"""Multi-GPU plumbing: one process per GPU, chains sharded contiguously, no data-path
+collective during sampling; the only exchange is the gather of samples/diagnostics
+(RCCL all_gather over xGMI on GPUs, gloo in the CPU tests) -- SURVEY.md 8e.
+
+The reference has no counterpart (single chain, single process)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def _on() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size() -> int:
+    return dist.get_world_size() if _on() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if _on() else 0
+
+
+def shard_chains(num_chains: int, r: int = None, w: int = None):
+    """Contiguous chain range [lo, hi) of rank r: sizes differ by at most one."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    base, rem = divmod(num_chains, w)
+    lo = r * base + min(r, rem)
+    return lo, lo + base + (1 if r < rem else 0)
+
+
+def chain_seeds(base_seed: int, num_chains: int, r: int = None, w: int = None):
+    """Per-chain seeds are a function of the GLOBAL chain index, so results do not depend
+    on how many GPUs the chains are spread over."""
+    lo, hi = shard_chains(num_chains, r, w)
+    return [base_seed + c for c in range(lo, hi)]
+
+
+def barrier(device=None):
+    if _on():
+        if device is not None and torch.device(device).type == "cuda":
+            dist.barrier(device_ids=[torch.device(device).index])
+        else:
+            dist.barrier()
+
+
+def gather_samples(x: torch.Tensor) -> torch.Tensor:
+    """All-gather the per-rank rows [C_r, ...] into [sum C_r, ...] (rank order)."""
+    if not _on():
+        return x
+    w = dist.get_world_size()
+    x = x.contiguous()
+    sizes = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(w)]
+    dist.all_gather(sizes, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
+    sizes = [int(s.item()) for s in sizes]
+    if len(set(sizes)) == 1:
+        out = torch.empty((w * sizes[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x)
+        return out
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    parts = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+
+
+def max_over_ranks(v: float, device=None) -> float:
+    if not _on():
+        return v
+    t = torch.tensor([v], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(v: int, device=None) -> int:
+    if not _on():
+        return v
+    t = torch.tensor([v], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leapfrog-steps/sec across all chains (BASELINE.json metric).
+
+Default workload = BASELINE config c3 (the configuration the metric is quoted on):
+1e4-dim correlated MVN, dense inverse mass matrix (fp64 MFMA path), NUTS
+max_tree_depth=10, 4096 chains per GPU, synthetic inputs of SURVEY.md 8d.  A "step" is
+one NUTS transition of every chain of the rank.  `--config c2` runs the 100-dim HMC
+(L=32, diagonal mass) configuration instead.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Chains shard embarrassingly: each rank owns 4096 chains with its own seeds ("weak"
+scaling); the only collective is the final gather of the last sample (RCCL all_gather),
+which is inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X FP64 matrix peak (AMD datasheet; = 256 CU * 4 SIMD * 32 flop/clk * 2.4 GHz).
+#                               /opt/skills/guides/MI355X_MICROARCH.md lists no f64 MFMA row.
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def build_c3(D, device, rho=0.5):
+    """Sigma_ij = rho^|i-j| s_i s_j, s_i = 1 + (i mod 3); precision is tridiagonal
+    analytically but stored and applied DENSE; imm = Sigma."""
+    i = torch.arange(D, device=device)
+    s = (1.0 + (i % 3)).to(torch.float64)
+    R = rho ** (i[:, None] - i[None, :]).abs().to(torch.float64)
+    Sigma = s[:, None] * R * s[None, :]
+    del R
+    d = torch.full((D,), (1 + rho * rho) / (1 - rho * rho), dtype=torch.float64, device=device)
+    d[0] = d[-1] = 1.0 / (1 - rho * rho)
+    P = torch.diag(d)
+    off = torch.full((D - 1,), -rho / (1 - rho * rho), dtype=torch.float64, device=device)
+    P += torch.diag(off, 1) + torch.diag(off, -1)
+    P = P / s[:, None] / s[None, :]
+    Sigma = 0.5 * (Sigma + Sigma.T)
+    P = 0.5 * (P + P.T)
+    return Sigma.contiguous(), P.contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
+    ap.add_argument("--dim", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    from aehmc_amd.engine import get_engine
+    from aehmc_amd.parallel import barrier, gather_samples, max_over_ranks, sum_over_ranks
+
+    C = args.chains
+    eng = get_engine(device)
+    seeds = [1000 + rank * C + c for c in range(C)]
+    q0 = np.random.default_rng(1234 + rank).standard_normal((C, args.dim or (100 if args.config == "c2" else 10_000)))
+    D = q0.shape[1]
+
+    if args.config == "c3":
+        Sigma, P = build_c3(D, device)
+        mu = torch.zeros(D, dtype=torch.float64, device=device)
+        target = targets.DenseMVN(mu, P)
+        imm = Sigma
+        eps = 0.5 * D ** -0.25
+        kernel = nuts.new_kernel(RandomStream(seeds=seeds), target, max_num_expansions=10)
+        state = nuts.new_state(torch.as_tensor(q0, device=device), target)
+        step = lambda st: kernel(st, eps, imm)
+        workload = (f"c3: {D}-dim correlated MVN (AR(1) rho=0.5, dense precision), dense inverse mass "
+                    f"matrix, NUTS max_tree_depth=10, {C} chains/GPU, eps={eps:.4f}")
+    else:
+        target = targets.IsoGaussian()
+        imm = torch.ones(D, dtype=torch.float64, device=device)
+        eps, L = 0.1, 32
+        kernel = hmc.new_kernel(RandomStream(seeds=seeds), target)
+        state = hmc.new_state(torch.as_tensor(q0, device=device), target)
+        step = lambda st: kernel(st, eps, imm, L)
+        workload = f"c2: {D}-dim isotropic Gaussian, HMC L={L}, diagonal mass, {C} chains/GPU, eps={eps}"
+
+    for _ in range(args.warmup):
+        info, _ = step(state)
+        state = info.state._replace(momentum=None)
+
+    eng.profile_enable(True)
+    n_leap = torch.zeros((), dtype=torch.int64, device=device)
+    barrier(device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info, _ = step(state)
+        state = info.state._replace(momentum=None)
+        n_leap += info.n_leapfrog.sum()
+    gathered = gather_samples(state.position)  # the path's one exchange step
+    torch.cuda.synchronize(device)
+    barrier(device)
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, device)
+    total_leap = sum_over_ranks(int(n_leap.item()), device)
+    kern_ms, kern_n = eng.profile_read()
+    eng.profile_enable(False)
+    assert gathered.shape[0] == C * world
+
+    if rank != 0:
+        return
+    value = total_leap / elapsed
+    if args.config == "c3":
+        flops = 2.0 * C * D * D  # algorithmic flops of one [C,D]x[D,D] launch (6*D^2 per leapfrog = 3 launches)
+        avg_s = kern_ms / 1e3 / max(kern_n, 1)
+        achieved = flops / avg_s / 1e12
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                    "kernel": "gemm_nt_f64_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n}
+    else:
+        # fused HMC kernel: algorithmic bytes = SURVEY.md 8d streaming figure 48*D B per leapfrog per chain
+        bytes_per_launch = 48.0 * D * C * 32
+        avg_s = kern_ms / 1e3 / max(kern_n, 1)
+        achieved = bytes_per_launch / avg_s / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": achieved / PEAK_HBM_GBS, "traffic": None, "kernel": "k_hmc_fused",
+                    "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
+                    "note": "state is register-resident for all L steps; >1 means on-chip reuse"}
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(args.config, D, q0, target, imm, eps)
+
+    print(json.dumps({
+        "metric": "leapfrog-steps/sec across all chains", "value": value, "unit": "leapfrog-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "chains_total": C * world, "dim": D,
+                   "leapfrogs_per_step": total_leap / args.steps},
+        "roofline": roofline, "cpu_baseline": cpu}))
+
+
+def cpu_baseline(config, D, q0, target, imm, eps):
+    """The C restatement (oracle, "port") timed on this host's cores on a bounded sample."""
+    from oracle import c_oracle as co
+    threads = min(os.cpu_count() or 1, 16)
+    n = threads
+    seeds = [1000 + c for c in range(n)]
+    if config == "c3":
+        mu = np.zeros(D)
+        otgt = co.Target(co.T_DENSE_MVN, D, mu=mu, prec=target.precision.cpu().numpy())
+        metric = co.Metric(imm.cpu().numpy(), D)
+        rng = co.site_states(seeds, 4)
+        q, U, g = co.new_state(otgt, q0[:n].copy())
+        max_exp = 3
+        t0 = time.perf_counter()
+        res = co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=max_exp, nthreads=threads)
+        dt = time.perf_counter() - t0
+        nl = int(res["n_leapfrog"].sum())
+        sample = (f"{n} chains x 1 NUTS transition truncated at max_num_expansions={max_exp} "
+                  f"({nl} leapfrogs), same D/target/metric, {threads} OpenMP threads over chains")
+    else:
+        n = 256
+        otgt, metric = co.Target(co.T_ISO_GAUSSIAN, D), co.Metric(np.ones(D), D)
+        rng = co.site_states([1000 + c for c in range(n)], 2)
+        q, U, g = co.new_state(otgt, q0[:n].copy())
+        reps = 200
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            co.hmc_step(otgt, metric, rng, eps, 32, q, U, g, nthreads=threads)
+        dt = time.perf_counter() - t0
+        nl = n * 32 * reps
+        sample = f"{n} chains x {reps} HMC transitions (L=32), {threads} OpenMP threads over chains"
+    return {"value": nl / dt, "unit": "leapfrog-steps/s", "cores": threads, "kind": "port",
+            "sample": sample, "host_cpu_count": os.cpu_count(),
+            "note": "C restatement of aehmc semantics (oracle/c), not Aesara; reported, not optimised"}
+
+
+if __name__ == "__main__":
+    main()

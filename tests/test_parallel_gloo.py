@@ -1,0 +1,57 @@
+"""The N>1 path on CPU: world_size-2 gloo processes exercise chain sharding, per-chain
+seeding and the one exchange step (sample gather)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aehmc_amd import parallel
+    lo, hi = parallel.shard_chains(total)
+    seeds = parallel.chain_seeds(1000, total)
+    assert seeds == [1000 + c for c in range(lo, hi)]
+    # stand-in for the per-rank samples: row c holds the chain's global index and seed
+    x = torch.tensor([[c, 1000 + c, rank] for c in range(lo, hi)], dtype=torch.float64)
+    parallel.barrier()
+    g = parallel.gather_samples(x)
+    assert g.shape == (total, 3)
+    assert torch.equal(g[:, 0], torch.arange(total, dtype=torch.float64))
+    assert parallel.max_over_ranks(float(rank)) == world - 1
+    assert parallel.sum_over_ranks(hi - lo) == total
+    if rank == 0:
+        np.save(os.path.join(tmp, "gathered.npy"), g.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 7])  # even and ragged shards
+def test_gather_world2_gloo(tmp_path, total):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    g = np.load(tmp_path / "gathered.npy")
+    assert g[:, 1].tolist() == [1000 + c for c in range(total)]
+
+
+def test_shards_partition():
+    from aehmc_amd import parallel
+    for total in (1, 7, 8, 4096, 32768):
+        for w in (1, 2, 4, 8):
+            spans = [parallel.shard_chains(total, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
