@@ -102,8 +102,17 @@ class Engine:
             if not torch.allclose(t, t.T, rtol=1e-12, atol=0):
                 raise ValueError("dense inverse mass matrix must be symmetric")
             L = torch.linalg.cholesky(t)  # metrics.py:56
-            eye = torch.eye(D, dtype=torch.float64, device=self.device)
-            sqrt_mass = torch.linalg.solve_triangular(L.T.contiguous(), eye, upper=True).contiguous()
+            LT = L.T.contiguous()
+            del L
+            # metrics.py:58 solve_triangular(L, I, lower=True, trans=True) = L^-T, by column
+            # blocks (one 1e4 x 1e4 trsm exhausts hipBLAS' workspace)
+            sqrt_mass = torch.empty(D, D, dtype=torch.float64, device=self.device)
+            for j in range(0, D, 1024):
+                w = min(1024, D - j)
+                rhs = torch.zeros(D, w, dtype=torch.float64, device=self.device)
+                rhs[j:j + w] = torch.eye(w, dtype=torch.float64, device=self.device)
+                sqrt_mass[:, j:j + w] = torch.linalg.solve_triangular(LT, rhs, upper=True)
+            del LT
         else:
             t = t.reshape(-1)
             if ndim == 1 and t.numel() != D:
