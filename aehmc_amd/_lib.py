@@ -48,7 +48,7 @@ SYMBOLS = {
     "aehmc_rng_bernoulli": (_I, [_P, _I64, _P, _I64, _P, _P, _P]),
     "aehmc_gemm_nt": (_I, [_P, _I64, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P]),
     "aehmc_profile_enable": (_I, [_P, _I]),
-    "aehmc_profile_read": (_I, [_P, ct.POINTER(_D), ct.POINTER(_I64)]),
+    "aehmc_profile_read": (_I, [_P, ct.POINTER(_D), ct.POINTER(_I64), ct.POINTER(_D)]),
 }
 
 

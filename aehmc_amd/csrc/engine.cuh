@@ -56,13 +56,18 @@ struct EngineArgs {
   uint64_t *rng;
   int nsites;
   // work vectors [C,D]
-  double *cur_q, *cur_p, *cur_g, *cur_v;
-  double *end_q[2], *end_p[2], *end_g[2], *end_v[2];
+  double *cur_q, *cur_p, *cur_g, *cur_v, *cur_w;
+  double *end_q[2], *end_p[2], *end_g[2], *end_v[2], *end_w[2];
   double *slot_q[2], *slot_p[2], *slot_g[2];
   double *psum, *psub;
   double *ckp, *cks, *ckv;          // [max_exp][C][D]
   double *vhalf, *rbuf, *zbuf;
   ChainCtl *ctl;
+  // dense metric, "linear" mode: w = imm g is carried with the state so that
+  // v_half = v - (eps/2) w and v' = v_half - (eps/2) w' need one metric GEMM per leapfrog
+  int linear;
+  // compacted list of live chains for the GEMMs (built by k_compact)
+  int *row_idx, *n_rows;
   // caller state / outputs
   double *q, *U, *g;
   aehmc_diagnostics out;
@@ -160,6 +165,49 @@ __device__ __forceinline__ bool leap_stages(const EngineArgs &a, long long c, in
   return false;
 }
 
+// Dense metric, linear mode.  By linearity of v = imm p the two metric products of a
+// leapfrog collapse into w' = imm g':  v_half = v - b w,  v' = v_half - b w'.
+// PHASE 12: p_half, v_half, q' (+ target / staging of r);  PHASE 3: p', v' (+ U for the
+// dense target).  Same return convention as leap_stages.
+template <int PHASE>
+__device__ __forceinline__ bool leap_linear(const EngineArgs &a, long long c, int lane, int dir,
+                                            double &U_out) {
+  const double step_size = (dir ? 1.0 : -1.0) * a.eps;
+  const double b = 0.5 * step_size, aa = 1 * step_size;
+  const size_t row = (size_t)c * a.D;
+  const bool elem = target_is_elem(a.tkind);
+  const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
+  double usum = 0.0;
+  for (long long i = lane; i < a.D; i += 64) {
+    if (PHASE == 12) {
+      double p = a.cur_p[row + i] - b * a.cur_g[row + i];
+      double v = a.cur_v[row + i] - b * a.cur_w[row + i];
+      a.cur_p[row + i] = p;
+      a.cur_v[row + i] = v;
+      double q = a.cur_q[row + i] + aa * v;
+      a.cur_q[row + i] = q;
+      if (elem) {
+        double u, gnew;
+        target_elem(a, i, q, u, gnew);
+        usum += u;
+        a.cur_g[row + i] = gnew;
+      } else if (tdense) {
+        a.rbuf[row + i] = q - a.mu[i];
+      }
+    } else {
+      double gi = a.cur_g[row + i];
+      if (tdense) usum += a.rbuf[row + i] * gi;
+      a.cur_p[row + i] = a.cur_p[row + i] - b * gi;
+      a.cur_v[row + i] = a.cur_v[row + i] - b * a.cur_w[row + i];
+    }
+  }
+  if ((PHASE == 12 && elem) || (PHASE == 3 && tdense)) {
+    U_out = target_finish(a, wave_sum(usum));
+    return true;
+  }
+  return false;
+}
+
 // ---------------------------------------------------------------------------------
 // NUTS bookkeeping after one leapfrog of the chain's moving end (cur_*).
 // ---------------------------------------------------------------------------------
@@ -188,6 +236,7 @@ __device__ inline void nuts_begin_expansion(const EngineArgs &a, long long c, in
       a.cur_p[row + i] = a.end_p[go_right][row + i];
       a.cur_g[row + i] = a.end_g[go_right][row + i];
       if (MET_DENSE) a.cur_v[row + i] = a.end_v[go_right][row + i];
+      if (MET_DENSE && a.linear) a.cur_w[row + i] = a.end_w[go_right][row + i];
     }
     ct.U_cur = ct.U_end[go_right];
   }
@@ -235,6 +284,7 @@ __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c,
     a.end_p[dir][row + i] = pc;
     a.end_g[dir][row + i] = a.cur_g[row + i];
     if (MET_DENSE) a.end_v[dir][row + i] = vc;
+    if (MET_DENSE && a.linear) a.end_w[dir][row + i] = a.cur_w[row + i];
   }
   d_l = wave_sum(d_l);
   d_r = wave_sum(d_r);
@@ -398,6 +448,7 @@ __device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lan
       a.end_p[e][row + i] = p;
       a.end_g[e][row + i] = g;
       if (MET_DENSE) a.end_v[e][row + i] = v;
+      if (MET_DENSE && a.linear) a.end_w[e][row + i] = a.cur_w[row + i];
     }
     a.slot_q[0][row + i] = q;
     a.slot_p[0][row + i] = p;
@@ -476,6 +527,47 @@ __global__ __launch_bounds__(256) void k_step(EngineArgs a) {
     nuts_book<MET_DENSE>(a, c, lane, ct);
   } else if (has_U && lane == 0) {
     a.ctl[c].U_cur = U_new;
+  }
+}
+
+template <int PHASE, bool BOOK>
+__global__ __launch_bounds__(256) void k_step_linear(EngineArgs a) {
+  AEHMC_CHAIN_OF_WAVE();
+  ChainCtl ct = a.ctl[c];
+  if (ct.done) return;
+  double U_new = 0.0;
+  bool has_U = leap_linear<PHASE>(a, c, lane, ct.dir, U_new);
+  if (BOOK) {
+    if (has_U) ct.U_cur = U_new;
+    nuts_book<true>(a, c, lane, ct);
+  } else if (has_U && lane == 0) {
+    a.ctl[c].U_cur = U_new;
+  }
+}
+
+// ascending list of live chains + count (one 1024-thread block; deterministic order)
+__global__ __launch_bounds__(1024) void k_compact(const ChainCtl *ctl, long long C, int *row_idx,
+                                                  int *n_rows, int *host_slot) {
+  __shared__ int cnt[1024];
+  const int t = threadIdx.x;
+  const long long per = (C + 1023) / 1024;
+  const long long lo = t * per, hi = (lo + per < C) ? lo + per : C;
+  int n = 0;
+  for (long long c = lo; c < hi; c++) n += ctl[c].done ? 0 : 1;
+  cnt[t] = n;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
+    int v = t >= off ? cnt[t - off] : 0;
+    __syncthreads();
+    cnt[t] += v;
+    __syncthreads();
+  }
+  int pos = cnt[t] - n;
+  for (long long c = lo; c < hi; c++)
+    if (!ctl[c].done) row_idx[pos++] = (int)c;
+  if (t == 1023) {
+    *n_rows = cnt[1023];
+    if (host_slot) *host_slot = cnt[1023];
   }
 }
 

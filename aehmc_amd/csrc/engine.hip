@@ -35,12 +35,16 @@ struct aehmc_ctx {
   int *d_active = nullptr;
   hipEvent_t ev[NRING] = {};
   bool opt_fused_hmc = true;
+  bool opt_dense_linear = true;  // one metric GEMM per leapfrog (v carried by linearity)
+  bool opt_compact = true;       // finished chains drop out of the GEMMs
   // profiling of the dominant (GEMM / fused) kernel with HIP events on the launch stream
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
   double prof_ms = 0.0;
   int64_t prof_n = 0;
+  unsigned long long *d_flops = nullptr;  // algorithmic flops of the profiled launches
+  double prof_flops = 0.0;
 };
 
 #define HIPCHK(expr)                                                                     \
@@ -81,6 +85,8 @@ extern "C" int aehmc_create(aehmc_ctx **out, int device) {
   HIPCHK(hipHostMalloc((void **)&ctx->h_active, NRING * sizeof(int), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void **)&ctx->d_active, ctx->h_active, 0));
   for (int i = 0; i < NRING; i++) HIPCHK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+  HIPCHK(hipMalloc((void **)&ctx->d_flops, sizeof(unsigned long long)));
+  HIPCHK(hipMemset(ctx->d_flops, 0, sizeof(unsigned long long)));
   return 0;
 }
 
@@ -89,6 +95,7 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   hipSetDevice(ctx->device);
   if (ctx->log_sigma) hipFree(ctx->log_sigma);
   if (ctx->h_active) hipHostFree(ctx->h_active);
+  if (ctx->d_flops) hipFree(ctx->d_flops);
   for (int i = 0; i < NRING; i++)
     if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->prof_ev) hipEventDestroy(e);
@@ -150,6 +157,14 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
     ctx->opt_fused_hmc = value != 0;
     return 0;
   }
+  if (!strcmp(name, "dense_linear")) {
+    ctx->opt_dense_linear = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "compact")) {
+    ctx->opt_compact = value != 0;
+    return 0;
+  }
   FAIL(std::string("unknown option ") + name);
 }
 
@@ -176,7 +191,11 @@ static int64_t ws_layout(const aehmc_ctx *ctx, int64_t C, int64_t E, char *base,
     r.cur_v = take(vec);
     r.end_v[0] = take(vec); r.end_v[1] = take(vec);
     r.ckv = take(vec * E);
+    r.cur_w = take(vec);
+    r.end_w[0] = take(vec); r.end_w[1] = take(vec);
   }
+  r.row_idx = reinterpret_cast<int *>(take(((size_t)C * sizeof(int) + 255) & ~(size_t)255));
+  r.n_rows = reinterpret_cast<int *>(take(256));
   r.ctl = reinterpret_cast<ChainCtl *>(take(((size_t)C * sizeof(ChainCtl) + 255) & ~(size_t)255));
   return (int64_t)off;
 }
@@ -212,15 +231,18 @@ static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a) {
   a.mu = ctx->tgt.mu;
   a.sigma = ctx->tgt.sigma;
   a.log_sigma = ctx->log_sigma;
+  a.linear = (a.met_ndim == 2 && ctx->opt_dense_linear) ? 1 : 0;
   return 0;
 }
 
 // ------------------------------------------------------------------ GEMM + profiling
 static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
-                const double *B, int64_t ldb, double *Cm, int64_t ldc, hipStream_t st) {
+                const double *B, int64_t ldb, double *Cm, int64_t ldc, hipStream_t st,
+                const int *row_idx = nullptr, const int *n_rows = nullptr) {
   const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
   if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
-  HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st));
+  HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st, row_idx, n_rows,
+                            p ? ctx->d_flops : nullptr));
   if (p) {
     HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
     ctx->prof_used += 2;
@@ -239,9 +261,13 @@ extern "C" int aehmc_profile_enable(aehmc_ctx *ctx, int enable) {
   ctx->prof_used = 0;
   ctx->prof_ms = 0.0;
   ctx->prof_n = 0;
+  ctx->prof_flops = 0.0;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemset(ctx->d_flops, 0, sizeof(unsigned long long)));
   return 0;
 }
-extern "C" int aehmc_profile_read(aehmc_ctx *ctx, double *ms_total, int64_t *launches) {
+extern "C" int aehmc_profile_read(aehmc_ctx *ctx, double *ms_total, int64_t *launches,
+                                  double *flops_total) {
   if (!ctx) return -2;
   HIPCHK(hipSetDevice(ctx->device));
   for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
@@ -252,8 +278,14 @@ extern "C" int aehmc_profile_read(aehmc_ctx *ctx, double *ms_total, int64_t *lau
     ctx->prof_n += 1;
   }
   ctx->prof_used = 0;
+  unsigned long long fl = 0;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(&fl, ctx->d_flops, sizeof(fl), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(ctx->d_flops, 0, sizeof(unsigned long long)));
+  ctx->prof_flops += (double)fl;
   if (ms_total) *ms_total = ctx->prof_ms;
   if (launches) *launches = ctx->prof_n;
+  if (flops_total) *flops_total = ctx->prof_flops;
   return 0;
 }
 
@@ -273,8 +305,10 @@ extern "C" int aehmc_gemm_nt(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, co
   } while (0)
 
 // one lock-step leapfrog of every live chain (integrators.py:54-73); `book` appends the
-// NUTS bookkeeping; `need_v` says whether v' = imm p' must be formed (dense metric)
-static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool need_v, hipStream_t st) {
+// NUTS bookkeeping; `need_v` says whether v' = imm p' must be formed (dense metric);
+// `ri`/`nr`: compacted live-chain list for the GEMMs (may be null)
+static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool need_v, hipStream_t st,
+                           const int *ri = nullptr, const int *nr = nullptr) {
   const bool md = a.met_ndim == 2;
   const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
   const int64_t C = a.C, D = a.D;
@@ -286,23 +320,32 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
   }
   if (!md && tdense) {
     LAUNCH((k_step<true, true, false, false, false>), C, st, a);
-    if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st)) return -1;
+    if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr)) return -1;
     if (book) LAUNCH((k_step<false, false, true, false, true>), C, st, a);
     else LAUNCH((k_step<false, false, true, false, false>), C, st, a);
     return 0;
   }
-  // dense metric
+  if (a.linear) {  // dense metric, v carried by linearity: one metric GEMM (w' = imm g')
+    LAUNCH((k_step_linear<12, false>), C, st, a);
+    if (tdense)
+      if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr)) return -1;
+    if (gemm(ctx, C, D, D, a.cur_g, D, ctx->met.imm, D, a.cur_w, D, st, ri, nr)) return -1;
+    if (book) LAUNCH((k_step_linear<3, true>), C, st, a);
+    else LAUNCH((k_step_linear<3, false>), C, st, a);
+    return 0;
+  }
+  // dense metric, literal: v_half = imm p_half and v' = imm p' formed directly
   LAUNCH((k_step<true, false, false, true, false>), C, st, a);
-  if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.vhalf, D, st)) return -1;
+  if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.vhalf, D, st, ri, nr)) return -1;
   if (!tdense) {
     LAUNCH((k_step<false, true, true, true, false>), C, st, a);
   } else {
     LAUNCH((k_step<false, true, false, true, false>), C, st, a);
-    if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st)) return -1;
+    if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr)) return -1;
     LAUNCH((k_step<false, false, true, true, false>), C, st, a);
   }
   if (need_v || book)
-    if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.cur_v, D, st)) return -1;
+    if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.cur_v, D, st, ri, nr)) return -1;
   if (book) LAUNCH((k_step<false, false, false, true, true>), C, st, a);
   return 0;
 }
@@ -319,6 +362,8 @@ static int launch_begin(aehmc_ctx *ctx, const EngineArgs &a, bool nuts, hipStrea
   LAUNCH(k_nuts_draw<true>, C, st, a);
   if (gemm(ctx, C, D, D, a.zbuf, D, ctx->met.sqrt_mass, D, a.cur_p, D, st)) return -1;  // p = L^-T z
   if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.cur_v, D, st)) return -1;
+  if (a.linear)  // w0 = imm g0
+    if (gemm(ctx, C, D, D, a.g, D, ctx->met.imm, D, a.cur_w, D, st)) return -1;
   if (nuts) LAUNCH(k_nuts_init<true>, C, st, a);
   else LAUNCH(k_hmc_init<true>, C, st, a);
   return 0;
@@ -366,6 +411,13 @@ extern "C" int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double 
   if (int rc = launch_begin(ctx, a, true, st)) return rc;
   long long maxsteps = 0;
   for (int j = 0; j < max_num_expansions; j++) maxsteps += (1LL << j) + 1;  // 2**j + 1 per expansion
+  const bool compact = ctx->opt_compact && (a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN);
+  const int *ri = compact ? a.row_idx : nullptr, *nr = compact ? a.n_rows : nullptr;
+  if (compact) {
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, (const ChainCtl *)a.ctl, (long long)C,
+                       a.row_idx, a.n_rows, (int *)nullptr);
+    HIPCHK(hipGetLastError());
+  }
   long long s = 0;
   int batch = 0;
   while (s < maxsteps) {
@@ -374,12 +426,21 @@ extern "C" int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double 
       HIPCHK(hipEventSynchronize(ctx->ev[slot]));
       if (ctx->h_active[slot] == 0) break;
     }
-    for (int k = 0; k < STEP_BATCH && s < maxsteps; k++, s++)
-      if (int rc = launch_leapfrog(ctx, a, true, true, st)) return rc;
-    int slot = batch % NRING;
-    hipLaunchKernelGGL(k_count_active, dim3(1), dim3(1024), 0, st, (const ChainCtl *)a.ctl,
-                       (long long)C, ctx->d_active + slot);
-    HIPCHK(hipGetLastError());
+    const int slot = batch % NRING;
+    for (int k = 0; k < STEP_BATCH && s < maxsteps; k++, s++) {
+      if (int rc = launch_leapfrog(ctx, a, true, true, st, ri, nr)) return rc;
+      if (compact) {
+        const bool last = (k == STEP_BATCH - 1) || (s == maxsteps - 1);
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, (const ChainCtl *)a.ctl,
+                           (long long)C, a.row_idx, a.n_rows, last ? ctx->d_active + slot : (int *)nullptr);
+        HIPCHK(hipGetLastError());
+      }
+    }
+    if (!compact) {
+      hipLaunchKernelGGL(k_count_active, dim3(1), dim3(1024), 0, st, (const ChainCtl *)a.ctl,
+                         (long long)C, ctx->d_active + slot);
+      HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(ctx->ev[slot], st));
     batch++;
   }
@@ -432,6 +493,7 @@ extern "C" int aehmc_leapfrog(aehmc_ctx *ctx, int64_t C, double step_size, int64
   EngineArgs a;
   if (int rc = fill_args(ctx, C, 1, a)) return rc;
   a.eps = step_size;
+  a.linear = 0;                           // building block: literal metric products
   a.cur_q = q; a.cur_p = p; a.cur_g = g;  // integrate the caller's arrays in place
   LAUNCH(k_ctl_set, C, st, a, (const double *)U);
   for (int64_t l = 0; l < nsteps; l++)

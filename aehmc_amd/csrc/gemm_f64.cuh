@@ -56,15 +56,15 @@ __device__ __forceinline__ GemmTileMap gemm_tile_of_block(int b, int Tm, int Tn)
   return r;
 }
 
-// loads this thread's 8 doubles of a 128 x 16 operand tile (row = tid/2, cols (tid&1)*8..+7)
+// loads this thread's 8 doubles of a 128 x 16 operand tile (row = tid/2, cols (tid&1)*8..+7);
+// `src_row` is the memory row of tile row tid/2 (or < 0 when that row is out of range)
 template <bool VEC>
 __device__ __forceinline__ void gemm_load_tile(const double *__restrict__ P, int64_t ld,
-                                               int64_t row0, int64_t nrows, int64_t k0,
-                                               int64_t K, int tid, double (&r)[8]) {
-  const int64_t row = row0 + (tid >> 1);
+                                               int64_t src_row, int64_t k0, int64_t K, int tid,
+                                               double (&r)[8]) {
   const int64_t k = k0 + (tid & 1) * 8;
-  if (row < nrows) {
-    const double *src = P + row * ld + k;
+  if (src_row >= 0) {
+    const double *src = P + src_row * ld + k;
     if (VEC && k + 8 <= K) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
@@ -82,17 +82,33 @@ __device__ __forceinline__ void gemm_load_tile(const double *__restrict__ P, int
   }
 }
 
+// row_idx / n_rows (both optional): compacted-row mode for the lock-step engine -- tile
+// row r reads A row row_idx[r] and writes C row row_idx[r], and only *n_rows rows exist
+// (chains whose transition has finished drop out of the product).
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
     int64_t M, int64_t N, int64_t K, const double *__restrict__ A, int64_t lda,
-    const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc) {
+    const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc,
+    const int *__restrict__ row_idx, const int *__restrict__ n_rows,
+    unsigned long long *__restrict__ flop_counter) {
   __shared__ __attribute__((aligned(16))) double lds[2][2][GEMM_BM][GEMM_LDS];  // [stage][A|B]
+  __shared__ int s_rows[GEMM_BM];
+  if (n_rows) M = *n_rows;
+  if (flop_counter && blockIdx.x == 0 && threadIdx.x == 0)  // algorithmic flops of this launch
+    atomicAdd(flop_counter, (unsigned long long)(2 * M * N * K));
   const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
   const GemmTileMap tile = gemm_tile_of_block(blockIdx.x, Tm, Tn);
   if (!tile.valid) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)tile.tm * GEMM_BM, n0 = (int64_t)tile.tn * GEMM_BN;
+  if (tid < GEMM_BM) {
+    const int64_t r = m0 + tid;
+    s_rows[tid] = r < M ? (row_idx ? row_idx[r] : (int)r) : -1;
+  }
+  __syncthreads();
+  const int64_t a_row = s_rows[tid >> 1];
+  const int64_t b_row = (n0 + (tid >> 1)) < N ? n0 + (tid >> 1) : -1;
 
   d4_t acc[4][4];
 #pragma unroll
@@ -104,8 +120,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
   const int nk = (int)((K + GEMM_BK - 1) / GEMM_BK);
   const int srow = tid >> 1, scol = (tid & 1) * 8;
 
-  gemm_load_tile<VEC>(A, lda, m0, M, 0, K, tid, ra);
-  gemm_load_tile<VEC>(B, ldb, n0, N, 0, K, tid, rb);
+  gemm_load_tile<VEC>(A, lda, a_row, 0, K, tid, ra);
+  gemm_load_tile<VEC>(B, ldb, b_row, 0, K, tid, rb);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     *reinterpret_cast<d2_t *>(&lds[0][0][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
@@ -117,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
   for (int kt = 0; kt < nk; kt++) {
     const int st = kt & 1;
     if (kt + 1 < nk) {
-      gemm_load_tile<VEC>(A, lda, m0, M, (int64_t)(kt + 1) * GEMM_BK, K, tid, ra);
-      gemm_load_tile<VEC>(B, ldb, n0, N, (int64_t)(kt + 1) * GEMM_BK, K, tid, rb);
+      gemm_load_tile<VEC>(A, lda, a_row, (int64_t)(kt + 1) * GEMM_BK, K, tid, ra);
+      gemm_load_tile<VEC>(B, ldb, b_row, (int64_t)(kt + 1) * GEMM_BK, K, tid, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < GEMM_BK / 4; kk++) {
@@ -153,15 +169,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
       const int64_t col = n0 + wn * 64 + j * 16 + fr;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int64_t row = m0 + wm * 64 + i * 16 + fk + 4 * r;
-        if (row < M && col < N) Cm[row * ldc + col] = acc[i][j][r];
+        const int64_t row = s_rows[wm * 64 + i * 16 + fk + 4 * r];
+        if (row >= 0 && col < N) Cm[row * ldc + col] = acc[i][j][r];
       }
     }
 }
 
 inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const double *A,
                                      int64_t lda, const double *B, int64_t ldb, double *Cm,
-                                     int64_t ldc, hipStream_t stream) {
+                                     int64_t ldc, hipStream_t stream,
+                                     const int *row_idx = nullptr, const int *n_rows = nullptr,
+                                     unsigned long long *flop_counter = nullptr) {
   if (M <= 0 || N <= 0) return hipSuccess;
   const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
   const int total = Tm * Tn;
@@ -170,10 +188,10 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
                    ((uintptr_t)B % 16 == 0);
   if (vec)
     hipLaunchKernelGGL(gemm_nt_f64_kernel<true>, dim3(grid), dim3(256), 0, stream, M, N, K, A,
-                       lda, B, ldb, Cm, ldc);
+                       lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);
   else
     hipLaunchKernelGGL(gemm_nt_f64_kernel<false>, dim3(grid), dim3(256), 0, stream, M, N, K, A,
-                       lda, B, ldb, Cm, ldc);
+                       lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);
   return hipGetLastError();
 }
 

@@ -227,9 +227,10 @@ class Engine:
         self._check(self.lib.aehmc_profile_enable(self.ctx, int(on)), "aehmc_profile_enable")
 
     def profile_read(self):
-        ms, n = ct.c_double(), ct.c_int64()
-        self._check(self.lib.aehmc_profile_read(self.ctx, ct.byref(ms), ct.byref(n)), "aehmc_profile_read")
-        return ms.value, n.value
+        ms, n, fl = ct.c_double(), ct.c_int64(), ct.c_double()
+        self._check(self.lib.aehmc_profile_read(self.ctx, ct.byref(ms), ct.byref(n), ct.byref(fl)),
+                    "aehmc_profile_read")
+        return ms.value, n.value, fl.value
 
 
 _engines = {}

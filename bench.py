@@ -120,7 +120,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, device)
     total_leap = sum_over_ranks(int(n_leap.item()), device)
-    kern_ms, kern_n = eng.profile_read()
+    kern_ms, kern_n, kern_flops = eng.profile_read()
     eng.profile_enable(False)
     assert gathered.shape[0] == C * world
 
@@ -128,12 +128,15 @@ def main():
         return
     value = total_leap / elapsed
     if args.config == "c3":
-        flops = 2.0 * C * D * D  # algorithmic flops of one [C,D]x[D,D] launch (6*D^2 per leapfrog = 3 launches)
+        # algorithmic flops per launch = 2 * live_rows * D * D (live rows counted on the device;
+        # SURVEY.md 8d's per-leapfrog figure is one such row per mat-vec), / mean launch duration
+        flops = kern_flops / max(kern_n, 1)
         avg_s = kern_ms / 1e3 / max(kern_n, 1)
         achieved = flops / avg_s / 1e12
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                    "kernel": "gemm_nt_f64_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n}
+                    "kernel": "gemm_nt_f64_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
+                    "avg_rows_per_launch": flops / (2.0 * D * D), "gemm_share_of_step_time": kern_ms / 1e3 / elapsed}
     else:
         # fused HMC kernel: algorithmic bytes = SURVEY.md 8d streaming figure 48*D B per leapfrog per chain
         bytes_per_launch = 48.0 * D * C * 32

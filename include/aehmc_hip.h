@@ -89,8 +89,13 @@ const char *aehmc_last_error(const aehmc_ctx *ctx);
 int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *target);
 int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
 
-/* engine options: "fused_hmc" (default 1: register-resident single-launch HMC when the
- * metric is diagonal and the target coordinate-wise; 0 forces the lock-step path) */
+/* engine options (name, default):
+ *  "fused_hmc" 1    register-resident single-launch HMC when the metric is diagonal and the
+ *                   target coordinate-wise; 0 forces the lock-step path
+ *  "dense_linear" 1 dense metric: carry w = imm g with the state so that
+ *                   v_half = v - (eps/2) w, v' = v_half - (eps/2) w' (one metric GEMM per
+ *                   leapfrog); 0 forms imm p_half and imm p' directly as metrics.py:71 does
+ *  "compact" 1      NUTS: chains whose transition has finished drop out of the GEMMs */
 int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value);
 
 /* workspace the caller must provide to the step calls for C chains */
@@ -131,9 +136,12 @@ int aehmc_rng_bernoulli(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t n, con
 int aehmc_gemm_nt(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
                   const double *B, int64_t ldb, double *Cmat, int64_t ldc, void *stream);
 
-/* timing hooks for bench.py: HIP events around the last dominant-kernel launches */
+/* timing hooks for bench.py: HIP events (on the launch stream) around every launch of the
+ * dominant kernel (fp64 GEMM, or the fused HMC kernel) since profile_enable(1), and the
+ * algorithmic flops of those GEMM launches (2*rows*N*K with the live row count). */
 int aehmc_profile_enable(aehmc_ctx *ctx, int enable);
-int aehmc_profile_read(aehmc_ctx *ctx, double *kernel_ms_total, int64_t *kernel_launches);
+int aehmc_profile_read(aehmc_ctx *ctx, double *kernel_ms_total, int64_t *kernel_launches,
+                       double *gemm_flops_total);
 
 #ifdef __cplusplus
 }

@@ -174,6 +174,39 @@ def test_hmc_matches_oracle(kind, tkind, D):
         state = info.state._replace(momentum=None)
 
 
+@pytest.mark.parametrize("linear,compact", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_dense_options_match_oracle(eng, linear, compact):
+    """literal (3 GEMMs/leapfrog, as metrics.py forms imm.p) and linear (velocity carried by
+    linearity, 2 GEMMs/leapfrog) dense paths, with and without live-chain compaction."""
+    from aehmc_amd import RandomStream, hmc, nuts
+    eng.set_option("dense_linear", linear)
+    eng.set_option("compact", compact)
+    try:
+        D, C, eps, max_exp = 150, 9, 0.12, 7
+        r = np.random.default_rng(77)
+        tgt, otgt, imm = make_case("dense", "dense", D, r)
+        seeds = [900 + c for c in range(C)]
+        q0 = r.normal(size=(C, D))
+        srng = RandomStream(seeds=seeds)
+        kernel = nuts.new_kernel(srng, tgt, max_num_expansions=max_exp)
+        hkernel = hmc.new_kernel(srng, tgt)
+        state = nuts.new_state(dev(q0), tgt)
+        rng, hrng = co.site_states(seeds, 4), co.site_states(seeds, 2, first_site=4)
+        metric = co.Metric(imm, D)
+        q, U, g = co.new_state(otgt, q0.copy())
+        for _ in range(3):
+            info, _ = kernel(state, eps, imm)
+            res = co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=max_exp)
+            check_state(info, q, U, g, res)
+            state = info.state._replace(momentum=None)
+        info, _ = hkernel(state, eps, imm, 11)   # dense HMC continues the same srng (sites 5, 6)
+        res = co.hmc_step(otgt, metric, hrng, eps, 11, q, U, g)
+        check_state(info, q, U, g, res, nuts=False)
+    finally:
+        eng.set_option("dense_linear", 1)
+        eng.set_option("compact", 1)
+
+
 def test_hmc_fused_equals_lockstep_bitwise(eng):
     """The register-resident single-launch HMC kernel and the generic lock-step path run
     the same arithmetic in the same order."""
