@@ -733,6 +733,10 @@ __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long 
   }
   if ((threadIdx.x & 63) == 0) pcg_store(rng + c * 4, g);
 }
+__global__ __launch_bounds__(256) void k_fill_i64(long long *x, long long n, long long v) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long long)gridDim.x * blockDim.x) x[i] = v;
+}
 __global__ void k_log(const double *x, double *y, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = log(x[i]);

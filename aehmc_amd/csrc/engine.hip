@@ -447,22 +447,25 @@ extern "C" int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double 
   return 0;
 }
 
-extern "C" int aehmc_hmc_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
-                              int64_t L, double divergence_threshold, double *q, double *U,
-                              double *g, const aehmc_diagnostics *out, void *stream) {
-  if (!ctx || !out) return -2;
-  HIPCHK(hipSetDevice(ctx->device));
-  hipStream_t st = (hipStream_t)stream;
+// T HMC transitions of every chain; optional per-transition outputs (samples [T,C,D],
+// acc_hist [T,C], div_hist [T,C])
+static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, int64_t L,
+                   double divergence_threshold, int64_t T, double *q, double *U, double *g,
+                   const aehmc_diagnostics *out, double *samples, double *acc_hist,
+                   int32_t *div_hist, hipStream_t st) {
   if (L < 0) FAIL("num_integration_steps must be >= 0");
+  if (T < 1) FAIL("number of transitions must be >= 1");
   if (!out->acceptance_probability || !out->is_diverging) FAIL("diagnostics arrays missing");
   if (!ctx->has_tgt || !ctx->has_met) FAIL("set_target and set_metric must be called first");
+  const int64_t D = ctx->tgt.D;
   // fused register-resident path (hmc_fused.cuh): diagonal/scalar metric, coordinate-wise target
-  if (ctx->opt_fused_hmc && hmc_fused_supported(ctx->tgt.kind, ctx->met.ndim, ctx->tgt.D)) {
+  if (ctx->opt_fused_hmc && hmc_fused_supported(ctx->tgt.kind, ctx->met.ndim, D)) {
     HmcFusedArgs f{};
-    f.C = C; f.D = ctx->tgt.D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
+    f.C = C; f.D = D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
     f.met_ndim = ctx->met.ndim; f.imm = ctx->met.imm; f.sqrt_mass = ctx->met.sqrt_mass;
     f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
     f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
+    f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;
     const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
     if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
     HIPCHK(launch_hmc_fused(f, st));
@@ -477,12 +480,44 @@ extern "C" int aehmc_hmc_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double s
   a.eps = step_size; a.thr = divergence_threshold;
   a.rng = rng; a.nsites = 2;
   a.q = q; a.U = U; a.g = g; a.out = *out;
-  if (int rc = launch_begin(ctx, a, false, st)) return rc;
-  for (int64_t l = 0; l < L; l++)
-    if (int rc = launch_leapfrog(ctx, a, false, l == L - 1, st)) return rc;
-  if (a.met_ndim == 2) LAUNCH(k_hmc_end<true>, C, st, a, (long long)L);
-  else LAUNCH(k_hmc_end<false>, C, st, a, (long long)L);
+  for (int64_t t = 0; t < T; t++) {
+    if (int rc = launch_begin(ctx, a, false, st)) return rc;
+    for (int64_t l = 0; l < L; l++)
+      if (int rc = launch_leapfrog(ctx, a, false, l == L - 1, st)) return rc;
+    if (a.met_ndim == 2) LAUNCH(k_hmc_end<true>, C, st, a, (long long)L);
+    else LAUNCH(k_hmc_end<false>, C, st, a, (long long)L);
+    if (samples)
+      HIPCHK(hipMemcpyAsync(samples + (size_t)t * C * D, q, (size_t)C * D * sizeof(double),
+                            hipMemcpyDeviceToDevice, st));
+    if (acc_hist)
+      HIPCHK(hipMemcpyAsync(acc_hist + (size_t)t * C, out->acceptance_probability, C * sizeof(double),
+                            hipMemcpyDeviceToDevice, st));
+    if (div_hist)
+      HIPCHK(hipMemcpyAsync(div_hist + (size_t)t * C, out->is_diverging, C * sizeof(int32_t),
+                            hipMemcpyDeviceToDevice, st));
+  }
+  if (T > 1 && out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
   return 0;
+}
+
+extern "C" int aehmc_hmc_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                              int64_t L, double divergence_threshold, double *q, double *U,
+                              double *g, const aehmc_diagnostics *out, void *stream) {
+  if (!ctx || !out) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  return hmc_run(ctx, C, rng, step_size, L, divergence_threshold, 1, q, U, g, out, nullptr, nullptr,
+                 nullptr, (hipStream_t)stream);
+}
+
+extern "C" int aehmc_hmc_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                                int64_t L, double divergence_threshold, int64_t num_samples,
+                                double *q, double *U, double *g, const aehmc_diagnostics *out,
+                                double *samples, double *acceptance_history,
+                                int32_t *divergence_history, void *stream) {
+  if (!ctx || !out) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  return hmc_run(ctx, C, rng, step_size, L, divergence_threshold, num_samples, q, U, g, out, samples,
+                 acceptance_history, divergence_history, (hipStream_t)stream);
 }
 
 extern "C" int aehmc_leapfrog(aehmc_ctx *ctx, int64_t C, double step_size, int64_t nsteps, double *q,

@@ -168,6 +168,21 @@ class Engine:
                                             self.stream), "aehmc_hmc_step")
         return out
 
+    def hmc_sample(self, rng, eps, L, thr, n, q, U, g, keep_samples=True):
+        C, D = q.shape
+        self.ensure_workspace(C, 1)
+        out, c = self._diag(C, D, False)
+        dev = self.device
+        samples = torch.empty(n, C, D, dtype=torch.float64, device=dev) if keep_samples else None
+        acc = torch.empty(n, C, dtype=torch.float64, device=dev)
+        div = torch.empty(n, C, dtype=torch.int32, device=dev)
+        self._check(self.lib.aehmc_hmc_sample(
+            self.ctx, C, rng.data_ptr(), float(eps), int(L), float(thr), int(n), q.data_ptr(),
+            U.data_ptr(), g.data_ptr(), ct.byref(c), samples.data_ptr() if keep_samples else None,
+            acc.data_ptr(), div.data_ptr(), self.stream), "aehmc_hmc_sample")
+        out["samples"], out["acceptance_history"], out["divergence_history"] = samples, acc, div
+        return out
+
     def nuts_step(self, rng, eps, max_exp, thr, q, U, g):
         C, D = q.shape
         self.ensure_workspace(C, max_exp)

@@ -44,4 +44,34 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
             n_leapfrog=layout.per_chain(out["n_leapfrog"]))
         return info, {srng: holder["rng"]}
 
+    def sample(state: IntegratorState, step_size, inverse_mass_matrix, num_integration_steps: int,
+               num_samples: int, keep_samples: bool = True):
+        """``num_samples`` consecutive transitions per chain in one engine call -- the
+        user-level ``aesara.scan(kernel, n_steps=N)`` loop of the reference
+        (tests/test_hmc.py:138-148).  Returns ``(samples [N, ...], Diagnostics of the last
+        transition, acceptance history [N, ...], divergence history [N, ...])``."""
+        eng = get_engine()
+        layout = Layout(tuple(state.position.shape), srng.batched, srng.num_chains)
+        if "rng" not in holder:
+            holder["rng"] = rng_to_device(rng_host, eng.device)
+        q, U, g = state_rows(state, layout, eng.device)
+        eng.set_target(logprob_fn, layout.D)
+        eng.set_metric(inverse_mass_matrix, layout.D)
+        out = eng.hmc_sample(holder["rng"], float(step_size), int(num_integration_steps),
+                             float(divergence_threshold), int(num_samples), q, U, g, keep_samples)
+        info = Diagnostics(
+            state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
+                                  potential_energy=layout.per_chain(U),
+                                  potential_energy_grad=layout.vec(g)),
+            acceptance_probability=layout.per_chain(out["acceptance_probability"]),
+            num_doublings=None, is_turning=None,
+            is_diverging=layout.per_chain(out["is_diverging"].bool()),
+            n_leapfrog=layout.per_chain(out["n_leapfrog"]))
+        n = int(num_samples)
+        samples = out["samples"].reshape((n,) + layout.user_shape) if keep_samples else None
+        hist_shape = (n,) + layout.scalar_chain_shape
+        return (samples, info, out["acceptance_history"].reshape(hist_shape),
+                out["divergence_history"].bool().reshape(hist_shape))
+
+    step.sample = sample
     return step

@@ -111,6 +111,17 @@ int aehmc_hmc_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
                    int64_t num_integration_steps, double divergence_threshold, double *q,
                    double *U, double *g, const aehmc_diagnostics *out, void *stream);
 
+/* num_samples consecutive HMC transitions per chain in one call -- the user-level loop
+ * `aesara.scan(kernel, n_steps=N)` of tests/test_hmc.py:138-148 / README.md.  One launch
+ * when the fused path applies.  Optional outputs: samples [N,C,D] (position after every
+ * transition), acceptance_history [N,C], divergence_history [N,C]; `out` describes the
+ * last transition, out->n_leapfrog the total. */
+int aehmc_hmc_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                     int64_t num_integration_steps, double divergence_threshold,
+                     int64_t num_samples, double *q, double *U, double *g,
+                     const aehmc_diagnostics *out, double *samples, double *acceptance_history,
+                     int32_t *divergence_history, void *stream);
+
 /* nuts.new_kernel(...)(state, step_size, imm) -- nuts.py:56-153, trajectory.py:154-374,428-714,
  * termination.py:19-235, proposals.py.  rng [C,4,4]: #1 momentum, #2 direction,
  * #3 uniform progressive, #4 biased progressive.  q,U,g updated in place. */

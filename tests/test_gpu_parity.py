@@ -232,6 +232,34 @@ def test_hmc_fused_equals_lockstep_bitwise(eng):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_hmc_sample_equals_repeated_steps(eng, fused):
+    """kernel.sample(N) (one launch on the fused path) == N calls of kernel(...)"""
+    from aehmc_amd import RandomStream, hmc, targets
+    r = np.random.default_rng(4)
+    D, C, L, N = 70, 16, 7, 6
+    q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
+    tgt = targets.DiagGaussian(r.normal(size=D), 0.5 + r.random(D))
+    eng.set_option("fused_hmc", fused)
+    try:
+        k1 = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        k2 = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        s1 = hmc.new_state(dev(q0), tgt)
+        samples, info, acc_hist, div_hist = k1.sample(s1, 0.15, imm, L, N)
+        s2 = hmc.new_state(dev(q0), tgt)
+        for t in range(N):
+            i2, _ = k2(s2, 0.15, imm, L)
+            s2 = i2.state._replace(momentum=None)
+            assert torch.equal(samples[t], i2.state.position)
+            assert torch.equal(acc_hist[t], i2.acceptance_probability)
+        assert torch.equal(info.state.position, i2.state.position)
+        assert torch.equal(info.state.momentum, i2.state.momentum)
+        assert torch.equal(info.state.potential_energy, i2.state.potential_energy)
+        assert info.n_leapfrog.sum().item() == C * L * N
+    finally:
+        eng.set_option("fused_hmc", 1)
+
+
 # ------------------------------------------------------------------ divergence / phantom scan
 @pytest.mark.parametrize("step_size, div, turn, doublings",
                          [(100000.0, True, False, 1), (0.0000001, False, False, 10), (1.0, False, True, 1)])
