@@ -52,6 +52,8 @@ struct EngineArgs {
   // target
   int tkind;
   const double *mu, *sigma, *log_sigma;
+  const double *X, *y;  // linreg data [N]
+  long long N;
   // per-chain RNG [C, nsites, 4]
   uint64_t *rng;
   int nsites;
@@ -700,6 +702,65 @@ __global__ __launch_bounds__(256) void k_is_turning(EngineArgs a, const double *
   d_r = wave_sum(d_r);
   if (lane == 0) out[c] = (d_l <= 0) | (d_r <= 0);
 }
+// examples/LinearRegression.ipynb:126-166 target, q = [w, log n]: U and dU/dq need sums
+// over the N data rows.  One 256-thread block serves 8 chains: every thread streams its
+// rows of (X, y) once (from L2) and accumulates sum(x r) and sum(r^2), r = y - x w, for
+// all 8 chains; wave shuffles + a fixed-order LDS pass finish the reduction
+// (deterministic).  to_ctl: write U into ctl[c].U_cur (leapfrog) or into U[c] (new_state).
+constexpr int LINREG_CPB = 8;
+__global__ __launch_bounds__(256) void k_target_linreg(EngineArgs a, const double *q, double *g,
+                                                       double *U, int to_ctl) {
+  __shared__ double part[4][2 * LINREG_CPB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long c0 = (long long)blockIdx.x * LINREG_CPB;
+  double w[LINREG_CPB], sxr[LINREG_CPB], srr[LINREG_CPB];
+  bool live[LINREG_CPB];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < LINREG_CPB; k++) {
+    const long long c = c0 + k;
+    live[k] = c < a.C && !(to_ctl && a.ctl[c].done);
+    w[k] = live[k] ? q[c * 2] : 0.0;
+    sxr[k] = srr[k] = 0.0;
+    any |= live[k];
+  }
+  if (!any) return;
+  for (long long i = tid; i < a.N; i += 256) {
+    const double x = a.X[i], yy = a.y[i];
+#pragma unroll
+    for (int k = 0; k < LINREG_CPB; k++) {
+      const double r = yy - x * w[k];
+      sxr[k] += x * r;
+      srr[k] += r * r;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < LINREG_CPB; k++) {
+    sxr[k] = wave_sum(sxr[k]);
+    srr[k] = wave_sum(srr[k]);
+    if (lane == 0) {
+      part[wave][2 * k] = sxr[k];
+      part[wave][2 * k + 1] = srr[k];
+    }
+  }
+  __syncthreads();
+  if (tid < LINREG_CPB && live[tid]) {
+    const int k = tid;
+    const long long c = c0 + k;
+    const double s_xr = ((part[0][2 * k] + part[1][2 * k]) + part[2][2 * k]) + part[3][2 * k];
+    const double s_rr = ((part[0][2 * k + 1] + part[1][2 * k + 1]) + part[2][2 * k + 1]) + part[3][2 * k + 1];
+    const double ww = q[c * 2], ell = q[c * 2 + 1], n = exp(ell), n2 = n * n, N = (double)a.N;
+    const double lp_w = -0.5 * ww * ww - AEHMC_LOG_SQRT_2PI;
+    const double lp_n = log(n) - n + ell;
+    const double lp_y = -0.5 * (s_rr / n2) - N * AEHMC_LOG_SQRT_2PI - N * ell;
+    g[c * 2] = -(-ww + s_xr / n2);
+    g[c * 2 + 1] = -(2.0 - n - N + s_rr / n2);
+    const double Uv = -(lp_w + lp_n + lp_y);
+    if (to_ctl) a.ctl[c].U_cur = Uv;
+    else U[c] = Uv;
+  }
+}
+
 // leapfrog-only driver state: ctl.dir = 1, U in ctl
 __global__ __launch_bounds__(256) void k_ctl_set(EngineArgs a, const double *U) {
   AEHMC_CHAIN_OF_WAVE();

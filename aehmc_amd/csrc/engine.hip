@@ -231,6 +231,7 @@ static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a) {
   a.mu = ctx->tgt.mu;
   a.sigma = ctx->tgt.sigma;
   a.log_sigma = ctx->log_sigma;
+  a.X = ctx->tgt.X; a.y = ctx->tgt.y; a.N = ctx->tgt.N;
   a.linear = (a.met_ndim == 2 && ctx->opt_dense_linear) ? 1 : 0;
   return 0;
 }
@@ -312,23 +313,32 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
   const bool md = a.met_ndim == 2;
   const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
   const int64_t C = a.C, D = a.D;
-  if (a.tkind == AEHMC_T_LINREG) FAIL("linreg target: not implemented on the lock-step path yet");
-  if (!md && !tdense) {
+  const bool tlin = a.tkind == AEHMC_T_LINREG;
+  // targets evaluated between the stages: dense MVN (GEMM) or linear regression (row sums)
+  auto target_ext = [&]() -> int {
+    if (tdense) return gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr);
+    hipLaunchKernelGGL(k_target_linreg, dim3((unsigned)((C + LINREG_CPB - 1) / LINREG_CPB)), dim3(256), 0,
+                       st, a, (const double *)a.cur_q, a.cur_g, (double *)nullptr, 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+  };
+  const bool text = tdense || tlin;
+  if (!md && !text) {
     if (book) LAUNCH((k_step<true, true, true, false, true>), C, st, a);
     else LAUNCH((k_step<true, true, true, false, false>), C, st, a);
     return 0;
   }
-  if (!md && tdense) {
+  if (!md && text) {
     LAUNCH((k_step<true, true, false, false, false>), C, st, a);
-    if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr)) return -1;
+    if (target_ext()) return -1;
     if (book) LAUNCH((k_step<false, false, true, false, true>), C, st, a);
     else LAUNCH((k_step<false, false, true, false, false>), C, st, a);
     return 0;
   }
   if (a.linear) {  // dense metric, v carried by linearity: one metric GEMM (w' = imm g')
     LAUNCH((k_step_linear<12, false>), C, st, a);
-    if (tdense)
-      if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr)) return -1;
+    if (text)
+      if (target_ext()) return -1;
     if (gemm(ctx, C, D, D, a.cur_g, D, ctx->met.imm, D, a.cur_w, D, st, ri, nr)) return -1;
     if (book) LAUNCH((k_step_linear<3, true>), C, st, a);
     else LAUNCH((k_step_linear<3, false>), C, st, a);
@@ -337,11 +347,11 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
   // dense metric, literal: v_half = imm p_half and v' = imm p' formed directly
   LAUNCH((k_step<true, false, false, true, false>), C, st, a);
   if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.vhalf, D, st, ri, nr)) return -1;
-  if (!tdense) {
+  if (!text) {
     LAUNCH((k_step<false, true, true, true, false>), C, st, a);
   } else {
     LAUNCH((k_step<false, true, false, true, false>), C, st, a);
-    if (gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr)) return -1;
+    if (target_ext()) return -1;
     LAUNCH((k_step<false, false, true, true, false>), C, st, a);
   }
   if (need_v || book)
@@ -390,6 +400,12 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
     LAUNCH(k_residual, C, st, a, q, a.rbuf);
     if (gemm(ctx, C, a.D, a.D, a.rbuf, a.D, ctx->tgt.prec, a.D, g, a.D, st)) return -1;
     LAUNCH(k_half_dot, C, st, a, (const double *)a.rbuf, (const double *)g, U);
+    return 0;
+  }
+  if (a.tkind == AEHMC_T_LINREG) {
+    hipLaunchKernelGGL(k_target_linreg, dim3((unsigned)((C + LINREG_CPB - 1) / LINREG_CPB)), dim3(256), 0,
+                       st, a, q, g, U, 0);
+    HIPCHK(hipGetLastError());
     return 0;
   }
   FAIL("new_state: target kind not implemented");

@@ -161,18 +161,16 @@ static double target_eval(const ao_target *t, const double *q, double *g, double
   }
   case AO_T_LINREG: { /* examples/LinearRegression.ipynb:126-166; q = [w, log n] */
     double w = q[0], ell = q[1], n = exp(ell), n2 = n * n;
-    double s_xr = 0.0, s_rr = 0.0, s_z2 = 0.0;
+    double s_xr = 0.0, s_rr = 0.0;
     for (int64_t i = 0; i < t->N; i++) {
       double r = t->y[i] - t->X[i] * w;
       s_xr += t->X[i] * r;
       s_rr += r * r;
-      double z = r / n;
-      s_z2 += z * z;
     }
     double N = (double)t->N;
     double lp_w = -0.5 * w * w - LOG_SQRT_2PI;
     double lp_n = log(n) - n + ell;
-    double lp_y = -0.5 * s_z2 - N * LOG_SQRT_2PI - N * ell;
+    double lp_y = -0.5 * (s_rr / n2) - N * LOG_SQRT_2PI - N * ell;
     g[0] = -(-w + s_xr / n2);
     g[1] = -(2.0 - n - N + s_rr / n2);
     return -(lp_w + lp_n + lp_y);

@@ -138,7 +138,7 @@ class LinearRegression:
         N = self.X.shape[0]
         lp_w = -0.5 * w * w - LOG_SQRT_2PI
         lp_n = np.log(n) - n + ell  # Gamma(2,1): log n - n - lgamma(2); + Jacobian
-        lp_y = -0.5 * np.sum((r / n) ** 2) - N * LOG_SQRT_2PI - N * ell
+        lp_y = -0.5 * (np.sum(r * r) / (n * n)) - N * LOG_SQRT_2PI - N * ell
         return float(lp_w + lp_n + lp_y)
 
     def __call__(self, q):

@@ -81,6 +81,51 @@ def test_g1_readme_bit_exact_on_gpu():
     assert srng in updates
 
 
+# ------------------------------------------------------------------ G2 / G3 on the GPU
+def test_g2_g3_regression_on_gpu(regression_data):
+    """examples/LinearRegression.ipynb: log-density at [3, log 10] (:188) and the single HMC
+    step from [3, log .21], eps=5e-5, L=1024, imm=[1,1], seed 0 (:293-297)."""
+    from aehmc_amd import RandomStream, hmc, targets
+    X, y = regression_data
+    tgt = targets.LinearRegression(X, y)
+    s = hmc.new_state(np.array([3.0, np.log(10.0)]), tgt)
+    assert -s.potential_energy.item() == pytest.approx(-32238.026021294307, rel=1e-12)
+    kernel = hmc.new_kernel(RandomStream(seed=0), tgt)
+    info, _ = kernel(hmc.new_state(np.array([3.0, np.log(0.21)]), tgt), 5e-5, np.array([1.0, 1.0]), 1024)
+    np.testing.assert_allclose(info.state.position.cpu().numpy(), [2.99946192, -1.30494977], atol=5e-9)
+    assert info.state.potential_energy.item() == pytest.approx(12433.00653542, abs=5e-9)
+    np.testing.assert_allclose(info.state.potential_energy_grad.cpu().numpy(),
+                               [-489.93218536, -22571.36970197], atol=5e-9)
+    assert info.acceptance_probability.item() == 1.0 and not info.is_diverging.item()
+
+
+@pytest.mark.parametrize("metric_kind", ["diag", "dense"])
+def test_regression_nuts_matches_oracle(regression_data, metric_kind):
+    """NUTS on the notebook's regression posterior (notebook cell 36 settings), 12 chains."""
+    from aehmc_amd import RandomStream, nuts, targets
+    X, y = regression_data
+    C = 12
+    r = np.random.default_rng(2)
+    tgt, otgt = targets.LinearRegression(X, y), co.Target(co.T_LINREG, 2, X=X, y=y)
+    imm = np.array([2.13e-05, 4.43e-05])
+    if metric_kind == "dense":
+        imm = np.array([[2.13e-05, 5e-6], [5e-6, 4.43e-05]])
+    eps = 0.8
+    seeds = [77 + c for c in range(C)]
+    q0 = np.array([3.0, np.log(0.49)]) + 0.01 * r.normal(size=(C, 2))
+    srng = RandomStream(seeds=seeds)
+    kernel = nuts.new_kernel(srng, tgt)
+    state = nuts.new_state(dev(q0), tgt)
+    rng, metric = co.site_states(seeds, 4), co.Metric(imm, 2)
+    q, U, g = co.new_state(otgt, q0.copy())
+    for _ in range(3):
+        info, _ = kernel(state, eps, imm)
+        res = co.nuts_step(otgt, metric, rng, eps, q, U, g)
+        # sums over 1e4 rows in a different order: 1e-9 on the state, exact discrete outputs
+        check_state(info, q, U, g, res)
+        state = info.state._replace(momentum=None)
+
+
 # ------------------------------------------------------------------ helpers
 def make_case(kind, tkind, D, r):
     from aehmc_amd import targets
