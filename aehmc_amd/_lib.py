@@ -17,8 +17,14 @@ class CTarget(ct.Structure):
 
 
 class CMetric(ct.Structure):
-    _fields_ = [("ndim", ct.c_int32), ("reserved", ct.c_int32), ("D", ct.c_int64),
+    _fields_ = [("ndim", ct.c_int32), ("per_chain", ct.c_int32), ("D", ct.c_int64),
                 ("imm", ct.c_void_p), ("sqrt_mass", ct.c_void_p)]
+
+
+class CAdaptState(ct.Structure):
+    _fields_ = [(n, ct.c_void_p) for n in ("da_step", "da_x", "da_x_avg", "da_g_avg", "da_mu",
+                                           "wc_mean", "wc_m2", "wc_n", "step_size", "imm",
+                                           "sqrt_mass")]
 
 
 class CDiagnostics(ct.Structure):
@@ -35,6 +41,10 @@ SYMBOLS = {
     "aehmc_last_error": (ct.c_char_p, [_P]),
     "aehmc_set_target": (_I, [_P, ct.POINTER(CTarget)]),
     "aehmc_set_metric": (_I, [_P, ct.POINTER(CMetric)]),
+    "aehmc_set_step_sizes": (_I, [_P, _P]),
+    "aehmc_adapt_init": (_I, [_P, _I64, _I64, _D, ct.POINTER(CAdaptState), _P]),
+    "aehmc_adapt_update": (_I, [_P, _I64, _I64, ct.c_int32, ct.c_int32, ct.c_int32, _D, _P, _P,
+                                ct.POINTER(CAdaptState), _P]),
     "aehmc_set_option": (_I, [_P, ct.c_char_p, _I64]),
     "aehmc_workspace_bytes": (_I64, [_P, _I64, _I64]),
     "aehmc_set_workspace": (_I, [_P, _P, _I64]),

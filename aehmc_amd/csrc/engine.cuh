@@ -45,9 +45,11 @@ struct ChainCtl {
 struct EngineArgs {
   long long C, D;
   double eps, thr;
+  const double *eps_c;  // optional per-chain step sizes [C] (window adaptation is per chain)
   int max_exp;
-  // metric (metrics.py:44-63)
+  // metric (metrics.py:44-63); imm_cs: chain stride of imm / sqrt_mass (0 = shared)
   int met_ndim;
+  long long imm_cs;
   const double *imm, *sqrt_mass;
   // target
   int tkind;
@@ -116,8 +118,8 @@ __device__ __forceinline__ bool target_is_elem(int k) {
   return k == AEHMC_T_STD_NORMAL || k == AEHMC_T_ISO_GAUSSIAN || k == AEHMC_T_DIAG_GAUSSIAN;
 }
 // diagonal / scalar velocity imm o p (metrics.py:47,51,71)
-__device__ __forceinline__ double vel_diag(const EngineArgs &a, long long i, double p) {
-  return (a.met_ndim == 0 ? a.imm[0] : a.imm[i]) * p;
+__device__ __forceinline__ double vel_diag(const EngineArgs &a, long long c, long long i, double p) {
+  return a.imm[c * a.imm_cs + (a.met_ndim == 0 ? 0 : i)] * p;
 }
 
 // ---------------------------------------------------------------------------------
@@ -130,7 +132,7 @@ __device__ __forceinline__ double vel_diag(const EngineArgs &a, long long i, dou
 template <bool DO1, bool DO2, bool DO3, bool MET_DENSE>
 __device__ __forceinline__ bool leap_stages(const EngineArgs &a, long long c, int lane, int dir,
                                             double &U_out) {
-  const double step_size = (dir ? 1.0 : -1.0) * a.eps;
+  const double step_size = (dir ? 1.0 : -1.0) * (a.eps_c ? a.eps_c[c] : a.eps);
   const double b = 0.5 * step_size, aa = 1 * step_size;
   const size_t row = (size_t)c * a.D;
   const bool elem = target_is_elem(a.tkind);
@@ -141,7 +143,7 @@ __device__ __forceinline__ bool leap_stages(const EngineArgs &a, long long c, in
     double gnew = 0.0;
     if (DO1) p = p - b * a.cur_g[row + i];
     if (DO2) {
-      double v = MET_DENSE ? a.vhalf[row + i] : vel_diag(a, i, p);
+      double v = MET_DENSE ? a.vhalf[row + i] : vel_diag(a, c, i, p);
       double q = a.cur_q[row + i] + aa * v;
       a.cur_q[row + i] = q;
       if (elem) {
@@ -174,7 +176,7 @@ __device__ __forceinline__ bool leap_stages(const EngineArgs &a, long long c, in
 template <int PHASE>
 __device__ __forceinline__ bool leap_linear(const EngineArgs &a, long long c, int lane, int dir,
                                             double &U_out) {
-  const double step_size = (dir ? 1.0 : -1.0) * a.eps;
+  const double step_size = (dir ? 1.0 : -1.0) * (a.eps_c ? a.eps_c[c] : a.eps);
   const double b = 0.5 * step_size, aa = 1 * step_size;
   const size_t row = (size_t)c * a.D;
   const bool elem = target_is_elem(a.tkind);
@@ -273,8 +275,8 @@ __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c,
   double d_l = 0.0, d_r = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
     double pc = a.cur_p[row + i], po = a.end_p[oth][row + i];
-    double vc = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, pc);
-    double vo = MET_DENSE ? a.end_v[oth][row + i] : vel_diag(a, i, po);
+    double vc = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, c, i, pc);
+    double vo = MET_DENSE ? a.end_v[oth][row + i] : vel_diag(a, c, i, po);
     double s = a.psum[row + i] + a.psub[row + i];
     a.psum[row + i] = s;
     double pl = dir ? po : pc, pr = dir ? pc : po;
@@ -345,7 +347,7 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
     double p = a.cur_p[row + i];
-    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, p);
+    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, c, i, p);
     kd += v * p;
     double s = (step == 0) ? p : a.psub[row + i] + p;  // trajectory.py:278,243
     a.psub[row + i] = s;
@@ -400,8 +402,8 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
         double d_l = 0.0, d_r = 0.0;
         for (long long i = lane; i < a.D; i += 64) {
           double pl = kp[i], pr = a.cur_p[row + i];
-          double vl = MET_DENSE ? kv[i] : vel_diag(a, i, pl);
-          double vr = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, pr);
+          double vl = MET_DENSE ? kv[i] : vel_diag(a, c, i, pl);
+          double vr = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, c, i, pr);
           double sub = a.psub[row + i] - ks[i] + pl;
           double rho = sub - (pr + pl) / 2;
           d_l += vl * rho;
@@ -440,7 +442,7 @@ __device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lan
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
     double q = a.q[row + i], g = a.g[row + i], p = a.cur_p[row + i];
-    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, p);
+    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, c, i, p);
     kd += v * p;
     a.cur_q[row + i] = q;
     a.cur_g[row + i] = g;
@@ -485,7 +487,7 @@ __device__ inline void draw_momentum(const EngineArgs &a, long long c, int lane)
   const size_t row = (size_t)c * a.D;
   Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4);
   double *dst = MET_DENSE ? a.zbuf : a.cur_p;
-  const double *sm = a.sqrt_mass;
+  const double *sm = a.sqrt_mass + c * a.imm_cs;
   const bool scalar = a.met_ndim == 0;
   wave_normals(g1, a.D, [=](long long i, double z) {
     dst[row + i] = MET_DENSE ? z : (scalar ? sm[0] : sm[i]) * z;
@@ -591,7 +593,7 @@ __device__ inline void hmc_init_chain(const EngineArgs &a, long long c, int lane
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
     double p = a.cur_p[row + i];
-    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, i, p);
+    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, c, i, p);
     kd += v * p;
     a.cur_q[row + i] = a.q[row + i];
     a.cur_g[row + i] = a.g[row + i];
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256) void k_hmc_end(EngineArgs a, long long L) {
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
     double p = -1.0 * a.cur_p[row + i];  // hmc.py:185 momentum flip
-    double v = MET_DENSE ? -1.0 * a.cur_v[row + i] : vel_diag(a, i, p);
+    double v = MET_DENSE ? -1.0 * a.cur_v[row + i] : vel_diag(a, c, i, p);
     kd += v * p;
   }
   kd = wave_sum(kd);
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(256) void k_half_dot(EngineArgs a, const double *x,
 __global__ __launch_bounds__(256) void k_vel_diag(EngineArgs a, const double *p, double *v) {
   AEHMC_CHAIN_OF_WAVE();
   const size_t row = (size_t)c * a.D;
-  for (long long i = lane; i < a.D; i += 64) v[row + i] = vel_diag(a, i, p[row + i]);
+  for (long long i = lane; i < a.D; i += 64) v[row + i] = vel_diag(a, c, i, p[row + i]);
 }
 __global__ __launch_bounds__(256) void k_is_turning(EngineArgs a, const double *pl, const double *pr,
                                                     const double *ps, const double *vl,
@@ -794,6 +796,92 @@ __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long 
   }
   if ((threadIdx.x & 63) == 0) pcg_store(rng + c * 4, g);
 }
+// ---- window adaptation (window_adaptation.py:119-227), one wave per chain ---------
+struct AdaptArgs {
+  long long C, D;
+  int stage, window_end, last;      // schedule entry of this warm-up step
+  double target, gamma, t0, kappa;  // step_size.py:9-14 defaults 0.8, 0.05, 10, 0.75
+  const double *p_accept, *position;
+  aehmc_adapt_state s;
+};
+__global__ __launch_bounds__(256) void k_adapt_init(AdaptArgs a, double initial_step_size) {
+  const int lane = threadIdx.x & 63;
+  const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= a.C) return;
+  for (long long i = lane; i < a.D; i += 64) {  // mass_matrix.py:37-61
+    a.s.wc_mean[c * a.D + i] = 0.0;
+    a.s.wc_m2[c * a.D + i] = 0.0;
+    a.s.imm[c * a.D + i] = 1.0;
+    a.s.sqrt_mass[c * a.D + i] = 1.0;
+  }
+  if (lane == 0) {  // algorithms.py:56-76, window_adaptation.py:139-140
+    a.s.da_step[c] = 1;
+    a.s.da_x[c] = 0.0;
+    a.s.da_x_avg[c] = 0.0;
+    a.s.da_g_avg[c] = 0.0;
+    a.s.da_mu[c] = initial_step_size;
+    a.s.wc_n[c] = 0;
+    a.s.step_size[c] = exp(0.0);
+  }
+}
+__global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= a.C) return;
+  // dual averaging, fast and slow stages alike (algorithms.py:104-115, step_size.py:97-98)
+  long long step = a.s.da_step[c];
+  const double x_old = a.s.da_x[c];
+  const double eta = 1.0 / ((double)step + a.t0);
+  const double gradient = a.target - a.p_accept[c];
+  double g_avg = (1.0 - eta) * a.s.da_g_avg[c] + eta * gradient;
+  double x = a.s.da_mu[c] - (sqrt((double)step) / a.gamma) * g_avg;
+  const double x_eta = pow((double)step, -a.kappa);
+  double x_avg = x_eta * x_old + (1.0 - x_eta) * a.s.da_x_avg[c];
+  double mu = a.s.da_mu[c];
+  step += 1;
+  double step_size = exp(x);
+  long long n = a.s.wc_n[c];
+  if (a.stage != 0) {  // Welford update with the new position (algorithms.py:187-197)
+    n += 1;
+    for (long long i = lane; i < a.D; i += 64) {
+      const double v = a.position[c * a.D + i];
+      double mean = a.s.wc_mean[c * a.D + i];
+      const double delta = v - mean;
+      mean = mean + delta / (double)n;
+      const double ud = v - mean;
+      a.s.wc_mean[c * a.D + i] = mean;
+      a.s.wc_m2[c * a.D + i] = a.s.wc_m2[c * a.D + i] + ud * delta;
+    }
+  }
+  if (a.window_end) {  // slow_final: window_adaptation.py:165-182, mass_matrix.py:83-118
+    const double nn = (double)n;
+    for (long long i = lane; i < a.D; i += 64) {
+      const double cov = a.s.wc_m2[c * a.D + i] / (double)(n - 1);
+      const double imm = (nn / (nn + 5)) * cov + 1e-3 * (5 / (nn + 5));
+      a.s.imm[c * a.D + i] = imm;
+      a.s.sqrt_mass[c * a.D + i] = sqrt(1.0 / imm);  // metrics.py:45,49
+      a.s.wc_mean[c * a.D + i] = 0.0;
+      a.s.wc_m2[c * a.D + i] = 0.0;
+    }
+    n = 0;
+    mu = step_size;  // da_init(step_size): the step size itself, not its log
+    step = 1;
+    x = 0.0;
+    x_avg = 0.0;
+    g_avg = 0.0;
+  }
+  if (a.last) step_size = exp(x_avg);  // window_adaptation.py:184-190
+  if (lane == 0) {
+    a.s.da_step[c] = step;
+    a.s.da_x[c] = x;
+    a.s.da_x_avg[c] = x_avg;
+    a.s.da_g_avg[c] = g_avg;
+    a.s.da_mu[c] = mu;
+    a.s.wc_n[c] = n;
+    a.s.step_size[c] = step_size;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_fill_i64(long long *x, long long n, long long v) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i < n; i += (long long)gridDim.x * blockDim.x) x[i] = v;

@@ -29,6 +29,7 @@ struct aehmc_ctx {
   aehmc_metric met{};
   bool has_met = false;
   double *log_sigma = nullptr;
+  const double *eps_c = nullptr;  // per-chain step sizes (aehmc_set_step_sizes)
   void *ws = nullptr;
   int64_t ws_bytes = 0;
   int *h_active = nullptr;  // pinned, device-visible
@@ -146,8 +147,51 @@ extern "C" int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *m) {
   if (m->ndim < 0 || m->ndim > 2)  // metrics.py:60-63
     FAIL("Expected a mass matrix of dimension 1 (diagonal) or 2, got " + std::to_string(m->ndim));
   if (!m->imm || !m->sqrt_mass || m->D <= 0) FAIL("metric needs imm, sqrt_mass and D");
+  if (m->per_chain && m->ndim == 2) FAIL("per-chain dense mass matrices are not supported");
   ctx->met = *m;
   ctx->has_met = true;
+  return 0;
+}
+
+extern "C" int aehmc_set_step_sizes(aehmc_ctx *ctx, const double *step_sizes) {
+  if (!ctx) return -2;
+  ctx->eps_c = step_sizes;
+  return 0;
+}
+
+static int adapt_args(aehmc_ctx *ctx, int64_t C, int64_t D, const aehmc_adapt_state *s, AdaptArgs &a) {
+  if (!s || C <= 0 || D <= 0) FAIL("adaptation: bad arguments");
+  if (!s->da_step || !s->da_x || !s->da_x_avg || !s->da_g_avg || !s->da_mu || !s->wc_mean ||
+      !s->wc_m2 || !s->wc_n || !s->step_size || !s->imm || !s->sqrt_mass)
+    FAIL("adaptation: state arrays missing");
+  memset(&a, 0, sizeof(a));
+  a.C = C; a.D = D; a.s = *s;
+  a.gamma = 0.05; a.t0 = 10; a.kappa = 0.75;  // step_size.py:9-14
+  return 0;
+}
+extern "C" int aehmc_adapt_init(aehmc_ctx *ctx, int64_t C, int64_t D, double initial_step_size,
+                                const aehmc_adapt_state *state, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  AdaptArgs a;
+  if (int rc = adapt_args(ctx, C, D, state, a)) return rc;
+  hipLaunchKernelGGL(k_adapt_init, chain_grid(C), dim3(256), 0, (hipStream_t)stream, a, initial_step_size);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t stage,
+                                  int32_t is_window_end, int32_t is_last, double target,
+                                  const double *p_accept, const double *position,
+                                  const aehmc_adapt_state *state, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  AdaptArgs a;
+  if (int rc = adapt_args(ctx, C, D, state, a)) return rc;
+  if (!p_accept || !position) FAIL("adaptation: acceptance_probability / position missing");
+  a.stage = stage; a.window_end = is_window_end; a.last = is_last; a.target = target;
+  a.p_accept = p_accept; a.position = position;
+  hipLaunchKernelGGL(k_adapt_update, chain_grid(C), dim3(256), 0, (hipStream_t)stream, a);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -227,6 +271,8 @@ static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a) {
   a.met_ndim = ctx->met.ndim;
   a.imm = ctx->met.imm;
   a.sqrt_mass = ctx->met.sqrt_mass;
+  a.imm_cs = ctx->met.per_chain ? (ctx->met.ndim == 0 ? 1 : ctx->met.D) : 0;
+  a.eps_c = ctx->eps_c;
   a.tkind = ctx->tgt.kind;
   a.mu = ctx->tgt.mu;
   a.sigma = ctx->tgt.sigma;
@@ -479,6 +525,8 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     HmcFusedArgs f{};
     f.C = C; f.D = D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
     f.met_ndim = ctx->met.ndim; f.imm = ctx->met.imm; f.sqrt_mass = ctx->met.sqrt_mass;
+    f.imm_cs = ctx->met.per_chain ? (ctx->met.ndim == 0 ? 1 : D) : 0;
+    f.eps_c = ctx->eps_c;
     f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
     f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
     f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;

@@ -20,7 +20,9 @@ namespace aehmc {
 struct HmcFusedArgs {
   long long C, D, L;
   double eps, thr;
+  const double *eps_c;  // optional per-chain step sizes
   int met_ndim;
+  long long imm_cs;     // chain stride of imm / sqrt_mass (0 = shared)
   const double *imm, *sqrt_mass;
   int tkind;
   const double *mu, *sigma, *log_sigma;
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
     const long long i = lane + 64 * r;
     ok[r] = i < a.D;
     const long long ii = ok[r] ? i : 0;
-    im[r] = a.met_ndim == 0 ? a.imm[0] : a.imm[ii];
-    sm[r] = a.met_ndim == 0 ? a.sqrt_mass[0] : a.sqrt_mass[ii];
+    im[r] = a.imm[c * a.imm_cs + (a.met_ndim == 0 ? 0 : ii)];
+    sm[r] = a.sqrt_mass[c * a.imm_cs + (a.met_ndim == 0 ? 0 : ii)];
     mu[r] = TK == AEHMC_T_DIAG_GAUSSIAN ? a.mu[ii] : 0.0;
     sg[r] = TK == AEHMC_T_DIAG_GAUSSIAN ? a.sigma[ii] : 1.0;
     q[r] = ok[r] ? a.q[row + ii] : 0.0;
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   double U = a.U[c];
   Pcg64 g1 = pcg_load(a.rng + (size_t)c * 8);      // site #1: momentum (hmc.py:122)
   Pcg64 g2 = pcg_load(a.rng + (size_t)c * 8 + 4);  // site #2: accept (hmc.py:194)
-  const double b = 0.5 * a.eps, aa = 1 * a.eps;
+  const double eps = a.eps_c ? a.eps_c[c] : a.eps;
+  const double b = 0.5 * eps, aa = 1 * eps;
   double pa = 0.0;
   int is_div = 0, acc = 0;
 

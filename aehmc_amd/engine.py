@@ -21,6 +21,16 @@ class EngineError(RuntimeError):
     pass
 
 
+class PerChain:
+    """Marks a step size [C] or a diagonal inverse mass matrix [C] / [C, D] as holding one
+    value (row) per chain -- what per-chain window adaptation produces.  The reference has
+    no chain axis, so a plain [C, D] array would be ambiguous with a dense [D, D] matrix."""
+
+    def __init__(self, value, sqrt_mass=None):
+        self.value = value
+        self.sqrt_mass = sqrt_mass
+
+
 class Engine:
     """One aehmc_ctx.  Not thread-safe (as the C-ABI)."""
 
@@ -84,6 +94,8 @@ class Engine:
     def set_metric(self, inverse_mass_matrix, D: int):
         """gaussian_metric(inverse_mass_matrix) -- aehmc/metrics.py:44-63."""
         imm = inverse_mass_matrix
+        if isinstance(imm, PerChain):
+            return self._set_metric_per_chain(imm, D)
         ndim = imm.ndim if hasattr(imm, "ndim") else np.ndim(imm)
         if ndim > 2:
             raise ValueError(
@@ -124,6 +136,36 @@ class Engine:
         if self.metric_ndim != ndim:
             self._ws = None
         self._metric_key, self.metric_ndim, self.metric_D = key, ndim, D
+
+    def _set_metric_per_chain(self, pc: PerChain, D: int):
+        t = _dev_f64(pc.value, self.device)
+        if t.ndim == 1:      # [C] scalar metrics (scalar positions): ndim 0
+            ndim, t = 0, t.reshape(-1, 1)
+        elif t.ndim == 2:    # [C, D] diagonal metrics
+            ndim = 1
+            if t.shape[1] != D:
+                raise ValueError(f"per-chain diagonal inverse mass matrix must be [C,{D}]")
+        else:
+            raise ValueError("PerChain inverse mass matrix must be [C] or [C, D]")
+        sm = _dev_f64(pc.sqrt_mass, self.device).reshape(t.shape) if pc.sqrt_mass is not None \
+            else torch.sqrt(torch.reciprocal(t))
+        c = _lib.CMetric(ndim=ndim, per_chain=1, D=D, imm=t.data_ptr(), sqrt_mass=sm.data_ptr())
+        self._keep["metric"] = (pc, t, sm)
+        self._check(self.lib.aehmc_set_metric(self.ctx, ct.byref(c)), "aehmc_set_metric")
+        if self.metric_ndim != ndim:
+            self._ws = None
+        self._metric_key, self.metric_ndim, self.metric_D = None, ndim, D
+
+    def set_step_sizes(self, eps):
+        """eps: PerChain -> per-chain step sizes; anything else -> scalar (returned)."""
+        if isinstance(eps, PerChain):
+            t = _dev_f64(eps.value, self.device).reshape(-1)
+            self._keep["eps"] = t
+            self._check(self.lib.aehmc_set_step_sizes(self.ctx, t.data_ptr()), "aehmc_set_step_sizes")
+            return 0.0
+        self._keep.pop("eps", None)
+        self._check(self.lib.aehmc_set_step_sizes(self.ctx, None), "aehmc_set_step_sizes")
+        return float(eps)
 
     def ensure_workspace(self, C: int, max_exp: int):
         need = self.lib.aehmc_workspace_bytes(self.ctx, C, max_exp)
@@ -237,6 +279,26 @@ class Engine:
                                            B.stride(0), out.data_ptr(), out.stride(0), self.stream),
                     "aehmc_gemm_nt")
         return out
+
+    # ------------------------------------------------------------------ warm-up
+    def adapt_alloc(self, C, D):
+        dev, f64, i64 = self.device, torch.float64, torch.int64
+        st = dict(da_step=torch.empty(C, dtype=i64, device=dev), da_x=torch.empty(C, dtype=f64, device=dev),
+                  da_x_avg=torch.empty(C, dtype=f64, device=dev), da_g_avg=torch.empty(C, dtype=f64, device=dev),
+                  da_mu=torch.empty(C, dtype=f64, device=dev), wc_mean=torch.empty(C, D, dtype=f64, device=dev),
+                  wc_m2=torch.empty(C, D, dtype=f64, device=dev), wc_n=torch.empty(C, dtype=i64, device=dev),
+                  step_size=torch.empty(C, dtype=f64, device=dev), imm=torch.empty(C, D, dtype=f64, device=dev),
+                  sqrt_mass=torch.empty(C, D, dtype=f64, device=dev))
+        return st, _lib.CAdaptState(**{k: v.data_ptr() for k, v in st.items()})
+
+    def adapt_init(self, C, D, initial_step_size, cstate):
+        self._check(self.lib.aehmc_adapt_init(self.ctx, C, D, float(initial_step_size), ct.byref(cstate),
+                                              self.stream), "aehmc_adapt_init")
+
+    def adapt_update(self, C, D, stage, window_end, last, target, p_accept, position, cstate):
+        self._check(self.lib.aehmc_adapt_update(self.ctx, C, D, int(stage), int(window_end), int(last),
+                                                float(target), p_accept.data_ptr(), position.data_ptr(),
+                                                ct.byref(cstate), self.stream), "aehmc_adapt_update")
 
     def profile_enable(self, on=True):
         self._check(self.lib.aehmc_profile_enable(self.ctx, int(on)), "aehmc_profile_enable")

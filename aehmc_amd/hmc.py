@@ -32,7 +32,7 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
         q, U, g = state_rows(state, layout, eng.device)
         eng.set_target(logprob_fn, layout.D)
         eng.set_metric(inverse_mass_matrix, layout.D)
-        out = eng.hmc_step(holder["rng"], float(step_size), int(num_integration_steps),
+        out = eng.hmc_step(holder["rng"], eng.set_step_sizes(step_size), int(num_integration_steps),
                            float(divergence_threshold), q, U, g)
         info = Diagnostics(
             state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
@@ -57,7 +57,7 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
         q, U, g = state_rows(state, layout, eng.device)
         eng.set_target(logprob_fn, layout.D)
         eng.set_metric(inverse_mass_matrix, layout.D)
-        out = eng.hmc_sample(holder["rng"], float(step_size), int(num_integration_steps),
+        out = eng.hmc_sample(holder["rng"], eng.set_step_sizes(step_size), int(num_integration_steps),
                              float(divergence_threshold), int(num_samples), q, U, g, keep_samples)
         info = Diagnostics(
             state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
@@ -74,4 +74,5 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
                 out["divergence_history"].bool().reshape(hist_shape))
 
     step.sample = sample
+    step.num_chains, step.batched = srng.num_chains, srng.batched
     return step

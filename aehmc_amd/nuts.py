@@ -32,7 +32,7 @@ def new_kernel(srng: RandomStream, logprob_fn, max_num_expansions: int = 10,
         q, U, g = state_rows(state, layout, eng.device)
         eng.set_target(logprob_fn, layout.D)
         eng.set_metric(inverse_mass_matrix, layout.D)
-        out = eng.nuts_step(holder["rng"], float(step_size), int(max_num_expansions),
+        out = eng.nuts_step(holder["rng"], eng.set_step_sizes(step_size), int(max_num_expansions),
                             float(divergence_threshold), q, U, g)
         info = Diagnostics(
             state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
@@ -45,4 +45,5 @@ def new_kernel(srng: RandomStream, logprob_fn, max_num_expansions: int = 10,
             n_leapfrog=layout.per_chain(out["n_leapfrog"]))
         return info, {srng: holder["rng"]}
 
+    step.num_chains, step.batched = srng.num_chains, srng.batched
     return step

@@ -1,0 +1,73 @@
+"""Stan-style window adaptation of the step size and the (diagonal) inverse mass matrix,
+one adaptation per chain (reference: aehmc/window_adaptation.py, step_size.py,
+mass_matrix.py, algorithms.py).  The schedule is host logic; the per-chain dual-averaging /
+Welford updates run in one HIP kernel per warm-up step (`aehmc_adapt_update`)."""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+from ._common import Layout
+from .engine import PerChain, get_engine
+from .integrators import IntegratorState
+
+
+def build_schedule(num_steps: int, initial_buffer_size: int = 75, final_buffer_size: int = 50,
+                   first_window_size: int = 25) -> List[Tuple[int, bool]]:
+    """(window_label, is_middle_window_end) per warm-up step (reference:
+    aehmc/window_adaptation.py:230-327): a fast initial buffer, slow windows doubling in
+    size with no memory, a fast final buffer; labels 0 = fast, 1 = slow."""
+    if num_steps < 20:  # too short for mass-matrix adaptation
+        return [(0, False)] * num_steps
+    if initial_buffer_size + first_window_size + final_buffer_size > num_steps:
+        initial_buffer_size = int(0.15 * num_steps)
+        final_buffer_size = int(0.1 * num_steps)
+        first_window_size = num_steps - initial_buffer_size - final_buffer_size
+    slow_end = num_steps - final_buffer_size
+    labels = [(0, False)] * initial_buffer_size
+    start, size = initial_buffer_size, first_window_size
+    while start < slow_end:
+        if 3 * size <= slow_end - start:
+            this, size = size, 2 * size
+        else:
+            this = slow_end - start
+        labels += [(1, False)] * (this - 1) + [(1, True)]
+        start += this
+    return labels + [(0, False)] * (num_steps - slow_end)
+
+
+def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matrix_full=False,
+        initial_step_size=1.0, target_acceptance_rate=0.80
+        ) -> Tuple[IntegratorState, Tuple, Dict]:
+    """Warm a (NUTS) kernel up for ``num_steps`` transitions (reference:
+    aehmc/window_adaptation.py:17-116).  Returns ``(last_chain_state, (step_size,
+    inverse_mass_matrix), updates)`` where the parameters are ``PerChain`` values -- one
+    step size and one diagonal inverse mass matrix per chain, exactly as running the
+    reference once per chain would produce -- to be passed back to ``kernel``."""
+    if is_mass_matrix_full:
+        raise NotImplementedError("per-chain dense mass-matrix adaptation is not supported; "
+                                  "use the diagonal adaptation")
+    eng = get_engine()
+    pos = initial_state.position
+    srng_chains = getattr(kernel, "num_chains", None)
+    batched = getattr(kernel, "batched", pos.ndim == 2)
+    layout = Layout(tuple(pos.shape), batched, srng_chains or (pos.shape[0] if batched else 1))
+    C, D = layout.C, layout.D
+    scalar_position = (len(layout.user_shape) - (1 if batched else 0)) == 0
+    st, cst = eng.adapt_alloc(C, D)
+    eng.adapt_init(C, D, float(initial_step_size), cst)
+    schedule = build_schedule(int(num_steps))
+
+    def imm_param():
+        return PerChain(st["imm"].reshape(C) if scalar_position else st["imm"], st["sqrt_mass"])
+
+    state, updates = initial_state, {}
+    for i, (stage, window_end) in enumerate(schedule):
+        info, updates = kernel(state, PerChain(st["step_size"]), imm_param())
+        state = info.state._replace(momentum=None)
+        eng.adapt_update(C, D, stage, window_end, i == len(schedule) - 1, float(target_acceptance_rate),
+                         info.acceptance_probability.reshape(C).contiguous(),
+                         state.position.reshape(C, D).contiguous(), cst)
+    step_size = st["step_size"].clone()
+    imm = st["imm"].clone()
+    return state, (PerChain(layout.per_chain(step_size)),
+                   PerChain(imm.reshape(C) if scalar_position else imm)), updates

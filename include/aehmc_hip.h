@@ -65,11 +65,24 @@ typedef struct {
  * L^-T with imm = L L^T (metrics.py:56-58).  Dense imm must be symmetric. */
 typedef struct {
   int32_t ndim;
-  int32_t reserved;
+  int32_t per_chain;       /* 1: imm / sqrt_mass are [C,1] (ndim 0) or [C,D] (ndim 1), one row per
+                              chain -- what per-chain window adaptation produces; 0: shared */
   int64_t D;
   const double *imm;       /* [1] | [D] | [D,D] */
   const double *sqrt_mass; /* [1] | [D] | [D,D] */
 } aehmc_metric;
+
+/* warm-up state of window_adaptation.run (window_adaptation.py:17-116), one row per chain:
+ * DualAveragingState (algorithms.py:9-14), Welford state (algorithms.py:141-165) and the
+ * current parameters (step_size, inverse_mass_matrix [+ its sqrt-mass]) */
+typedef struct {
+  int64_t *da_step;                      /* [C] */
+  double *da_x, *da_x_avg, *da_g_avg, *da_mu; /* [C] */
+  double *wc_mean, *wc_m2;               /* [C,D] (diagonal adaptation) */
+  int64_t *wc_n;                         /* [C] */
+  double *step_size;                     /* [C] */
+  double *imm, *sqrt_mass;               /* [C,D] */
+} aehmc_adapt_state;
 
 /* per-transition outputs == trajectory.py:379-384 Diagnostics (+ n_leapfrog) */
 typedef struct {
@@ -128,6 +141,21 @@ int aehmc_hmc_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
 int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
                     int64_t max_num_expansions, double divergence_threshold, double *q,
                     double *U, double *g, const aehmc_diagnostics *out, void *stream);
+
+/* per-chain step sizes [C] overriding the scalar step_size argument of the step calls
+ * (NULL restores the scalar) -- window adaptation adapts one step size per chain */
+int aehmc_set_step_sizes(aehmc_ctx *ctx, const double *step_sizes);
+
+/* window_adaptation.window_adaptation(...).init / .update (window_adaptation.py:119-227,
+ * step_size.py:9-100, mass_matrix.py:12-120, algorithms.py:17-204), diagonal mass matrix,
+ * one adaptation per chain.  `stage` / `is_window_end` come from build_schedule
+ * (window_adaptation.py:230-327, host side); `is_last` = last warm-up step. */
+int aehmc_adapt_init(aehmc_ctx *ctx, int64_t C, int64_t D, double initial_step_size,
+                     const aehmc_adapt_state *state, void *stream);
+int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t stage, int32_t is_window_end,
+                       int32_t is_last, double target_acceptance_rate,
+                       const double *acceptance_probability, const double *position,
+                       const aehmc_adapt_state *state, void *stream);
 
 /* ---- building blocks exported for known-answer tests / callers that want them ---- */
 

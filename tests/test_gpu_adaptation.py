@@ -1,0 +1,111 @@
+"""Window adaptation on the GPU (per chain) against the numpy restatement driven by the C
+oracle's NUTS kernel on the same seeds; plus the reference's statistical check
+(tests/test_hmc.py:13-97)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle as co  # noqa: E402
+from oracle import np_adaptation as na  # noqa: E402
+from oracle import np_oracle as no  # noqa: E402
+
+
+class OracleNuts:
+    """kernel(state, step_size, imm) for one chain, backed by oracle/c (scheme-A RNG)."""
+
+    def __init__(self, otgt, seed, D):
+        self.otgt, self.D = otgt, D
+        self.rng = co.site_states([seed], 4)
+
+    def __call__(self, state, eps, imm):
+        q = np.atleast_1d(np.array(state.position, dtype=np.float64)).reshape(1, self.D).copy()
+        U = np.array([state.potential_energy], dtype=np.float64)
+        g = np.atleast_1d(np.array(state.potential_energy_grad, dtype=np.float64)).reshape(1, self.D).copy()
+        metric = co.Metric(imm, self.D)
+        res = co.nuts_step(self.otgt, metric, self.rng, float(eps), q, U, g)
+        scalar = np.ndim(state.position) == 0
+        st = no.IntegratorState(np.float64(q[0, 0]) if scalar else q[0].copy(), None, float(U[0]),
+                                np.float64(g[0, 0]) if scalar else g[0].copy())
+        return SimpleNamespace(state=st, acceptance_probability=float(res["acceptance_probability"][0]))
+
+
+def test_adapt_update_kernel_matches_oracle():
+    """The per-chain dual-averaging / Welford / window-end update in isolation: identical
+    (acceptance probability, position) sequences in, identical warm-up state out."""
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    C, D, num_steps = 5, 7, 200
+    r = np.random.default_rng(11)
+    st, cst = eng.adapt_alloc(C, D)
+    eng.adapt_init(C, D, 0.37, cst)
+    init, update = na.window_adaptation(num_steps, initial_step_size=0.37)
+    ref = [init(np.zeros(D)) for _ in range(C)]
+    schedule = na.build_schedule(num_steps)
+    assert st["step_size"].cpu().numpy().tolist() == [1.0] * C
+    for i, (stage, wend) in enumerate(schedule):
+        pa = r.random(C)
+        pos = r.normal(size=(C, D)) * (1 + np.arange(D))
+        eng.adapt_update(C, D, stage, wend, i == num_steps - 1, 0.8, torch.as_tensor(pa, device="cuda"),
+                         torch.as_tensor(pos, device="cuda"), cst)
+        ref = [update(i, ws, pr, pos[c], pa[c]) for c, (ws, pr) in enumerate(ref)]
+        if wend or i % 37 == 0 or i == num_steps - 1:
+            for c, ((da, mm), (eps, imm)) in enumerate(ref):
+                assert st["step_size"][c].item() == pytest.approx(eps, rel=1e-12)
+                np.testing.assert_allclose(st["imm"][c].cpu().numpy(), imm, rtol=1e-12)
+                assert st["da_step"][c].item() == da.step and st["wc_n"][c].item() == mm[2]
+                assert st["da_x_avg"][c].item() == pytest.approx(da.iterates_avg, rel=1e-12, abs=1e-15)
+                assert st["da_mu"][c].item() == pytest.approx(da.shrinkage_pts, rel=1e-12)
+                np.testing.assert_allclose(st["wc_m2"][c].cpu().numpy(), mm[1], rtol=1e-12, atol=1e-13)
+                np.testing.assert_allclose(st["sqrt_mass"][c].cpu().numpy(), np.sqrt(1 / imm), rtol=1e-12)
+
+
+@pytest.mark.parametrize("scalar", [True, False])
+def test_window_adaptation_matches_oracle(scalar):
+    """End to end on identical seeds.  The warm-up loop feeds the step size back into the
+    trajectory, which amplifies last-bit differences by ~1.2x per step, so the horizon is
+    kept at 60 steps (fast buffer, one slow window with its mass-matrix update, fast buffer)."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    C, D, num_steps = 4, (1 if scalar else 3), 60
+    r = np.random.default_rng(5)
+    mu, sigma = (np.array([1.0]), np.array([2.0])) if scalar else (r.normal(size=D), 0.5 + 2 * r.random(D))
+    tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
+    seeds = [300 + c for c in range(C)]
+    q0 = r.normal(size=(C,) if scalar else (C, D))
+    kernel = nuts.new_kernel(RandomStream(seeds=seeds), tgt)
+    state = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt, num_chains=C)
+    last, (eps, imm), _ = window_adaptation.run(kernel, state, num_steps, initial_step_size=1.0)
+    eps_g, imm_g = eps.value.cpu().numpy(), imm.value.cpu().numpy()
+    pos_g = last.position.cpu().numpy()
+    for c in range(C):
+        ok = OracleNuts(otgt, seeds[c], D)
+        qc = np.float64(q0[c]) if scalar else q0[c]
+        Uo, go = no.DiagGaussian(mu, sigma)(qc)
+        st = no.IntegratorState(qc, None, Uo, go)
+        st, (eps_o, imm_o) = na.run(ok, st, num_steps, initial_step_size=1.0)
+        assert eps_g[c] == pytest.approx(eps_o, rel=1e-6)
+        np.testing.assert_allclose(imm_g[c], imm_o, rtol=1e-6)
+        np.testing.assert_allclose(pos_g[c], st.position, rtol=1e-6, atol=1e-9)
+
+
+def test_window_adaptation_statistics():
+    """tests/test_hmc.py:13-97: N(1, 2^2), 1000 warm-up steps with NUTS: step size in (0.1, 2),
+    inverse mass matrix ~ 4 (the reference asserts rel 1.0 on one chain; 64 chains here)."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    C = 64
+    tgt = targets.DiagGaussian(np.array([1.0]), np.array([2.0]))
+    kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+    state = nuts.new_state(torch.ones(C, dtype=torch.float64, device="cuda"), tgt, num_chains=C)
+    last, (eps, imm), _ = window_adaptation.run(kernel, state, 1000)
+    e, m = eps.value.cpu().numpy(), imm.value.cpu().numpy()
+    assert ((e > 0.1) & (e < 2)).all()
+    assert np.all(np.abs(m - 4.0) / 4.0 < 1.0)
+    # NB: the reference's NUTS is not exactly invariant (2**j+1 leapfrogs per expansion, stale
+    # checkpoint indices): its literal restatement has stationary variance 4.6 for this
+    # target at eps=1, imm=1 (oracle/c, 256 chains x 500 draws) -- parity, not exactness, is
+    # the contract, so only the reference's own loose assertions are checked here.
+    info, _ = kernel(last, eps, imm)
+    assert torch.isfinite(info.state.position).all()
