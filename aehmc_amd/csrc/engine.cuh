@@ -212,6 +212,22 @@ __device__ __forceinline__ bool leap_linear(const EngineArgs &a, long long c, in
   return false;
 }
 
+// The chain's RNG call sites, kept in registers for the duration of a kernel (every lane
+// holds the same state); lane 0 writes them back.
+struct ChainRng {
+  Pcg64 g[4];
+};
+__device__ __forceinline__ ChainRng rng_load(const EngineArgs &a, long long c) {
+  ChainRng r;
+  for (int k = 0; k < a.nsites && k < 4; k++) r.g[k] = pcg_load(a.rng + ((size_t)c * a.nsites + k) * 4);
+  return r;
+}
+__device__ __forceinline__ void rng_store(const EngineArgs &a, long long c, int lane, const ChainRng &r,
+                                          int first, int last) {
+  if (lane == 0)
+    for (int k = first; k <= last && k < a.nsites; k++) pcg_store(a.rng + ((size_t)c * a.nsites + k) * 4, r.g[k]);
+}
+
 // ---------------------------------------------------------------------------------
 // NUTS bookkeeping after one leapfrog of the chain's moving end (cur_*).
 // ---------------------------------------------------------------------------------
@@ -227,10 +243,8 @@ __device__ __forceinline__ void copy_cur_to_slot(const EngineArgs &a, size_t row
 
 template <bool MET_DENSE>
 __device__ inline void nuts_begin_expansion(const EngineArgs &a, long long c, int lane,
-                                            ChainCtl &ct, int prev_dir) {
-  Pcg64 g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
-  int go_right = rng_bernoulli(g2, 0.5);  // trajectory.py:516
-  if (lane == 0) pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
+                                            ChainCtl &ct, int prev_dir, ChainRng &rng) {
+  int go_right = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
   ct.dir = go_right;
   ct.step = 0;
   if (prev_dir >= 0 && prev_dir != go_right) {  // cur <- the other end (trajectory.py:518)
@@ -268,7 +282,8 @@ __device__ inline void nuts_write_outputs(const EngineArgs &a, long long c, int 
 // expand_once after integrate() returned: trajectory.py:537-608
 template <bool MET_DENSE>
 __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c, int lane,
-                                               ChainCtl &ct, bool is_div, bool has_term) {
+                                               ChainCtl &ct, bool is_div, bool has_term,
+                                               ChainRng &rng) {
   const size_t row = (size_t)c * a.D;
   const int dir = ct.dir, oth = 1 - dir;
   // one pass: moving end <- cur, psum += psub, whole-trajectory U-turn dots (metrics.py:75-104)
@@ -299,9 +314,7 @@ __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c,
   double pb = exp(ct.sub_w - ct.prop_w);               // proposals.py:130 (always drawn)
   if (pb > 1.0) pb = 1.0;
   if (pb < 0.0) pb = 0.0;
-  Pcg64 g4 = pcg_load(a.rng + ((size_t)c * a.nsites + 3) * 4);
-  int acc_b = rng_bernoulli(g4, pb);
-  if (lane == 0) pcg_store(a.rng + ((size_t)c * a.nsites + 3) * 4, g4);
+  int acc_b = rng_bernoulli(rng.g[3], pb);
   if (is_div || has_term) {
     ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);  // trajectory.py:560-564
   } else {
@@ -321,13 +334,14 @@ __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c,
     ct.done = 1;  // caller keeps the chain alive while a phantom scan is pending
   } else {
     ct.j += 1;
-    nuts_begin_expansion<MET_DENSE>(a, c, lane, ct, dir);
+    nuts_begin_expansion<MET_DENSE>(a, c, lane, ct, dir, rng);
   }
 }
 
 // dynamic_integration.integrate body, one step: trajectory.py:195-305
 template <bool MET_DENSE>
-__device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, ChainCtl ct) {
+__device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, ChainCtl &ct,
+                                 ChainRng &rng) {
   const size_t row = (size_t)c * a.D;
   const int step = ct.step;
   if (!ct.phantom) ct.nleap += 1;
@@ -378,9 +392,7 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
     // progressive_uniform_sampling proposals.py:72-102
     double pa = 1.0 / (1.0 + exp(-(np_w - ct.sub_w)));
     if (isnan(pa)) pa = 0.0;
-    Pcg64 g3 = pcg_load(a.rng + ((size_t)c * a.nsites + 2) * 4);
-    int acc = rng_bernoulli(g3, pa);
-    if (lane == 0) pcg_store(a.rng + ((size_t)c * a.nsites + 2) * 4, g3);
+    int acc = rng_bernoulli(rng.g[2], pa);
     ct.sub_w = np_logaddexp(ct.sub_w, np_w);
     ct.sub_slpa = np_logaddexp(ct.sub_slpa, np_slpa);
     if (acc) {
@@ -422,22 +434,22 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
   if (step == 0 && div && !ct.phantom) {
     // trajectory.py:336: integrate() returns the first-step tuple, yet the scan still
     // executes (and draws from site #3): finalize now, keep stepping as a phantom.
-    nuts_finalize_expansion<MET_DENSE>(a, c, lane, ct, true, false);
+    nuts_finalize_expansion<MET_DENSE>(a, c, lane, ct, true, false, rng);
     ct.done = 0;
     ct.phantom = 1;
     ct.step = 1;
   } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
     if (ct.phantom) ct.done = 1;
-    else nuts_finalize_expansion<MET_DENSE>(a, c, lane, ct, div, term);
+    else nuts_finalize_expansion<MET_DENSE>(a, c, lane, ct, div, term, rng);
   } else {
     ct.step = step + 1;
   }
-  if (lane == 0) a.ctl[c] = ct;
 }
 
 // nuts.py:113-125 after the momentum is in cur_p (and cur_v for a dense metric)
 template <bool MET_DENSE>
-__device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lane) {
+__device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lane, ChainCtl &ct,
+                                       ChainRng &rng) {
   const size_t row = (size_t)c * a.D;
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
@@ -460,7 +472,6 @@ __device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lan
     a.psum[row + i] = p;
   }
   kd = wave_sum(kd);
-  ChainCtl ct;
   const double U = a.U[c];
   ct.H0 = U + 0.5 * kd;
   ct.prop_E = ct.H0;
@@ -476,23 +487,20 @@ __device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lan
   ct.done = ct.phantom = 0;
   ct.prop_slot = 0;
   ct.ndoubl = ct.out_div = ct.out_turn = ct.hmc_accept = 0;
-  nuts_begin_expansion<MET_DENSE>(a, c, lane, ct, -1);
-  if (lane == 0) a.ctl[c] = ct;
+  nuts_begin_expansion<MET_DENSE>(a, c, lane, ct, -1, rng);
 }
 
 // metrics.py:65-68: z ~ N(0, I) from site #1; diagonal metric scales in place,
 // dense metric stages z for the GEMM with L^-T.
 template <bool MET_DENSE>
-__device__ inline void draw_momentum(const EngineArgs &a, long long c, int lane) {
+__device__ inline void draw_momentum(const EngineArgs &a, long long c, int lane, Pcg64 &g1) {
   const size_t row = (size_t)c * a.D;
-  Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4);
   double *dst = MET_DENSE ? a.zbuf : a.cur_p;
   const double *sm = a.sqrt_mass + c * a.imm_cs;
   const bool scalar = a.met_ndim == 0;
   wave_normals(g1, a.D, [=](long long i, double z) {
     dst[row + i] = MET_DENSE ? z : (scalar ? sm[0] : sm[i]) * z;
   });
-  if (lane == 0) pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
   __threadfence_block();  // elements were written by arbitrary lanes of this wave
 }
 
@@ -505,17 +513,44 @@ __device__ inline void draw_momentum(const EngineArgs &a, long long c, int lane)
 template <bool MET_DENSE>
 __global__ __launch_bounds__(256) void k_nuts_draw(EngineArgs a) {
   AEHMC_CHAIN_OF_WAVE();
-  draw_momentum<MET_DENSE>(a, c, lane);
+  ChainRng rng = rng_load(a, c);
+  draw_momentum<MET_DENSE>(a, c, lane, rng.g[0]);
+  rng_store(a, c, lane, rng, 0, 0);
 }
 template <bool MET_DENSE>
 __global__ __launch_bounds__(256) void k_nuts_init(EngineArgs a) {
   AEHMC_CHAIN_OF_WAVE();
-  nuts_init_chain<MET_DENSE>(a, c, lane);
+  ChainRng rng = rng_load(a, c);
+  ChainCtl ct;
+  nuts_init_chain<MET_DENSE>(a, c, lane, ct, rng);
+  rng_store(a, c, lane, rng, 1, 1);
+  if (lane == 0) a.ctl[c] = ct;
 }
 __global__ __launch_bounds__(256) void k_nuts_begin_diag(EngineArgs a) {
   AEHMC_CHAIN_OF_WAVE();
-  draw_momentum<false>(a, c, lane);
-  nuts_init_chain<false>(a, c, lane);
+  ChainRng rng = rng_load(a, c);
+  ChainCtl ct;
+  draw_momentum<false>(a, c, lane, rng.g[0]);
+  nuts_init_chain<false>(a, c, lane, ct, rng);
+  rng_store(a, c, lane, rng, 0, 1);
+  if (lane == 0) a.ctl[c] = ct;
+}
+// Whole NUTS transition of a chain in ONE launch (diagonal / scalar metric, coordinate-wise
+// target): the wave that owns the chain loops leapfrog + bookkeeping until its tree is
+// done; chains of different depth simply retire at different times.  Same device
+// functions, hence same bits, as the lock-step path.
+__global__ __launch_bounds__(256) void k_nuts_fused(EngineArgs a) {
+  AEHMC_CHAIN_OF_WAVE();
+  ChainRng rng = rng_load(a, c);
+  ChainCtl ct;
+  draw_momentum<false>(a, c, lane, rng.g[0]);
+  nuts_init_chain<false>(a, c, lane, ct, rng);
+  while (!ct.done) {
+    double U_new = 0.0;
+    if (leap_stages<true, true, true, false>(a, c, lane, ct.dir, U_new)) ct.U_cur = U_new;
+    nuts_book<false>(a, c, lane, ct, rng);
+  }
+  rng_store(a, c, lane, rng, 0, 3);
 }
 // MODE: stage set; BOOK: run the NUTS bookkeeping afterwards
 template <bool DO1, bool DO2, bool DO3, bool MET_DENSE, bool BOOK>
@@ -528,7 +563,10 @@ __global__ __launch_bounds__(256) void k_step(EngineArgs a) {
   if (DO1 || DO2 || DO3) has_U = leap_stages<DO1, DO2, DO3, MET_DENSE>(a, c, lane, ct.dir, U_new);
   if (BOOK) {
     if (has_U) ct.U_cur = U_new;
-    nuts_book<MET_DENSE>(a, c, lane, ct);
+    ChainRng rng = rng_load(a, c);
+    nuts_book<MET_DENSE>(a, c, lane, ct, rng);
+    rng_store(a, c, lane, rng, 1, 3);
+    if (lane == 0) a.ctl[c] = ct;
   } else if (has_U && lane == 0) {
     a.ctl[c].U_cur = U_new;
   }
@@ -543,7 +581,10 @@ __global__ __launch_bounds__(256) void k_step_linear(EngineArgs a) {
   bool has_U = leap_linear<PHASE>(a, c, lane, ct.dir, U_new);
   if (BOOK) {
     if (has_U) ct.U_cur = U_new;
-    nuts_book<true>(a, c, lane, ct);
+    ChainRng rng = rng_load(a, c);
+    nuts_book<true>(a, c, lane, ct, rng);
+    rng_store(a, c, lane, rng, 1, 3);
+    if (lane == 0) a.ctl[c] = ct;
   } else if (has_U && lane == 0) {
     a.ctl[c].U_cur = U_new;
   }
@@ -613,7 +654,9 @@ __global__ __launch_bounds__(256) void k_hmc_init(EngineArgs a) {
 }
 __global__ __launch_bounds__(256) void k_hmc_begin_diag(EngineArgs a) {
   AEHMC_CHAIN_OF_WAVE();
-  draw_momentum<false>(a, c, lane);
+  ChainRng rng = rng_load(a, c);
+  draw_momentum<false>(a, c, lane, rng.g[0]);
+  rng_store(a, c, lane, rng, 0, 0);
   hmc_init_chain<false>(a, c, lane);
 }
 template <bool MET_DENSE>

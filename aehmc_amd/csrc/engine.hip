@@ -36,6 +36,7 @@ struct aehmc_ctx {
   int *d_active = nullptr;
   hipEvent_t ev[NRING] = {};
   bool opt_fused_hmc = true;
+  bool opt_fused_nuts = true;    // whole NUTS transition in one launch (diag metric, coordinate-wise target)
   bool opt_dense_linear = true;  // one metric GEMM per leapfrog (v carried by linearity)
   bool opt_compact = true;       // finished chains drop out of the GEMMs
   // profiling of the dominant (GEMM / fused) kernel with HIP events on the launch stream
@@ -199,6 +200,10 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
   if (!ctx || !name) return -2;
   if (!strcmp(name, "fused_hmc")) {
     ctx->opt_fused_hmc = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "fused_nuts")) {
+    ctx->opt_fused_nuts = value != 0;
     return 0;
   }
   if (!strcmp(name, "dense_linear")) {
@@ -470,6 +475,16 @@ extern "C" int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double 
   a.eps = step_size; a.thr = divergence_threshold;
   a.rng = rng; a.nsites = 4;
   a.q = q; a.U = U; a.g = g; a.out = *out;
+  if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
+    const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
+    if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+    LAUNCH(k_nuts_fused, C, st, a);
+    if (p) {
+      HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
+      ctx->prof_used += 2;
+    }
+    return 0;
+  }
   if (int rc = launch_begin(ctx, a, true, st)) return rc;
   long long maxsteps = 0;
   for (int j = 0; j < max_num_expansions; j++) maxsteps += (1LL << j) + 1;  // 2**j + 1 per expansion

@@ -277,6 +277,32 @@ def test_hmc_fused_equals_lockstep_bitwise(eng):
         assert np.array_equal(a, b)
 
 
+def test_nuts_fused_equals_lockstep_bitwise(eng):
+    """The single-launch NUTS kernel (one wavefront loops a chain's whole tree) and the
+    one-launch-per-leapfrog lock-step path share their device functions: same bits."""
+    from aehmc_amd import RandomStream, nuts, targets
+    r = np.random.default_rng(1)
+    D, C = 130, 40
+    q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
+    mu, sigma = r.normal(size=D), 0.5 + r.random(D)
+    outs = []
+    for fused in (1, 0):
+        eng.set_option("fused_nuts", fused)
+        tgt = targets.DiagGaussian(mu, sigma)
+        srng = RandomStream(seeds=list(range(C)))
+        kernel = nuts.new_kernel(srng, tgt, max_num_expansions=7)
+        state = nuts.new_state(dev(q0), tgt)
+        for _ in range(3):
+            info, upd = kernel(state, 0.2, imm)
+            state = info.state._replace(momentum=None)
+        outs.append((info.state.position.cpu().numpy(), info.state.momentum.cpu().numpy(),
+                     info.acceptance_probability.cpu().numpy(), info.n_leapfrog.cpu().numpy(),
+                     info.num_doublings.cpu().numpy(), upd[srng].cpu().numpy()))
+    eng.set_option("fused_nuts", 1)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("fused", [1, 0])
 def test_hmc_sample_equals_repeated_steps(eng, fused):
     """kernel.sample(N) (one launch on the fused path) == N calls of kernel(...)"""
