@@ -77,6 +77,17 @@ struct EngineArgs {
   aehmc_diagnostics out;
 };
 
+// two-entry arrays are picked with a select, never indexed dynamically (a dynamic index
+// into the kernel-argument struct or ChainCtl sends them to scratch memory)
+template <class T>
+__device__ __forceinline__ T pick2(T const (&arr)[2], int i) {
+  return i ? arr[1] : arr[0];
+}
+__device__ __forceinline__ void put2(double (&arr)[2], int i, double v) {
+  if (i) arr[1] = v;
+  else arr[0] = v;
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
@@ -219,13 +230,21 @@ struct ChainRng {
 };
 __device__ __forceinline__ ChainRng rng_load(const EngineArgs &a, long long c) {
   ChainRng r;
-  for (int k = 0; k < a.nsites && k < 4; k++) r.g[k] = pcg_load(a.rng + ((size_t)c * a.nsites + k) * 4);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {  // static indices only (a dynamic one sends g[] to scratch)
+    r.g[k].state = 0;
+    r.g[k].inc = 0;
+    if (k < a.nsites) r.g[k] = pcg_load(a.rng + ((size_t)c * a.nsites + k) * 4);
+  }
   return r;
 }
 __device__ __forceinline__ void rng_store(const EngineArgs &a, long long c, int lane, const ChainRng &r,
                                           int first, int last) {
-  if (lane == 0)
-    for (int k = first; k <= last && k < a.nsites; k++) pcg_store(a.rng + ((size_t)c * a.nsites + k) * 4, r.g[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k >= first && k <= last && k < a.nsites) pcg_store(a.rng + ((size_t)c * a.nsites + k) * 4, r.g[k]);
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -235,9 +254,9 @@ template <bool MET_DENSE>
 __device__ __forceinline__ void copy_cur_to_slot(const EngineArgs &a, size_t row, int lane,
                                                  int slot) {
   for (long long i = lane; i < a.D; i += 64) {
-    a.slot_q[slot][row + i] = a.cur_q[row + i];
-    a.slot_p[slot][row + i] = a.cur_p[row + i];
-    a.slot_g[slot][row + i] = a.cur_g[row + i];
+    pick2(a.slot_q, slot)[row + i] = a.cur_q[row + i];
+    pick2(a.slot_p, slot)[row + i] = a.cur_p[row + i];
+    pick2(a.slot_g, slot)[row + i] = a.cur_g[row + i];
   }
 }
 
@@ -250,13 +269,13 @@ __device__ inline void nuts_begin_expansion(const EngineArgs &a, long long c, in
   if (prev_dir >= 0 && prev_dir != go_right) {  // cur <- the other end (trajectory.py:518)
     const size_t row = (size_t)c * a.D;
     for (long long i = lane; i < a.D; i += 64) {
-      a.cur_q[row + i] = a.end_q[go_right][row + i];
-      a.cur_p[row + i] = a.end_p[go_right][row + i];
-      a.cur_g[row + i] = a.end_g[go_right][row + i];
-      if (MET_DENSE) a.cur_v[row + i] = a.end_v[go_right][row + i];
-      if (MET_DENSE && a.linear) a.cur_w[row + i] = a.end_w[go_right][row + i];
+      a.cur_q[row + i] = pick2(a.end_q, go_right)[row + i];
+      a.cur_p[row + i] = pick2(a.end_p, go_right)[row + i];
+      a.cur_g[row + i] = pick2(a.end_g, go_right)[row + i];
+      if (MET_DENSE) a.cur_v[row + i] = pick2(a.end_v, go_right)[row + i];
+      if (MET_DENSE && a.linear) a.cur_w[row + i] = pick2(a.end_w, go_right)[row + i];
     }
-    ct.U_cur = ct.U_end[go_right];
+    ct.U_cur = pick2(ct.U_end, go_right);
   }
 }
 
@@ -265,12 +284,12 @@ __device__ inline void nuts_write_outputs(const EngineArgs &a, long long c, int 
   const size_t row = (size_t)c * a.D;
   const int s = ct.prop_slot;
   for (long long i = lane; i < a.D; i += 64) {
-    a.q[row + i] = a.slot_q[s][row + i];
-    a.g[row + i] = a.slot_g[s][row + i];
-    if (a.out.momentum) a.out.momentum[row + i] = a.slot_p[s][row + i];
+    a.q[row + i] = pick2(a.slot_q, s)[row + i];
+    a.g[row + i] = pick2(a.slot_g, s)[row + i];
+    if (a.out.momentum) a.out.momentum[row + i] = pick2(a.slot_p, s)[row + i];
   }
   if (lane == 0) {
-    a.U[c] = ct.U_slot[s];
+    a.U[c] = pick2(ct.U_slot, s);
     a.out.acceptance_probability[c] = ct.acc_prob;
     if (a.out.num_doublings) a.out.num_doublings[c] = ct.ndoubl;
     if (a.out.is_turning) a.out.is_turning[c] = ct.out_turn;
@@ -289,9 +308,9 @@ __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c,
   // one pass: moving end <- cur, psum += psub, whole-trajectory U-turn dots (metrics.py:75-104)
   double d_l = 0.0, d_r = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
-    double pc = a.cur_p[row + i], po = a.end_p[oth][row + i];
+    double pc = a.cur_p[row + i], po = pick2(a.end_p, oth)[row + i];
     double vc = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, c, i, pc);
-    double vo = MET_DENSE ? a.end_v[oth][row + i] : vel_diag(a, c, i, po);
+    double vo = MET_DENSE ? pick2(a.end_v, oth)[row + i] : vel_diag(a, c, i, po);
     double s = a.psum[row + i] + a.psub[row + i];
     a.psum[row + i] = s;
     double pl = dir ? po : pc, pr = dir ? pc : po;
@@ -299,16 +318,16 @@ __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c,
     double rho = s - (pr + pl) / 2;
     d_l += vl * rho;
     d_r += vr * rho;
-    a.end_q[dir][row + i] = a.cur_q[row + i];
-    a.end_p[dir][row + i] = pc;
-    a.end_g[dir][row + i] = a.cur_g[row + i];
-    if (MET_DENSE) a.end_v[dir][row + i] = vc;
-    if (MET_DENSE && a.linear) a.end_w[dir][row + i] = a.cur_w[row + i];
+    pick2(a.end_q, dir)[row + i] = a.cur_q[row + i];
+    pick2(a.end_p, dir)[row + i] = pc;
+    pick2(a.end_g, dir)[row + i] = a.cur_g[row + i];
+    if (MET_DENSE) pick2(a.end_v, dir)[row + i] = vc;
+    if (MET_DENSE && a.linear) pick2(a.end_w, dir)[row + i] = a.cur_w[row + i];
   }
   d_l = wave_sum(d_l);
   d_r = wave_sum(d_r);
   const bool turning = (d_l <= 0) | (d_r <= 0);
-  ct.U_end[dir] = ct.U_cur;
+  put2(ct.U_end, dir, ct.U_cur);
 
   ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;  // trajectory.py:551-553
   double pb = exp(ct.sub_w - ct.prop_w);               // proposals.py:130 (always drawn)
@@ -387,7 +406,7 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
     ct.sub_slpa = np_slpa;
     ct.length = 1;
     copy_cur_to_slot<MET_DENSE>(a, row, lane, ct.prop_slot ^ 1);
-    ct.U_slot[ct.prop_slot ^ 1] = ct.U_cur;
+    put2(ct.U_slot, ct.prop_slot ^ 1, ct.U_cur);
   } else {
     // progressive_uniform_sampling proposals.py:72-102
     double pa = 1.0 / (1.0 + exp(-(np_w - ct.sub_w)));
@@ -399,7 +418,7 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
       ct.sub_E = E;
       if (!ct.phantom) {
         copy_cur_to_slot<MET_DENSE>(a, row, lane, ct.prop_slot ^ 1);
-        ct.U_slot[ct.prop_slot ^ 1] = ct.U_cur;
+        put2(ct.U_slot, ct.prop_slot ^ 1, ct.U_cur);
       }
     }
     ct.length += 1;

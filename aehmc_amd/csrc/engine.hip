@@ -36,7 +36,7 @@ struct aehmc_ctx {
   int *d_active = nullptr;
   hipEvent_t ev[NRING] = {};
   bool opt_fused_hmc = true;
-  bool opt_fused_nuts = true;    // whole NUTS transition in one launch (diag metric, coordinate-wise target)
+  bool opt_fused_nuts = false;   // whole NUTS transition in one launch (diag metric, coordinate-wise target)
   bool opt_dense_linear = true;  // one metric GEMM per leapfrog (v carried by linearity)
   bool opt_compact = true;       // finished chains drop out of the GEMMs
   // profiling of the dominant (GEMM / fused) kernel with HIP events on the launch stream

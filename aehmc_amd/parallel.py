@@ -37,9 +37,13 @@ def chain_seeds(base_seed: int, num_chains: int, r: int = None, w: int = None):
     return [base_seed + c for c in range(lo, hi)]
 
 
+def _cpu_backend() -> bool:
+    return dist.get_backend() == "gloo"
+
+
 def barrier(device=None):
     if _on():
-        if device is not None and torch.device(device).type == "cuda":
+        if device is not None and torch.device(device).type == "cuda" and not _cpu_backend():
             dist.barrier(device_ids=[torch.device(device).index])
         else:
             dist.barrier()
@@ -51,6 +55,8 @@ def gather_samples(x: torch.Tensor) -> torch.Tensor:
         return x
     w = dist.get_world_size()
     x = x.contiguous()
+    if _cpu_backend() and x.is_cuda:  # gloo dry runs: stage through the host
+        return gather_samples(x.cpu()).to(x.device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(w)]
     dist.all_gather(sizes, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
     sizes = [int(s.item()) for s in sizes]
@@ -69,7 +75,8 @@ def gather_samples(x: torch.Tensor) -> torch.Tensor:
 def max_over_ranks(v: float, device=None) -> float:
     if not _on():
         return v
-    t = torch.tensor([v], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([v], dtype=torch.float64,
+                     device="cpu" if (device is None or _cpu_backend()) else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -77,6 +84,7 @@ def max_over_ranks(v: float, device=None) -> float:
 def sum_over_ranks(v: int, device=None) -> int:
     if not _on():
         return v
-    t = torch.tensor([v], dtype=torch.int64, device=device if device is not None else "cpu")
+    t = torch.tensor([v], dtype=torch.int64,
+                     device="cpu" if (device is None or _cpu_backend()) else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())

@@ -64,10 +64,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # dry-run knobs for a 1-GPU box: AEHMC_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and
+    # AEHMC_DIST_BACKEND=gloo swaps RCCL for gloo (the driver's multi-GPU runs use neither)
+    if os.environ.get("AEHMC_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("AEHMC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
 

@@ -105,9 +105,11 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
 /* engine options (name, default):
  *  "fused_hmc" 1    register-resident single-launch HMC when the metric is diagonal and the
  *                   target coordinate-wise; 0 forces the lock-step path
- *  "fused_nuts" 1   whole NUTS transition in one launch (one wavefront per chain loops
- *                   leapfrog + tree bookkeeping) when the metric is diagonal and the target
- *                   coordinate-wise; 0 forces the lock-step path (one launch per leapfrog)
+ *  "fused_nuts" 0   1: whole NUTS transition in one launch (one wavefront per chain loops
+ *                   leapfrog + tree bookkeeping over its HBM-resident state) when the metric is
+ *                   diagonal and the target coordinate-wise -- lowest latency for a few
+ *                   chains; the lock-step path (one launch per leapfrog) has the higher
+ *                   throughput for thousands of chains and is the default
  *  "dense_linear" 1 dense metric: carry w = imm g with the state so that
  *                   v_half = v - (eps/2) w, v' = v_half - (eps/2) w' (one metric GEMM per
  *                   leapfrog); 0 forms imm p_half and imm p' directly as metrics.py:71 does

@@ -1,0 +1,67 @@
+"""Committed fixtures (tests/golden/vectors_v1.json): the oracle must keep reproducing them
+(CPU), and the HIP path must reproduce them without any oracle at run time (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = json.load(open(os.path.join(HERE, "golden", "vectors_v1.json")))
+
+
+def _oracle_run(case):
+    from oracle import c_oracle as co
+    D, C = case["D"], case["C"]
+    kind = {"std_normal": co.T_STD_NORMAL, "iso": co.T_ISO_GAUSSIAN, "diag": co.T_DIAG_GAUSSIAN}[case["target_kind"]]
+    otgt = co.Target(kind, D, mu=np.array(case["mu"]), sigma=np.array(case["sigma"]))
+    imm = np.float64(case["imm"][0]) if case["metric_kind"] == "scalar" else np.array(case["imm"])
+    metric = co.Metric(imm, D)
+    q, U, g = co.new_state(otgt, np.array(case["q0"]))
+    rng = co.site_states(case["seeds"], 4 if case["sampler"] == "nuts" else 2)
+    for st in case["steps"]:
+        if case["sampler"] == "nuts":
+            res = co.nuts_step(otgt, metric, rng, case["eps"], q, U, g, max_exp=case["max_exp"])
+        else:
+            res = co.hmc_step(otgt, metric, rng, case["eps"], case["L"], q, U, g)
+        yield q, U, res, st
+
+
+@pytest.mark.parametrize("case", FIX["derived"], ids=lambda c: c["name"])
+def test_oracle_reproduces_fixtures(case):
+    for q, U, res, st in _oracle_run(case):
+        assert np.array_equal(q, np.array(st["position"]))  # same machine code path: bit-exact
+        assert res["n_leapfrog"].tolist() == st["n_leapfrog"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FIX["derived"], ids=lambda c: c["name"])
+def test_hip_reproduces_fixtures(case):
+    import torch
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    D = case["D"]
+    tgt = {"std_normal": targets.StdNormal, "iso": targets.IsoGaussian}.get(case["target_kind"])
+    tgt = tgt() if tgt else targets.DiagGaussian(np.array(case["mu"]), np.array(case["sigma"]))
+    imm = np.float64(case["imm"][0]) if case["metric_kind"] == "scalar" else np.array(case["imm"])
+    mod = nuts if case["sampler"] == "nuts" else hmc
+    srng = RandomStream(seeds=case["seeds"])
+    kernel = nuts.new_kernel(srng, tgt, max_num_expansions=case["max_exp"]) if mod is nuts \
+        else hmc.new_kernel(srng, tgt)
+    state = mod.new_state(torch.as_tensor(np.array(case["q0"]), device="cuda"), tgt)
+    for st in case["steps"]:
+        info, _ = kernel(state, case["eps"], imm) if mod is nuts else kernel(state, case["eps"], imm, case["L"])
+        state = info.state._replace(momentum=None)
+        np.testing.assert_allclose(info.state.position.cpu().numpy(), np.array(st["position"]),
+                                   rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(info.acceptance_probability.cpu().numpy(),
+                                   st["acceptance_probability"], rtol=1e-9)
+        assert info.n_leapfrog.cpu().tolist() == st["n_leapfrog"]
+        assert info.is_diverging.cpu().int().tolist() == st["is_diverging"]
+        if mod is nuts:
+            assert info.num_doublings.cpu().tolist() == st["num_doublings"]
+            assert info.is_turning.cpu().int().tolist() == st["is_turning"]
+
+
+def test_published_values_are_the_reference_ones():
+    p = FIX["published"]
+    assert p["G1"]["position"] == 1.1034719409361107 and p["G3"]["logprob"] == -32238.026021294307

@@ -298,7 +298,7 @@ def test_nuts_fused_equals_lockstep_bitwise(eng):
         outs.append((info.state.position.cpu().numpy(), info.state.momentum.cpu().numpy(),
                      info.acceptance_probability.cpu().numpy(), info.n_leapfrog.cpu().numpy(),
                      info.num_doublings.cpu().numpy(), upd[srng].cpu().numpy()))
-    eng.set_option("fused_nuts", 1)
+    eng.set_option("fused_nuts", 0)
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
 
@@ -436,3 +436,31 @@ def test_config2_full_size_properties_and_subset_parity():
     assert info.n_leapfrog.sum().item() == C * L
     # stationarity: positions stay ~N(0, I)
     assert abs(info.state.position.var().item() - 1.0) < 0.02
+
+
+# ------------------------------------------------------------------ full-size config c5 (one GPU's shard)
+def test_config5_regression_warmup_properties():
+    """BASELINE config 5 at one GPU's share: regression scaled to 1e5 rows (notebook generator),
+    D=2, 1024 of the 8192 chains, NUTS + window adaptation.  Size-independent properties:
+    every chain finds the posterior mode (w ~ 3, n ~ |noise|), adapted step sizes are finite
+    and positive, leapfrog counts are consistent, and the state equals a fresh new_state."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    rng = np.random.default_rng(0)
+    N, C = 100_000, 1024
+    X = rng.normal(0, 1, size=(N,))
+    y = 3 * X + rng.normal(0, 1)
+    tgt = targets.LinearRegression(X, y)
+    q0 = np.array([3.0, np.log(0.5)]) + 0.05 * rng.normal(size=(C, 2))
+    kernel = nuts.new_kernel(RandomStream(seeds=[5000 + c for c in range(C)]), tgt)
+    state = nuts.new_state(dev(q0), tgt)
+    last, (eps, imm), _ = window_adaptation.run(kernel, state, 40)
+    e, m = eps.value.cpu().numpy(), imm.value.cpu().numpy()
+    assert np.isfinite(e).all() and (e > 0).all() and np.isfinite(m).all() and (m > 0).all()
+    info, _ = kernel(last, eps, imm)
+    pos = info.state.position.cpu().numpy()
+    assert np.isfinite(pos).all()
+    assert abs(np.median(pos[:, 0]) - 3.0) < 0.05
+    assert (info.n_leapfrog.cpu().numpy() >= 2).all()
+    fresh = nuts.new_state(info.state.position, tgt)
+    np.testing.assert_allclose(fresh.potential_energy.cpu().numpy(),
+                               info.state.potential_energy.cpu().numpy(), rtol=1e-10)
