@@ -1,0 +1,92 @@
+"""Edge cases through the C-ABI: ragged sizes, degenerate arguments, non-finite inputs,
+error paths (reference behaviours: metrics.py:60-63, proposals.py:43-45, hmc.py:189-191)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle as co  # noqa: E402
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+
+
+@pytest.mark.parametrize("C,D", [(1, 1), (3, 63), (5, 64), (7, 65), (2, 129), (9, 1025)])
+def test_ragged_shapes_nuts_and_hmc(C, D):
+    """C not a multiple of 4 chains per block, D around the 64-lane and register-tile edges
+    (1025 > the fused HMC kernel's limit -> lock-step path)."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    r = np.random.default_rng(C * 1000 + D)
+    mu, sigma, imm = r.normal(size=D), 0.5 + r.random(D), 0.5 + r.random(D)
+    tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
+    metric = co.Metric(imm, D)
+    seeds = list(range(C))
+    q0 = r.normal(size=(C, D))
+    eps = 0.3 / D ** 0.25
+    srng = RandomStream(seeds=seeds)
+    nk, hk = nuts.new_kernel(srng, tgt, max_num_expansions=5), hmc.new_kernel(srng, tgt)
+    state = nuts.new_state(dev(q0), tgt)
+    q, U, g = co.new_state(otgt, q0.copy())
+    rng, hrng = co.site_states(seeds, 4), co.site_states(seeds, 2, first_site=4)
+    info, _ = nk(state, eps, imm)
+    co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=5)
+    np.testing.assert_allclose(info.state.position.cpu().numpy(), q, rtol=1e-9, atol=1e-12)
+    info, _ = hk(info.state._replace(momentum=None), eps, imm, 5)
+    co.hmc_step(otgt, metric, hrng, eps, 5, q, U, g)
+    np.testing.assert_allclose(info.state.position.cpu().numpy(), q, rtol=1e-9, atol=1e-12)
+
+
+def test_degenerate_arguments():
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    tgt = targets.StdNormal()
+    q0 = dev(np.random.default_rng(0).normal(size=(4, 3)))
+    state = hmc.new_state(q0, tgt)
+    # L = 0: nothing integrates, delta = 0 -> p_accept = 1, state unchanged (hmc.py:185-195)
+    info, _ = hmc.new_kernel(RandomStream(seeds=[1, 2, 3, 4]), tgt)(state, 0.1, np.ones(3), 0)
+    assert torch.equal(info.state.position, q0) and (info.acceptance_probability == 1).all()
+    assert (info.n_leapfrog == 0).all()
+    # a single expansion: 2 leapfrogs (2**0 + 1)
+    info, _ = nuts.new_kernel(RandomStream(seeds=[1, 2, 3, 4]), tgt, max_num_expansions=1)(state, 1e-3, np.ones(3))
+    assert (info.n_leapfrog == 2).all() and (info.num_doublings == 1).all()
+    # negative step size integrates backwards in time: still a valid transition
+    info, _ = nuts.new_kernel(RandomStream(seeds=[1, 2, 3, 4]), tgt)(state, -0.2, np.ones(3))
+    assert torch.isfinite(info.state.position).all()
+
+
+def test_non_finite_energy_is_divergence_not_error():
+    """NaN energy -> delta = -inf -> is_diverging, p_accept = 0, chain stays (hmc.py:189-195;
+    proposals.py:43-45)."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    tgt = targets.StdNormal()
+    q0 = np.array([[0.5, 0.5], [1.0, -1.0]])
+    state = hmc.new_state(dev(q0), tgt)
+    info, _ = hmc.new_kernel(RandomStream(seeds=[0, 1]), tgt)(state, 1e200, np.ones(2), 3)
+    assert info.is_diverging.all() and (info.acceptance_probability == 0).all()
+    assert torch.equal(info.state.position.cpu(), torch.as_tensor(q0))
+    info, _ = nuts.new_kernel(RandomStream(seeds=[0, 1]), tgt)(state, 1e200, np.ones(2))
+    assert info.is_diverging.all() and torch.equal(info.state.position.cpu(), torch.as_tensor(q0))
+    assert (info.num_doublings == 1).all()
+
+
+def test_error_paths():
+    from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.engine import EngineError, get_engine
+    tgt = targets.StdNormal()
+    state = nuts.new_state(dev(np.zeros((2, 3))), tgt)
+    kernel = nuts.new_kernel(RandomStream(seeds=[0, 1]), tgt)
+    with pytest.raises(ValueError):  # metrics.py:60-63
+        kernel(state, 0.1, np.ones((3, 3, 3)))
+    with pytest.raises(ValueError):  # wrong diagonal length
+        kernel(state, 0.1, np.ones(4))
+    with pytest.raises(ValueError):  # non-symmetric dense imm
+        kernel(state, 0.1, np.array([[1.0, 0.5, 0], [0.0, 1, 0], [0, 0, 1.0]]))
+    with pytest.raises(ValueError):  # chain count mismatch
+        kernel(nuts.new_state(dev(np.zeros((3, 3))), tgt), 0.1, np.ones(3))
+    eng = get_engine()
+    with pytest.raises(EngineError):
+        eng.set_option("no_such_option", 1)
+    bad = nuts.new_kernel(RandomStream(seeds=[0, 1]), tgt, max_num_expansions=0)
+    with pytest.raises(EngineError):
+        bad(state, 0.1, np.ones(3))

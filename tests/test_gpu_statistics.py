@@ -1,0 +1,57 @@
+"""The reference's end-to-end statistical checks (tests/test_hmc.py:100-264), run on many
+independent chains on the GPU so that the Monte-Carlo error is far tighter than the
+reference's single-chain version."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("step_size, diverges", [(3.9, False), (4.1, True)])
+def test_univariate_hmc(step_size, diverges):
+    # tests/test_hmc.py:100-155: N(1, 2^2), L=30, start at 3.0; stable iff step < 2 sigma
+    from aehmc_amd import RandomStream, hmc, targets
+    C = 256
+    tgt = targets.DiagGaussian(np.array([1.0]), np.array([2.0]))
+    srng = RandomStream(seeds=list(range(C)))
+    srng.sites(1)  # the reference draws Y_rv from the same stream first (test_hmc.py:116)
+    kernel = hmc.new_kernel(srng, tgt)
+    state = hmc.new_state(torch.full((C,), 3.0, dtype=torch.float64, device="cuda"), tgt, num_chains=C)
+    samples, info, acc, div = kernel.sample(state, step_size, 1.0, 30, 2000)
+    s = samples.cpu().numpy()
+    if diverges:
+        assert np.all(s == 3.0)
+    else:
+        assert np.mean(s[1000:]) == pytest.approx(1.0, rel=1e-1)
+        assert np.var(s[1000:]) == pytest.approx(4.0, rel=1e-1)
+        # many chains: much tighter than the reference's 10 %
+        assert abs(np.mean(s[1000:]) - 1.0) < 0.05 and abs(np.var(s[1000:]) - 4.0) < 0.2
+
+
+def test_hmc_mcse_correlated_mvn():
+    # tests/test_hmc.py:190-264: mu=[0,3], sigma=[1,2], rho=.5, eps=1, L=30, imm=sigma (sic)
+    from scipy import stats
+    from aehmc_amd import RandomStream, hmc, targets
+    loc, scale, rho = np.array([0.0, 3.0]), np.array([1.0, 2.0]), 0.5
+    cov = np.diag(scale**2)
+    cov[0, 1] = cov[1, 0] = rho * scale[0] * scale[1]
+    prec = np.linalg.inv(cov)
+    prec = 0.5 * (prec + prec.T)
+    C = 512
+    tgt = targets.DenseMVN(loc, prec)
+    kernel = hmc.new_kernel(RandomStream(seeds=[10_000 + c for c in range(C)]), tgt)
+    q0 = np.random.default_rng(0).standard_normal((C, 2))
+    state = hmc.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+    _, info, _, _ = kernel.sample(state, 1.0, scale, 30, 300, keep_samples=False)   # burn-in
+    samples, info, acc, div = kernel.sample(info.state._replace(momentum=None), 1.0, scale, 30, 400)
+    s = samples.cpu().numpy()  # [400, C, 2]
+    assert not div.any().item()
+
+    def pvalue(delta):  # chains are independent: MCSE from the spread of per-chain means
+        m = delta.mean(axis=0)
+        return stats.norm.sf(np.abs(m.mean(axis=0)) / (m.std(axis=0, ddof=1) / np.sqrt(C)))
+
+    assert np.all(pvalue(s - loc) > 0.001)
+    assert np.all(pvalue(np.square(s - loc) - scale**2) > 0.001)
+    assert np.all(pvalue(np.prod(s - loc, axis=2) / np.prod(scale) - rho) > 0.001)
