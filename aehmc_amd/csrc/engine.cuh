@@ -948,6 +948,10 @@ __global__ __launch_bounds__(256) void k_fill_i64(long long *x, long long n, lon
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i < n; i += (long long)gridDim.x * blockDim.x) x[i] = v;
 }
+__global__ __launch_bounds__(256) void k_add_i64(long long *acc, const long long *x, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (long long)gridDim.x * blockDim.x) acc[i] += x[i];
+}
 __global__ void k_log(const double *x, double *y, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = log(x[i]);

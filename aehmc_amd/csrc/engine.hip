@@ -462,12 +462,9 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
   FAIL("new_state: target kind not implemented");
 }
 
-extern "C" int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
-                               int64_t max_num_expansions, double divergence_threshold, double *q,
-                               double *U, double *g, const aehmc_diagnostics *out, void *stream) {
-  if (!ctx || !out) return -2;
-  HIPCHK(hipSetDevice(ctx->device));
-  hipStream_t st = (hipStream_t)stream;
+static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                    int64_t max_num_expansions, double divergence_threshold, double *q, double *U,
+                    double *g, const aehmc_diagnostics *out, hipStream_t st) {
   if (max_num_expansions < 1 || max_num_expansions > 20) FAIL("max_num_expansions must be in [1, 20]");
   if (!out->acceptance_probability || !out->is_diverging) FAIL("diagnostics arrays missing");
   EngineArgs a;
@@ -520,6 +517,50 @@ extern "C" int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double 
     }
     HIPCHK(hipEventRecord(ctx->ev[slot], st));
     batch++;
+  }
+  return 0;
+}
+
+extern "C" int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                               int64_t max_num_expansions, double divergence_threshold, double *q,
+                               double *U, double *g, const aehmc_diagnostics *out, void *stream) {
+  if (!ctx || !out) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  return nuts_run(ctx, C, rng, step_size, max_num_expansions, divergence_threshold, q, U, g, out,
+                  (hipStream_t)stream);
+}
+
+extern "C" int aehmc_nuts_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                                 int64_t max_num_expansions, double divergence_threshold,
+                                 int64_t num_samples, double *q, double *U, double *g,
+                                 const aehmc_diagnostics *out, double *samples,
+                                 double *acceptance_history, int32_t *divergence_history,
+                                 int64_t *n_leapfrog_total, void *stream) {
+  if (!ctx || !out) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (num_samples < 1) FAIL("number of transitions must be >= 1");
+  if (!ctx->has_tgt) FAIL("set_target and set_metric must be called first");
+  const int64_t D = ctx->tgt.D;
+  if (n_leapfrog_total) {
+    if (!out->n_leapfrog) FAIL("n_leapfrog_total needs out->n_leapfrog");
+    HIPCHK(hipMemsetAsync(n_leapfrog_total, 0, C * sizeof(int64_t), st));
+  }
+  for (int64_t t = 0; t < num_samples; t++) {
+    if (int rc = nuts_run(ctx, C, rng, step_size, max_num_expansions, divergence_threshold, q, U, g,
+                          out, st))
+      return rc;
+    if (samples)
+      HIPCHK(hipMemcpyAsync(samples + (size_t)t * C * D, q, (size_t)C * D * sizeof(double),
+                            hipMemcpyDeviceToDevice, st));
+    if (acceptance_history)
+      HIPCHK(hipMemcpyAsync(acceptance_history + (size_t)t * C, out->acceptance_probability,
+                            C * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (divergence_history)
+      HIPCHK(hipMemcpyAsync(divergence_history + (size_t)t * C, out->is_diverging, C * sizeof(int32_t),
+                            hipMemcpyDeviceToDevice, st));
+    if (n_leapfrog_total)
+      LAUNCH(k_add_i64, C, st, (long long *)n_leapfrog_total, (const long long *)out->n_leapfrog, (long long)C);
   }
   return 0;
 }

@@ -234,6 +234,23 @@ class Engine:
                                              ct.byref(c), self.stream), "aehmc_nuts_step")
         return out
 
+    def nuts_sample(self, rng, eps, max_exp, thr, n, q, U, g, keep_samples=True):
+        C, D = q.shape
+        self.ensure_workspace(C, max_exp)
+        out, c = self._diag(C, D, True)
+        dev = self.device
+        samples = torch.empty(n, C, D, dtype=torch.float64, device=dev) if keep_samples else None
+        acc = torch.empty(n, C, dtype=torch.float64, device=dev)
+        div = torch.empty(n, C, dtype=torch.int32, device=dev)
+        total = torch.zeros(C, dtype=torch.int64, device=dev)
+        self._check(self.lib.aehmc_nuts_sample(
+            self.ctx, C, rng.data_ptr(), float(eps), int(max_exp), float(thr), int(n), q.data_ptr(),
+            U.data_ptr(), g.data_ptr(), ct.byref(c), samples.data_ptr() if keep_samples else None,
+            acc.data_ptr(), div.data_ptr(), total.data_ptr(), self.stream), "aehmc_nuts_sample")
+        out["samples"], out["acceptance_history"], out["divergence_history"] = samples, acc, div
+        out["n_leapfrog"] = total
+        return out
+
     def leapfrog(self, eps, nsteps, q, p, U, g):
         C, D = q.shape
         self.ensure_workspace(C, 1)

@@ -45,5 +45,36 @@ def new_kernel(srng: RandomStream, logprob_fn, max_num_expansions: int = 10,
             n_leapfrog=layout.per_chain(out["n_leapfrog"]))
         return info, {srng: holder["rng"]}
 
+    def sample(state: IntegratorState, step_size, inverse_mass_matrix, num_samples: int,
+               keep_samples: bool = True):
+        """``num_samples`` consecutive transitions per chain in one engine call (the
+        reference's user-level ``aesara.scan(kernel, n_steps=N)``, tests/test_hmc.py:296-324).
+        Returns ``(samples [N, ...], Diagnostics of the last transition with the leapfrog
+        TOTAL in n_leapfrog, acceptance history, divergence history)``."""
+        eng = get_engine()
+        layout = Layout(tuple(state.position.shape), srng.batched, srng.num_chains)
+        if "rng" not in holder:
+            holder["rng"] = rng_to_device(rng_host, eng.device)
+        q, U, g = state_rows(state, layout, eng.device)
+        eng.set_target(logprob_fn, layout.D)
+        eng.set_metric(inverse_mass_matrix, layout.D)
+        out = eng.nuts_sample(holder["rng"], eng.set_step_sizes(step_size), int(max_num_expansions),
+                              float(divergence_threshold), int(num_samples), q, U, g, keep_samples)
+        info = Diagnostics(
+            state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
+                                  potential_energy=layout.per_chain(U),
+                                  potential_energy_grad=layout.vec(g)),
+            acceptance_probability=layout.per_chain(out["acceptance_probability"]),
+            num_doublings=layout.per_chain(out["num_doublings"]),
+            is_turning=layout.per_chain(out["is_turning"].bool()),
+            is_diverging=layout.per_chain(out["is_diverging"].bool()),
+            n_leapfrog=layout.per_chain(out["n_leapfrog"]))
+        n = int(num_samples)
+        samples = out["samples"].reshape((n,) + layout.user_shape) if keep_samples else None
+        hist_shape = (n,) + layout.scalar_chain_shape
+        return (samples, info, out["acceptance_history"].reshape(hist_shape),
+                out["divergence_history"].bool().reshape(hist_shape))
+
+    step.sample = sample
     step.num_chains, step.batched = srng.num_chains, srng.batched
     return step

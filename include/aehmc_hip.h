@@ -162,6 +162,15 @@ int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t stage, int3
                        const double *acceptance_probability, const double *position,
                        const aehmc_adapt_state *state, void *stream);
 
+/* num_samples consecutive NUTS transitions per chain (the user-level scan of
+ * tests/test_hmc.py:296-324); same optional outputs as aehmc_hmc_sample plus the per-chain
+ * leapfrog total [C].  `out` describes the last transition. */
+int aehmc_nuts_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
+                      int64_t max_num_expansions, double divergence_threshold, int64_t num_samples,
+                      double *q, double *U, double *g, const aehmc_diagnostics *out, double *samples,
+                      double *acceptance_history, int32_t *divergence_history,
+                      int64_t *n_leapfrog_total, void *stream);
+
 /* ---- building blocks exported for known-answer tests / callers that want them ---- */
 
 /* integrators.py:54-73 applied nsteps times to C chains (state in place) */
