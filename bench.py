@@ -143,8 +143,14 @@ def main():
         flops = kern_flops / max(kern_n, 1)
         avg_s = kern_ms / 1e3 / max(kern_n, 1)
         achieved = flops / avg_s / 1e12
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r1", "c3_pmc_summary.json")
+        if os.path.exists(pmc) and D == 10_000 and C == 4096:  # measured offline: rocprofv3 --pmc cannot run inside the bench
+            traffic = json.load(open(pmc))["gemm_summary"]["traffic_bytes_per_launch_avg"]
+            traffic_src = "profiles/r1/c3_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                    "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": (2.0 * flops / (2.0 * D * D) * D + D * D) * 8,
                     "kernel": "gemm_nt_f64_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
                     "avg_rows_per_launch": flops / (2.0 * D * D), "gemm_share_of_step_time": kern_ms / 1e3 / elapsed}
     else:
@@ -155,7 +161,10 @@ def main():
         roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS, "traffic": None, "kernel": "k_hmc_fused",
                     "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
-                    "note": "state is register-resident for all L steps; >1 means on-chip reuse"}
+                    "achieved_io_only_GBs": 40.0 * D * C * 25 / avg_s / 1e9,
+                    "note": "achieved uses SURVEY 8d's streaming figure (48*D B per leapfrog); the state is "
+                            "register-resident for all L steps, so frac > 1 means on-chip reuse; "
+                            "achieved_io_only_GBs counts what the kernel really moves (40*D B per transition)"}
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
