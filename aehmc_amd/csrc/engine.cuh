@@ -88,10 +88,28 @@ __device__ __forceinline__ void put2(double (&arr)[2], int i, double v) {
   else arr[0] = v;
 }
 
+// Wavefront all-reduce of a double.  Four DPP butterfly stages (xor 1, xor 2, mirror within
+// 8, mirror within 16: every stage adds a value to its mirror image, so all lanes of a
+// 16-lane row end with the same bits), then the four row sums are read with v_readlane and
+// added in a fixed order.  The result is wave-uniform by construction (and known to be so
+// by the compiler, which keeps it in SGPRs) -- no LDS-crossbar ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return x + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double read_lane_f64(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                          __builtin_amdgcn_readlane(__double2loint(x), l));
+}
 __device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-  return x;
+  x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);   // quad_perm [2,3,0,1]
+  x = dpp_add<0x141>(x);  // row_half_mirror
+  x = dpp_add<0x140>(x);  // row_mirror
+  return ((read_lane_f64(x, 0) + read_lane_f64(x, 16)) + read_lane_f64(x, 32)) + read_lane_f64(x, 48);
 }
 
 __device__ __forceinline__ double np_logaddexp(double x, double y) {  // numpy npy_logaddexp
@@ -524,9 +542,12 @@ __device__ inline void draw_momentum(const EngineArgs &a, long long c, int lane,
 }
 
 // ------------------------------------------------------------------- kernels ------
+// the wave index is made explicitly wave-uniform so that per-chain scalars (ChainCtl, RNG
+// states) are fetched with scalar loads and live in SGPRs
 #define AEHMC_CHAIN_OF_WAVE()                                                   \
   const int lane = threadIdx.x & 63;                                            \
-  const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+  const long long c = (long long)blockIdx.x * (blockDim.x >> 6) +               \
+                      __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  \
   if (c >= a.C) return;
 
 template <bool MET_DENSE>

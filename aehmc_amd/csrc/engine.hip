@@ -12,6 +12,7 @@
 #include "engine.cuh"
 #include "gemm_f64.cuh"
 #include "hmc_fused.cuh"
+#include "nuts_resident.cuh"
 
 using namespace aehmc;
 
@@ -36,6 +37,8 @@ struct aehmc_ctx {
   int *d_active = nullptr;
   hipEvent_t ev[NRING] = {};
   bool opt_fused_hmc = true;
+  int opt_resident_min_team = 0;  // tests: always use the smallest team that holds the chain
+  bool opt_resident_nuts = true;  // register-resident single-launch NUTS (nuts_resident.cuh)
   bool opt_fused_nuts = false;   // whole NUTS transition in one launch (diag metric, coordinate-wise target)
   bool opt_dense_linear = true;  // one metric GEMM per leapfrog (v carried by linearity)
   bool opt_compact = true;       // finished chains drop out of the GEMMs
@@ -200,6 +203,14 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
   if (!ctx || !name) return -2;
   if (!strcmp(name, "fused_hmc")) {
     ctx->opt_fused_hmc = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "resident_min_team")) {
+    ctx->opt_resident_min_team = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "resident_nuts")) {
+    ctx->opt_resident_nuts = value != 0;
     return 0;
   }
   if (!strcmp(name, "fused_nuts")) {
@@ -472,6 +483,16 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   a.eps = step_size; a.thr = divergence_threshold;
   a.rng = rng; a.nsites = 4;
   a.q = q; a.U = U; a.g = g; a.out = *out;
+  if (ctx->opt_resident_nuts && nuts_resident_supported(a.tkind, a.met_ndim, a.D)) {
+    const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
+    if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+    HIPCHK(launch_nuts_resident(a, st, ctx->opt_resident_min_team));
+    if (p) {
+      HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
+      ctx->prof_used += 2;
+    }
+    return 0;
+  }
   if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
     const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
     if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));

@@ -47,7 +47,7 @@ inline bool hmc_fused_supported(int tkind, int met_ndim, long long D) {
 template <int R, int TK>
 __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double zlds[];  // [4 waves][R*64]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long c = (long long)blockIdx.x * 4 + w;
   if (c >= a.C) return;
   const size_t row = (size_t)c * a.D;

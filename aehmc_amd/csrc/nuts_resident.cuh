@@ -1,0 +1,463 @@
+// Register-resident NUTS transition (gfx950): the whole nuts.new_kernel(...)(state, eps, imm)
+// call in ONE launch, the chain's moving state living on chip for the entire tree.
+//
+// A *team* of T threads owns one chain:
+//   T = 64            one wavefront per chain (the north star's layout), 128 < D <= 512;
+//   T = 256 / 1024    one workgroup per chain for larger D (cross-wave sums through LDS);
+//   T = 1 ... 32      sub-wavefront teams for small D: 64/T chains share a wavefront, so the
+//                     per-chain scalar work (RNG, exp/log of the proposal weights, tree
+//                     indices) -- ~3000 fp64 instructions per leapfrog that a full wave
+//                     would execute 64x redundantly -- is executed once per T lanes; the
+//                     chains of a wave diverge like ordinary SIMT threads.
+// Thread t keeps elements t, t+T, ... of
+// q, p, dU/dq and of the sub-trajectory momentum sum in VGPRs; energies and U-turn dot
+// products are __shfl_xor wavefront reductions (plus one LDS hop across the waves of a
+// workgroup team).  HBM/L2 sees only the U-turn checkpoints (written every other step,
+// ~1 pair read per step), the trajectory ends at expansion boundaries and the proposal on
+// accept -- instead of the 88*D bytes per leapfrog of a streaming implementation.
+//
+// Diagonal / scalar metric (shared or per chain), coordinate-wise targets.  Arithmetic and
+// its order are those of the lock-step path in engine.cuh (for T = 64 bit for bit, tested);
+// reference: nuts.py:56-153, trajectory.py:154-374,428-714, termination.py:85-235,
+// proposals.py:19-174, integrators.py:54-73, metrics.py:44-104.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "engine.cuh"
+
+namespace aehmc {
+
+template <int T>
+struct Team {
+  static constexpr bool SUB = (T < 64);    // several chains per wavefront
+  static constexpr bool WAVE = (T == 64);  // one wavefront per chain
+  static constexpr bool MULTI = (T > 64);  // one workgroup per chain
+  static constexpr int BLOCK = MULTI ? T : 256;
+  static constexpr int NW = MULTI ? T / 64 : 1;  // waves per team
+};
+
+// butterfly sum over the T (< 64) consecutive lanes of a sub-wavefront team
+template <int T>
+__device__ __forceinline__ double subwave_sum(double x) {
+  if (T >= 2) x = dpp_add<0xB1>(x);
+  if (T >= 4) x = dpp_add<0x4E>(x);
+  if (T >= 8) x = dpp_add<0x141>(x);
+  if (T >= 16) x = dpp_add<0x140>(x);
+  if (T >= 32) x += __shfl_xor(x, 16);
+  return x;
+}
+
+// sum of two values over the team; every thread of the team returns the same bits
+template <int T>
+__device__ __forceinline__ void team_sum2(double &x, double &y, double (*red)[2 * Team<T>::NW], int &flip) {
+  if (Team<T>::SUB) {
+    x = subwave_sum<T>(x);
+    y = subwave_sum<T>(y);
+    return;
+  }
+  x = wave_sum(x);
+  y = wave_sum(y);
+  if (Team<T>::MULTI) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    double *buf = red[flip];
+    flip ^= 1;  // double-buffered: the next reduction writes the other buffer
+    if (lane == 0) {
+      buf[2 * wave] = x;
+      buf[2 * wave + 1] = y;
+    }
+    __syncthreads();
+    double sx = buf[0], sy = buf[1];
+#pragma unroll
+    for (int w = 1; w < Team<T>::NW; w++) {
+      sx += buf[2 * w];
+      sy += buf[2 * w + 1];
+    }
+    x = sx;
+    y = sy;
+  }
+}
+
+template <int T, int R>
+__global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
+  using TM = Team<T>;
+  __shared__ double red[2][2 * TM::NW];
+  int flip = 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long c = TM::SUB    ? ((long long)blockIdx.x * 256 + threadIdx.x) / T
+                      : TM::WAVE ? (long long)blockIdx.x * 4 + wave
+                                 : (long long)blockIdx.x;
+  const int t = TM::SUB ? (int)(threadIdx.x % T) : TM::WAVE ? lane : (int)threadIdx.x;
+  if (c >= a.C) return;  // a whole team leaves together (only workgroup teams use the barrier)
+  const size_t row = (size_t)c * a.D;
+  const bool lead = t == 0;
+
+  double q[R], p[R], g[R], pb[R];  // moving end + sub-trajectory momentum sum
+  bool ok[R];
+  // imm is re-read from L1/L2 when many elements per thread would cost registers
+  constexpr bool IM_REG = R <= 4;
+  double imr[IM_REG ? R : 1];
+  const size_t imo = (size_t)c * a.imm_cs;
+#define IMM(r) (IM_REG ? imr[IM_REG ? (r) : 0] : a.imm[imo + (a.met_ndim == 0 ? 0 : (long long)t + (long long)T * (r))])
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const long long i = (long long)t + (long long)T * r;
+    ok[r] = i < a.D;
+    if (IM_REG) imr[r] = ok[r] ? a.imm[imo + (a.met_ndim == 0 ? 0 : i)] : 1.0;
+    q[r] = ok[r] ? a.q[row + i] : 0.0;
+    g[r] = ok[r] ? a.g[row + i] : 0.0;
+  }
+
+  // ---- momentum, site #1 (nuts.py:113 -> metrics.py:65-68) ------------------------
+  ChainRng rng = rng_load(a, c);
+  if (TM::SUB) {
+    // every lane of the team walks the chain's stream itself and keeps its own elements
+    const double *sm = a.sqrt_mass + imo;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      p[r] = 0.0;
+      for (int tt = 0; tt < T; tt++) {
+        const long long i = (long long)tt + (long long)T * r;
+        if (i < a.D) {
+          const double z = rng_standard_normal(rng.g[0]);
+          if (tt == t) p[r] = (a.met_ndim == 0 ? sm[0] : sm[i]) * z;
+        }
+      }
+    }
+    if (lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
+  } else {
+    if (TM::WAVE || wave == 0) {
+      const double *sm = a.sqrt_mass + imo;
+      const bool scalar = a.met_ndim == 0;
+      double *dst = a.zbuf;
+      wave_normals(rng.g[0], a.D, [=](long long i, double z) { dst[row + i] = (scalar ? sm[0] : sm[i]) * z; });
+      if (lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
+    }
+    __threadfence_block();
+    if (TM::MULTI) __syncthreads();
+  }
+
+  // ---- nuts.py:113-125 ----------------------------------------------------------------
+  ChainCtl ct;
+  double kd = 0.0, zero = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const long long i = (long long)t + (long long)T * r;
+    if (!TM::SUB) p[r] = ok[r] ? a.zbuf[row + i] : 0.0;
+    pb[r] = 0.0;
+    if (ok[r]) {
+      kd += (IMM(r) * p[r]) * p[r];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        a.end_q[e][row + i] = q[r];
+        a.end_p[e][row + i] = p[r];
+        a.end_g[e][row + i] = g[r];
+      }
+      a.slot_q[0][row + i] = q[r];
+      a.slot_p[0][row + i] = p[r];
+      a.slot_g[0][row + i] = g[r];
+      a.psum[row + i] = p[r];
+    }
+  }
+  team_sum2<T>(kd, zero, red, flip);
+  {
+    const double U = a.U[c];
+    ct.H0 = U + 0.5 * kd;
+    ct.prop_E = ct.H0;
+    ct.prop_w = 0.0;
+    ct.prop_slpa = -INFINITY;
+    ct.sub_E = ct.sub_w = ct.sub_slpa = 0.0;
+    ct.U_cur = ct.U_end[0] = ct.U_end[1] = ct.U_slot[0] = ct.U_slot[1] = U;
+    ct.acc_prob = 0.0;
+    ct.nleap = 0;
+    ct.j = 0;
+    ct.length = 0;
+    ct.tmin = ct.tmax = 0;
+    ct.done = ct.phantom = 0;
+    ct.prop_slot = 0;
+    ct.ndoubl = ct.out_div = ct.out_turn = ct.hmc_accept = 0;
+    ct.dir = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
+    ct.step = 0;
+  }
+  const double eps = a.eps_c ? a.eps_c[c] : a.eps;
+
+  while (!ct.done) {
+    // ---- one leapfrog of the moving end, in registers (integrators.py:54-73) ---------
+    const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
+    const double b = 0.5 * step_size, aa = 1 * step_size;
+    double usum = 0.0;
+    kd = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        const long long i = (long long)t + (long long)T * r;
+        double pp = p[r] - b * g[r];
+        double qq = q[r] + aa * (IMM(r) * pp);
+        double u, gg;
+        target_elem(a, i, qq, u, gg);
+        usum += u;
+        pp = pp - b * gg;
+        q[r] = qq;
+        g[r] = gg;
+        p[r] = pp;
+        kd += (IMM(r) * pp) * pp;
+      }
+    }
+    team_sum2<T>(usum, kd, red, flip);
+    ct.U_cur = target_finish(a, usum);
+
+    // ---- dynamic_integration body (trajectory.py:195-305) ------------------------------
+    const int step = ct.step;
+    if (!ct.phantom) ct.nleap += 1;
+    int tmin, tmax;
+    if (step == 0) {
+      tmin = ct.tmin;  // termination.py:109-113: stale indices of the previous sub-trajectory
+      tmax = ct.tmax;
+    } else {
+      int n1 = __ffs(~step) - 1;
+      tmax = __popc(step >> 1);
+      tmin = tmax - n1 + 1;
+    }
+    const bool even = (step & 1) == 0;
+    {
+      double *ckp = a.ckp + ((size_t)tmax * a.C + c) * a.D;
+      double *cks = a.cks + ((size_t)tmax * a.C + c) * a.D;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          const long long i = (long long)t + (long long)T * r;
+          pb[r] = (step == 0) ? p[r] : pb[r] + p[r];
+          if (even) {
+            ckp[i] = p[r];
+            cks[i] = pb[r];
+          }
+        }
+      }
+    }
+    ct.tmin = tmin;
+    ct.tmax = tmax;
+    const double E = ct.U_cur + 0.5 * kd;  // proposals.py:19-62
+    double delta = ct.H0 - E;
+    if (isnan(delta)) delta = -INFINITY;
+    const bool div = fabs(delta) > a.thr;
+    const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
+    bool term = false, take = false;
+    if (step == 0) {
+      ct.sub_E = E;
+      ct.sub_w = np_w;
+      ct.sub_slpa = np_slpa;
+      ct.length = 1;
+      take = true;
+    } else {
+      double pa = 1.0 / (1.0 + exp(-(np_w - ct.sub_w)));  // proposals.py:96-99
+      if (isnan(pa)) pa = 0.0;
+      int acc = rng_bernoulli(rng.g[2], pa);
+      ct.sub_w = np_logaddexp(ct.sub_w, np_w);
+      ct.sub_slpa = np_logaddexp(ct.sub_slpa, np_slpa);
+      if (acc) {
+        ct.sub_E = E;
+        take = !ct.phantom;
+      }
+      ct.length += 1;
+      if (tmax >= tmin) {  // termination.py:133-187
+        int idx = tmax;
+        bool crit = false;
+        for (;;) {
+          const double *kp = a.ckp + ((size_t)idx * a.C + c) * a.D;
+          const double *ks = a.cks + ((size_t)idx * a.C + c) * a.D;
+          double d_l = 0.0, d_r = 0.0;
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            if (ok[r]) {
+              const long long i = (long long)t + (long long)T * r;
+              double pl = kp[i], pr = p[r];
+              double vl = IMM(r) * pl, vr = IMM(r) * pr;
+              double sub = pb[r] - ks[i] + pl;
+              double rho = sub - (pr + pl) / 2;
+              d_l += vl * rho;
+              d_r += vr * rho;
+            }
+          }
+          team_sum2<T>(d_l, d_r, red, flip);
+          crit = (d_l <= 0) | (d_r <= 0);
+          bool reached = (idx - 1) < tmin;
+          idx -= 1;
+          if (crit || reached) break;
+        }
+        term = crit;
+      }
+    }
+    if (take) {  // sub-trajectory proposal <- moving end (copy on accept)
+      const int s = ct.prop_slot ^ 1;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          const long long i = (long long)t + (long long)T * r;
+          pick2(a.slot_q, s)[row + i] = q[r];
+          pick2(a.slot_p, s)[row + i] = p[r];
+          pick2(a.slot_g, s)[row + i] = g[r];
+        }
+      }
+      put2(ct.U_slot, s, ct.U_cur);
+    }
+
+    // ---- sub-trajectory / expansion control (trajectory.py:336, 537-608) ----------------
+    bool finalize = false, fin_div = false, fin_term = false;
+    if (step == 0 && div && !ct.phantom) {
+      finalize = true;
+      fin_div = true;
+    } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
+      if (ct.phantom) ct.done = 1;
+      else {
+        finalize = true;
+        fin_div = div;
+        fin_term = term;
+      }
+    } else {
+      ct.step = step + 1;
+    }
+    if (finalize) {
+      const int dir = ct.dir, oth = 1 - dir;
+      double d_l = 0.0, d_r = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          const long long i = (long long)t + (long long)T * r;
+          double pc = p[r], po = pick2(a.end_p, oth)[row + i];
+          double vc = IMM(r) * pc, vo = IMM(r) * po;
+          double s = a.psum[row + i] + pb[r];
+          a.psum[row + i] = s;
+          double pl = dir ? po : pc, pr = dir ? pc : po;
+          double vl = dir ? vo : vc, vr = dir ? vc : vo;
+          double rho = s - (pr + pl) / 2;
+          d_l += vl * rho;
+          d_r += vr * rho;
+          pick2(a.end_q, dir)[row + i] = q[r];
+          pick2(a.end_p, dir)[row + i] = pc;
+          pick2(a.end_g, dir)[row + i] = g[r];
+        }
+      }
+      team_sum2<T>(d_l, d_r, red, flip);
+      const bool turning = (d_l <= 0) | (d_r <= 0);
+      put2(ct.U_end, dir, ct.U_cur);
+      ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;
+      double pbias = exp(ct.sub_w - ct.prop_w);
+      if (pbias > 1.0) pbias = 1.0;
+      if (pbias < 0.0) pbias = 0.0;
+      int acc_b = rng_bernoulli(rng.g[3], pbias);
+      if (fin_div || fin_term) {
+        ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);
+      } else {
+        ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);
+        ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
+        if (acc_b) {
+          ct.prop_slot ^= 1;
+          ct.prop_E = ct.sub_E;
+        }
+      }
+      ct.ndoubl = ct.j + 1;
+      ct.out_div = fin_div;
+      ct.out_turn = turning;
+      const bool end_transition = fin_div || turning || fin_term || (ct.j + 1 == a.max_exp);
+      if (end_transition) {
+        const int s = ct.prop_slot;  // outputs (the phantom scan below cannot change them)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          if (ok[r]) {
+            const long long i = (long long)t + (long long)T * r;
+            a.q[row + i] = pick2(a.slot_q, s)[row + i];
+            a.g[row + i] = pick2(a.slot_g, s)[row + i];
+            if (a.out.momentum) a.out.momentum[row + i] = pick2(a.slot_p, s)[row + i];
+          }
+        }
+        if (lead) {
+          a.U[c] = pick2(ct.U_slot, s);
+          a.out.acceptance_probability[c] = ct.acc_prob;
+          if (a.out.num_doublings) a.out.num_doublings[c] = ct.ndoubl;
+          if (a.out.is_turning) a.out.is_turning[c] = ct.out_turn;
+          a.out.is_diverging[c] = ct.out_div;
+        }
+        if (step == 0 && fin_div) {  // trajectory.py:336: the scan still runs (phantom)
+          ct.phantom = 1;
+          ct.step = 1;
+        } else {
+          ct.done = 1;
+        }
+      } else {
+        ct.j += 1;
+        const int go_right = rng_bernoulli(rng.g[1], 0.5);
+        ct.dir = go_right;
+        ct.step = 0;
+        if (go_right != dir) {  // continue from the other end
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            if (ok[r]) {
+              const long long i = (long long)t + (long long)T * r;
+              q[r] = pick2(a.end_q, go_right)[row + i];
+              p[r] = pick2(a.end_p, go_right)[row + i];
+              g[r] = pick2(a.end_g, go_right)[row + i];
+            }
+          }
+          ct.U_cur = pick2(ct.U_end, go_right);
+        }
+      }
+    }
+  }
+  if (lead) {
+    if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
+    pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, rng.g[1]);
+    pcg_store(a.rng + ((size_t)c * a.nsites + 2) * 4, rng.g[2]);
+    pcg_store(a.rng + ((size_t)c * a.nsites + 3) * 4, rng.g[3]);
+  }
+#undef IMM
+}
+
+inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
+  return (tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN) &&
+         met_ndim < 2 && D <= 10240;
+}
+
+template <int T, int R>
+inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
+  const unsigned grid = Team<T>::SUB    ? (unsigned)((a.C * T + 255) / 256)
+                        : Team<T>::WAVE ? (unsigned)((a.C + 3) / 4)
+                                        : (unsigned)a.C;
+  hipLaunchKernelGGL((k_nuts_resident<T, R>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a);
+  return hipGetLastError();
+}
+// Team size: the smallest team that holds the chain (<= 4 elements per lane below a wave,
+// <= 8-10 above), widened -- fewer chains per wavefront -- while that still leaves about
+// 4096 wavefronts in flight, because a wider team wastes lanes but keeps the per-chain RNG /
+// control state wave-uniform (SGPRs, scalar branches).
+inline hipError_t launch_nuts_resident(const EngineArgs &a, hipStream_t st, int force_min_team = 0) {
+  const long long D = a.D, C = a.C;
+  if (D > 512) {
+    if (D <= 1024) return launch_nuts_resident_tr<256, 4>(a, st);
+    if (D <= 2048) return launch_nuts_resident_tr<256, 8>(a, st);
+    if (D <= 4096) return launch_nuts_resident_tr<1024, 4>(a, st);
+    if (D <= 8192) return launch_nuts_resident_tr<1024, 8>(a, st);
+    return launch_nuts_resident_tr<1024, 10>(a, st);
+  }
+  const int tmin = D <= 4 ? 1 : D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64;
+  int twant = 64;
+  while (twant > 1 && C * (twant / 2) >= 64LL * 4096) twant /= 2;
+  const int T = force_min_team ? tmin : (tmin > twant ? tmin : twant);
+  switch (T) {
+    case 1:
+      if (D <= 1) return launch_nuts_resident_tr<1, 1>(a, st);
+      if (D <= 2) return launch_nuts_resident_tr<1, 2>(a, st);
+      return launch_nuts_resident_tr<1, 4>(a, st);
+    case 2: return launch_nuts_resident_tr<2, 4>(a, st);
+    case 4: return launch_nuts_resident_tr<4, 4>(a, st);
+    case 8: return launch_nuts_resident_tr<8, 4>(a, st);
+    case 16: return launch_nuts_resident_tr<16, 4>(a, st);
+    case 32: return launch_nuts_resident_tr<32, 4>(a, st);
+    default:
+      if (D <= 64) return launch_nuts_resident_tr<64, 1>(a, st);
+      if (D <= 128) return launch_nuts_resident_tr<64, 2>(a, st);
+      if (D <= 256) return launch_nuts_resident_tr<64, 4>(a, st);
+      return launch_nuts_resident_tr<64, 8>(a, st);
+  }
+}
+
+}  // namespace aehmc

@@ -101,9 +101,8 @@ __device__ inline double rng_standard_normal(Pcg64 &rng) {
 __device__ inline int binomial1_inversion(Pcg64 &rng, double p) {
   double q = 1.0 - p;
   double qn = exp(1 * log(q));
-  double np_ = 1 * p;
-  double b = np_ + 10.0 * sqrt(np_ * q + 1);
-  long long bound = (long long)(1.0 < b ? 1.0 : b);
+  // numpy: bound = min(n, n p + 10 sqrt(n p q + 1)); with n == 1 the second term is >= 10
+  const long long bound = 1;
   long long X = 0;
   double px = qn;
   double U = pcg_next_double(rng);
@@ -127,8 +126,10 @@ __device__ inline int rng_bernoulli(Pcg64 &rng, double p) {
 }
 
 // ---- wave-cooperative sequence of normals ----------------------------------------
+// broadcast lane `src` (wave-uniform) to the whole wave: v_readlane, result in SGPRs
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
-  unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
   return (((uint64_t)hi) << 32) | lo;
 }
 __device__ __forceinline__ u128 shfl_u128(u128 v, int src) {
@@ -155,9 +156,9 @@ __device__ inline void wave_normals(Pcg64 &rng, long long n, Store store) {
     if (lane < f) store(pos + lane, d.x);
     if (f < need) {
       ZigDraw df;
-      df.x = __shfl(d.x, f);
+      df.x = __longlong_as_double((long long)shfl_u64((uint64_t)__double_as_longlong(d.x), f));
       df.rabs = shfl_u64(d.rabs, f);
-      df.idx = __shfl(d.idx, f);
+      df.idx = __builtin_amdgcn_readlane(d.idx, f);
       df.accept = false;
       rng.state = shfl_u128(sk, f);
       double z = zig_slow(rng, df);

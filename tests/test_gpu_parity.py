@@ -277,6 +277,62 @@ def test_hmc_fused_equals_lockstep_bitwise(eng):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("D,C", [(1, 5), (130, 40), (300, 6), (512, 5)])
+def test_nuts_resident_equals_lockstep_bitwise(eng, D, C):
+    """Register-resident single-launch NUTS with one wavefront per chain (128 < D <= 512; and
+    D = 1, which has no reduction) runs the lock-step path's arithmetic in the same order:
+    identical bits, identical RNG use."""
+    from aehmc_amd import RandomStream, nuts, targets
+    r = np.random.default_rng(D)
+    q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
+    mu, sigma = r.normal(size=D), 0.5 + r.random(D)
+    outs = []
+    for resident in (1, 0):
+        eng.set_option("resident_nuts", resident)
+        tgt = targets.DiagGaussian(mu, sigma)
+        srng = RandomStream(seeds=list(range(C)))
+        kernel = nuts.new_kernel(srng, tgt, max_num_expansions=7)
+        state = nuts.new_state(dev(q0), tgt)
+        for _ in range(3):
+            info, upd = kernel(state, 0.25 / D ** 0.25, imm)
+            state = info.state._replace(momentum=None)
+        outs.append((info.state.position.cpu().numpy(), info.state.momentum.cpu().numpy(),
+                     info.state.potential_energy.cpu().numpy(), info.state.potential_energy_grad.cpu().numpy(),
+                     info.acceptance_probability.cpu().numpy(), info.n_leapfrog.cpu().numpy(),
+                     info.num_doublings.cpu().numpy(), info.is_turning.cpu().numpy(), upd[srng].cpu().numpy()))
+    eng.set_option("resident_nuts", 1)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("D,C", [(2, 70), (3, 33), (7, 50), (16, 9), (40, 19), (100, 13), (128, 5),
+                                 (700, 4), (2048, 3), (3000, 3), (10000, 2)])
+def test_nuts_resident_teams_match_oracle(eng, D, C):
+    """Sub-wavefront teams (D <= 128: 64/T chains per wave, divergent SIMT control flow) and
+    workgroup teams (D > 512: cross-wave reductions): summation order differs from the oracle
+    and from the lock-step path -> 1e-9 on values, exact discrete outputs and RNG use."""
+    from aehmc_amd import RandomStream, nuts, targets
+    eng.set_option("resident_min_team", 1)
+    r = np.random.default_rng(D + 1)
+    mu, sigma, imm = r.normal(size=D), 0.5 + r.random(D), 0.5 + r.random(D)
+    tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
+    metric, seeds = co.Metric(imm, D), [70 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    eps = 0.25 / D ** 0.25
+    srng = RandomStream(seeds=seeds)
+    kernel = nuts.new_kernel(srng, tgt, max_num_expansions=6)
+    state = nuts.new_state(dev(q0), tgt)
+    rng = co.site_states(seeds, 4)
+    q, U, g = co.new_state(otgt, q0.copy())
+    for _ in range(3):
+        info, updates = kernel(state, eps, imm)
+        res = co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=6)
+        check_state(info, q, U, g, res)
+        assert np.array_equal(updates[srng].cpu().numpy().view(np.uint64)[:, :, :2], rng[:, :, :2])
+        state = info.state._replace(momentum=None)
+    eng.set_option("resident_min_team", 0)
+
+
 def test_nuts_fused_equals_lockstep_bitwise(eng):
     """The single-launch NUTS kernel (one wavefront loops a chain's whole tree) and the
     one-launch-per-leapfrog lock-step path share their device functions: same bits."""

@@ -14,7 +14,7 @@ eng = get_engine()
 q0 = torch.as_tensor(np.random.default_rng(0).standard_normal((C, D)), device="cuda")
 imm = torch.ones(D, dtype=torch.float64, device="cuda")
 for fused in (1, 0):
-    eng.set_option("fused_nuts", fused)
+    eng.set_option("resident_nuts", fused)
     tgt = targets.IsoGaussian()
     kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt)
     state = nuts.new_state(q0, tgt)
@@ -24,5 +24,5 @@ for fused in (1, 0):
         info, _ = kernel(state, eps, imm); state = info.state._replace(momentum=None)
         nl += int(info.n_leapfrog.sum().item())
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"D={D} C={C} eps={eps:.4f} fused={fused}: {nl/dt:.3e} leapfrog/s  {dt/steps*1e3:.2f} ms/transition "
+    print(f"D={D} C={C} eps={eps:.4f} resident={fused}: {nl/dt:.3e} leapfrog/s  {dt/steps*1e3:.2f} ms/transition "
           f"{nl/steps/C:.1f} leapfrogs/chain  ~{88.0*D*nl/dt/1e9:.0f} GB/s at 88*D B/leapfrog")
