@@ -38,7 +38,7 @@ struct aehmc_ctx {
   hipEvent_t ev[NRING] = {};
   bool opt_fused_hmc = true;
   int opt_resident_min_team = 0;  // tests: always use the smallest team that holds the chain
-  bool opt_resident_nuts = true;  // register-resident single-launch NUTS (nuts_resident.cuh)
+  int opt_resident_nuts = 2;      // register-resident single-launch NUTS: 0 off, 1 on, 2 auto
   bool opt_fused_nuts = false;   // whole NUTS transition in one launch (diag metric, coordinate-wise target)
   bool opt_dense_linear = true;  // one metric GEMM per leapfrog (v carried by linearity)
   bool opt_compact = true;       // finished chains drop out of the GEMMs
@@ -210,7 +210,7 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
     return 0;
   }
   if (!strcmp(name, "resident_nuts")) {
-    ctx->opt_resident_nuts = value != 0;
+    ctx->opt_resident_nuts = (int)value;
     return 0;
   }
   if (!strcmp(name, "fused_nuts")) {
@@ -483,7 +483,13 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   a.eps = step_size; a.thr = divergence_threshold;
   a.rng = rng; a.nsites = 4;
   a.q = q; a.U = U; a.g = g; a.out = *out;
-  if (ctx->opt_resident_nuts && nuts_resident_supported(a.tkind, a.met_ndim, a.D)) {
+  // auto: the resident kernel has a fixed latency of one chain's whole tree (~1.3 ms), so it
+  // wins once the state no longer fits the lock-step kernels' on-chip reuse (D > 256) or
+  // there are enough chains to fill the GPU with sub-wavefront teams (measured crossovers,
+  // tools/nuts_diag_bench.py)
+  const bool want_resident = ctx->opt_resident_nuts == 1 ||
+                             (ctx->opt_resident_nuts == 2 && (a.D > 256 || C >= 16384));
+  if (want_resident && nuts_resident_supported(a.tkind, a.met_ndim, a.D)) {
     const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
     if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
     HIPCHK(launch_nuts_resident(a, st, ctx->opt_resident_min_team));

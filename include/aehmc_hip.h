@@ -105,10 +105,11 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
 /* engine options (name, default):
  *  "fused_hmc" 1    register-resident single-launch HMC when the metric is diagonal and the
  *                   target coordinate-wise; 0 forces the lock-step path
- *  "resident_nuts" 1 register-resident single-launch NUTS (a wavefront, or a 256/1024-thread
- *                   workgroup for large D, keeps the chain's moving state in VGPRs for the whole
- *                   tree) when the metric is diagonal/scalar, the target coordinate-wise and
- *                   D <= 10240; 0 falls back to the paths below
+ *  "resident_nuts" 2 register-resident single-launch NUTS (a team of 1..64 lanes, or a
+ *                   256/1024-thread workgroup for large D, keeps the chain's moving state in
+ *                   VGPRs for the whole tree) for diagonal/scalar metrics, coordinate-wise
+ *                   targets, D <= 10240.  2 = auto (used when D > 256 or C >= 16384, where it
+ *                   beats the lock-step path), 1 = always, 0 = never
  *  "resident_min_team" 0  1: always give a chain the smallest team of lanes that holds it
  *                   (64/T chains per wavefront) instead of widening teams while the GPU would
  *                   otherwise run fewer than ~4096 wavefronts
