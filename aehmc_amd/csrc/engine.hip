@@ -49,6 +49,13 @@ struct aehmc_ctx {
   double prof_ms = 0.0;
   int64_t prof_n = 0;
   unsigned long long *d_flops = nullptr;  // algorithmic flops of the profiled launches
+  // stream-K GEMM: persistent grid, partial-accumulator hand-off buffers
+  bool opt_streamk = true;
+  int sk_grid = 0;
+  double *sk_partial = nullptr;
+  int *sk_flags = nullptr;
+  int sk_epoch = 0;
+  int *h_err = nullptr, *d_err = nullptr;  // pinned: a bounded spin expired
   double prof_flops = 0.0;
 };
 
@@ -90,6 +97,22 @@ extern "C" int aehmc_create(aehmc_ctx **out, int device) {
   HIPCHK(hipHostMalloc((void **)&ctx->h_active, NRING * sizeof(int), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void **)&ctx->d_active, ctx->h_active, 0));
   for (int i = 0; i < NRING; i++) HIPCHK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_nt_f64_streamk_kernel<true>, 256, 0));
+    if (per_cu > 2) per_cu = 2;
+    ctx->sk_grid = (prop.multiProcessorCount * per_cu / 8) * 8;  // all workgroups co-resident
+    if (ctx->sk_grid > 0) {
+      HIPCHK(hipMalloc((void **)&ctx->sk_partial, (size_t)ctx->sk_grid * 64 * 256 * sizeof(double)));
+      HIPCHK(hipMalloc((void **)&ctx->sk_flags, ctx->sk_grid * sizeof(int)));
+      HIPCHK(hipMemset(ctx->sk_flags, 0, ctx->sk_grid * sizeof(int)));
+    }
+    HIPCHK(hipHostMalloc((void **)&ctx->h_err, sizeof(int), hipHostMallocMapped));
+    *ctx->h_err = 0;
+    HIPCHK(hipHostGetDevicePointer((void **)&ctx->d_err, ctx->h_err, 0));
+  }
   HIPCHK(hipMalloc((void **)&ctx->d_flops, sizeof(unsigned long long)));
   HIPCHK(hipMemset(ctx->d_flops, 0, sizeof(unsigned long long)));
   return 0;
@@ -101,6 +124,9 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (ctx->log_sigma) hipFree(ctx->log_sigma);
   if (ctx->h_active) hipHostFree(ctx->h_active);
   if (ctx->d_flops) hipFree(ctx->d_flops);
+  if (ctx->sk_partial) hipFree(ctx->sk_partial);
+  if (ctx->sk_flags) hipFree(ctx->sk_flags);
+  if (ctx->h_err) hipHostFree(ctx->h_err);
   for (int i = 0; i < NRING; i++)
     if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->prof_ev) hipEventDestroy(e);
@@ -221,6 +247,10 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
     ctx->opt_dense_linear = value != 0;
     return 0;
   }
+  if (!strcmp(name, "streamk")) {
+    ctx->opt_streamk = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "compact")) {
     ctx->opt_compact = value != 0;
     return 0;
@@ -304,8 +334,11 @@ static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A
                 const int *row_idx = nullptr, const int *n_rows = nullptr) {
   const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
   if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+  if (*ctx->h_err) FAIL("stream-K GEMM: a workgroup hand-off timed out (results invalid)");
+  GemmStreamK sk{ctx->sk_partial, ctx->sk_flags, ctx->d_err, ++ctx->sk_epoch};
+  const bool use_sk = ctx->opt_streamk && ctx->sk_grid > 0;
   HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st, row_idx, n_rows,
-                            p ? ctx->d_flops : nullptr));
+                            p ? ctx->d_flops : nullptr, use_sk ? &sk : nullptr, ctx->sk_grid));
   if (p) {
     HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
     ctx->prof_used += 2;

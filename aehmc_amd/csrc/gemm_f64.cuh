@@ -175,17 +175,216 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
     }
 }
 
+// ---- stream-K variant -------------------------------------------------------------
+// A persistent grid of G = 2 x #CU workgroups splits the (tile, k) iteration space evenly,
+// so a launch whose tile count is not a multiple of G (e.g. 2900 live chains: 1817 tiles =
+// 3.55 rounds of 512) no longer pays for a partly empty last round.  A tile cut between
+// two neighbouring workgroups is summed IN ORDER: the workgroup that owns the head of the
+// tile (k = 0 .. ke) computes it first and publishes its accumulators; the owner of the tail
+// loads them as its initial accumulator and continues the same k-chain -- bitwise the same
+// result as the unsplit kernel, no atomics.  Hand-off: plain stores -> s_waitcnt vmcnt(0)
+// -> barrier -> agent-scope release -> flag; consumer: relaxed poll -> agent-scope acquire
+// -> barrier -> plain loads (cdna_hip_programming.md, Guideline 16).  Every spin is bounded.
+// When fewer than G tiles exist (W < nk) the grid simply strides over whole tiles.
+struct GemmStreamK {
+  double *partial;  // [G][64][256] accumulators of head segments
+  int *flags;       // [G] epoch of the last publish
+  int *err;         // set to 1 if a bounded spin expired (host-visible)
+  int epoch;
+};
+
+__device__ __forceinline__ void gemm_tile_coords(int t, int Tm, int Tn, int &tm, int &tn) {
+  const int per_panel = Tm * GEMM_PANEL_W;
+  const int nfull = Tn / GEMM_PANEL_W;
+  const int panel = t / per_panel;
+  if (panel < nfull) {
+    const int rr = t - panel * per_panel;
+    tn = panel * GEMM_PANEL_W + rr % GEMM_PANEL_W;
+    tm = rr / GEMM_PANEL_W;
+  } else {
+    int wlast = Tn - nfull * GEMM_PANEL_W;
+    if (wlast < 1) wlast = 1;
+    const int rr = t - nfull * per_panel;
+    tn = nfull * GEMM_PANEL_W + rr % wlast;
+    tm = rr / wlast;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_streamk_kernel(
+    int64_t M, int64_t N, int64_t K, const double *__restrict__ A, int64_t lda,
+    const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc,
+    const int *__restrict__ row_idx, const int *__restrict__ n_rows,
+    unsigned long long *__restrict__ flop_counter, GemmStreamK sk) {
+  __shared__ __attribute__((aligned(16))) double lds[2][2][GEMM_BM][GEMM_LDS];
+  __shared__ int s_rows[GEMM_BM];
+  if (n_rows) M = *n_rows;
+  if (flop_counter && blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(flop_counter, (unsigned long long)(2 * M * N * K));
+  const int G = gridDim.x;                                     // multiple of 8
+  const int bb = (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;  // an XCD owns a contiguous tile range
+  const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+  const long long T = (long long)Tm * Tn;
+  if (T == 0) return;
+  const int nk = (int)((K + GEMM_BK - 1) / GEMM_BK);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int srow = tid >> 1, scol = (tid & 1) * 8;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  // one pass over tile t, K-tiles [kb, ke): mode 0 = full tile -> C; 1 = head -> publish
+  // partial; 2 = tail: continue from the neighbour's partial -> C
+  auto pass = [&](int t, int kb, int ke, int mode) {
+    int tm, tn;
+    gemm_tile_coords(t, Tm, Tn, tm, tn);
+    const int64_t m0 = (int64_t)tm * GEMM_BM, n0 = (int64_t)tn * GEMM_BN;
+    __syncthreads();  // previous pass is done with s_rows / LDS
+    if (tid < GEMM_BM) {
+      const int64_t r = m0 + tid;
+      s_rows[tid] = r < M ? (row_idx ? row_idx[r] : (int)r) : -1;
+    }
+    __syncthreads();
+    const int64_t a_row = s_rows[tid >> 1];
+    const int64_t b_row = (n0 + (tid >> 1)) < N ? n0 + (tid >> 1) : -1;
+    d4_t acc[4][4];
+    if (mode == 2) {
+      if (tid == 0) {
+        const long long t0 = clock64();
+        while (__hip_atomic_load(&sk.flags[bb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+          __builtin_amdgcn_s_sleep(16);
+          if (clock64() - t0 > 4000000000LL) {  // ~2 s: never hang the GPU
+            *sk.err = 1;
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      const double *src = sk.partial + (size_t)(bb - 1) * (64 * 256);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[i][j][r] = src[((i * 4 + j) * 4 + r) * 256 + tid];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    double ra[8], rb[8];
+    gemm_load_tile<VEC>(A, lda, a_row, (int64_t)kb * GEMM_BK, K, tid, ra);
+    gemm_load_tile<VEC>(B, ldb, b_row, (int64_t)kb * GEMM_BK, K, tid, rb);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      *reinterpret_cast<d2_t *>(&lds[0][0][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
+      *reinterpret_cast<d2_t *>(&lds[0][1][srow][scol + 2 * i]) = (d2_t){rb[2 * i], rb[2 * i + 1]};
+    }
+    __syncthreads();
+    for (int kt = kb; kt < ke; kt++) {
+      const int st = (kt - kb) & 1;
+      if (kt + 1 < ke) {
+        gemm_load_tile<VEC>(A, lda, a_row, (int64_t)(kt + 1) * GEMM_BK, K, tid, ra);
+        gemm_load_tile<VEC>(B, ldb, b_row, (int64_t)(kt + 1) * GEMM_BK, K, tid, rb);
+      }
+#pragma unroll
+      for (int kk = 0; kk < GEMM_BK / 4; kk++) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) a[i] = lds[st][0][wm * 64 + i * 16 + fr][kk * 4 + fk];
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = lds[st][1][wn * 64 + j * 16 + fr][kk * 4 + fk];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < ke) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          *reinterpret_cast<d2_t *>(&lds[st ^ 1][0][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
+          *reinterpret_cast<d2_t *>(&lds[st ^ 1][1][srow][scol + 2 * i]) = (d2_t){rb[2 * i], rb[2 * i + 1]};
+        }
+      }
+      __syncthreads();
+    }
+    if (mode == 1) {
+      double *dst = sk.partial + (size_t)bb * (64 * 256);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) dst[((i * 4 + j) * 4 + r) * 256 + tid] = acc[i][j][r];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&sk.flags[bb], sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int64_t col = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int64_t row = s_rows[wm * 64 + i * 16 + fk + 4 * r];
+            if (row >= 0 && col < N) Cm[row * ldc + col] = acc[i][j][r];
+          }
+        }
+    }
+  };
+
+  const long long total = T * nk;
+  const long long W = (total + G - 1) / G;
+  // Whole tiles, strided over the grid (the one-tile-per-workgroup order, which keeps the
+  // workgroups of an XCD on one column panel at a time) when there are fewer tiles than
+  // workgroups or when the last round is nearly full anyway; contiguous (tile, k) ranges cost
+  // L2 locality (measured: -11 % at 4.94 rounds) and only pay when a round would be wasted.
+  const long long rounds = (T + G - 1) / G;
+  if (W < nk || (rounds * G - T) * 100 < 15 * (long long)G) {
+    for (long long t = blockIdx.x; t < T; t += G) {
+      // same tile -> XCD assignment as gemm_tile_of_block within each round
+      const long long base = (t / G) * G, left = (T - base < G) ? T - base : G;
+      const long long chunk = (left + 7) / 8, slot = (t - base) / 8, x = (t - base) % 8;
+      if (slot < chunk && x * chunk + slot < left) pass((int)(base + x * chunk + slot), 0, nk, 0);
+    }
+    return;
+  }
+  const long long it0 = (long long)bb * W, it1 = (it0 + W < total) ? it0 + W : total;
+  if (it0 >= it1) return;
+  const int tf = (int)(it0 / nk), ks = (int)(it0 % nk);
+  const int tl = (int)((it1 - 1) / nk), ke = (int)((it1 - 1) % nk) + 1;
+  const bool has_tail = ks > 0;             // tile tf: [ks, nk) continues workgroup bb-1's head
+  const bool has_head = ke < nk;            // tile tl: [0, ke) is continued by workgroup bb+1
+  if (has_head) pass(tl, 0, ke, 1);         // first: the neighbour waits for it last
+  for (int t = has_tail ? tf + 1 : tf; t <= (has_head ? tl - 1 : tl); t++) pass(t, 0, nk, 0);
+  if (has_tail) pass(tf, ks, nk, 2);
+}
+
 inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const double *A,
                                      int64_t lda, const double *B, int64_t ldb, double *Cm,
                                      int64_t ldc, hipStream_t stream,
                                      const int *row_idx = nullptr, const int *n_rows = nullptr,
-                                     unsigned long long *flop_counter = nullptr) {
+                                     unsigned long long *flop_counter = nullptr,
+                                     const GemmStreamK *sk = nullptr, int sk_grid = 0) {
   if (M <= 0 || N <= 0) return hipSuccess;
   const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
   const int total = Tm * Tn;
   const int grid = ((total + 7) / 8) * 8;
   const bool vec = (lda % 2 == 0) && (ldb % 2 == 0) && ((uintptr_t)A % 16 == 0) &&
                    ((uintptr_t)B % 16 == 0);
+  if (vec && sk && sk_grid > 0 && total >= sk_grid) {  // enough tiles for an even (tile, k) split
+    hipLaunchKernelGGL(gemm_nt_f64_streamk_kernel<true>, dim3(sk_grid), dim3(256), 0, stream, M, N, K,
+                       A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter, *sk);
+    return hipGetLastError();
+  }
   if (vec)
     hipLaunchKernelGGL(gemm_nt_f64_kernel<true>, dim3(grid), dim3(256), 0, stream, M, N, K, A,
                        lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);

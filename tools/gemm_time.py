@@ -1,17 +1,21 @@
+#!/usr/bin/env python3
+"""Timing of the fp64 MFMA GEMM at the c3 shape for several live-row counts, stream-K on/off
+(interleaved in one process).  usage: python tools/gemm_time.py [M ...]"""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aehmc_amd.engine import get_engine
 eng = get_engine()
 N = K = 10000
 B = torch.randn(N, K, dtype=torch.float64, device="cuda")
-for M in (4096, 2900):
+for M in [int(x) for x in sys.argv[1:]] or [4096, 2900, 2048, 1024, 512]:
     A = torch.randn(M, K, dtype=torch.float64, device="cuda")
-    eng.gemm_nt(A, B); torch.cuda.synchronize()
-    best = 1e9
-    for r in range(3):
+    for sk in (1, 0, 1, 0):
+        eng.set_option("streamk", sk)
+        eng.gemm_nt(A, B); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5): eng.gemm_nt(A, B)
         e1.record(); torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / 5)
-    print(f"{os.environ.get('TAG','')} M={M}: {best:.3f} ms {2.0*M*N*K/best/1e9:.1f} TF")
+        ms = e0.elapsed_time(e1) / 5
+        print(f"M={M} streamk={sk}: {ms:.3f} ms {2.0*M*N*K/ms/1e9:.1f} TFLOP/s")
+eng.set_option("streamk", 1)
