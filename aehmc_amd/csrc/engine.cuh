@@ -973,6 +973,81 @@ __global__ __launch_bounds__(256) void k_add_i64(long long *acc, const long long
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i < n; i += (long long)gridDim.x * blockDim.x) acc[i] += x[i];
 }
+// ---- gaussian_metric set-up (metrics.py:44-59): sqrt(1/imm), or L^-T with imm = L L^T ----
+__global__ void k_sqrt_recip(const double *x, double *y, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = sqrt(1.0 / x[i]);
+}
+constexpr int FACT_NB = 64;
+// One workgroup: (optionally) Cholesky-factor the n x n (n <= 64) diagonal block in place
+// (lower), then invert the lower-triangular factor; writes inv and inv^T, zero padded to
+// [64][64].  info: first non-positive pivot (1-based, global index) if any.
+__global__ __launch_bounds__(256) void k_potrf_trtri(double *A, long long ld, int n, int do_factor,
+                                                     double *inv, double *invT, int *info, int pivot_base) {
+  __shared__ double L[FACT_NB][FACT_NB + 1], X[FACT_NB][FACT_NB + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
+    const int i = e / FACT_NB, j = e % FACT_NB;
+    L[i][j] = (i < n && j <= i) ? A[(long long)i * ld + j] : 0.0;
+    X[i][j] = 0.0;
+  }
+  __syncthreads();
+  if (do_factor) {
+    for (int j = 0; j < n; j++) {
+      if (tid == 0) {
+        const double d = L[j][j];
+        if (!(d > 0.0) && *info == 0) *info = pivot_base + j + 1;
+        L[j][j] = sqrt(d);
+      }
+      __syncthreads();
+      const double djj = L[j][j];
+      for (int i = j + 1 + tid; i < n; i += 256) L[i][j] = L[i][j] / djj;
+      __syncthreads();
+      for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
+        const int i = e / FACT_NB, k = e % FACT_NB;
+        if (k > j && k <= i && i < n) L[i][k] = L[i][k] - L[i][j] * L[k][j];
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
+      const int i = e / FACT_NB, j = e % FACT_NB;
+      if (i < n && j <= i) A[(long long)i * ld + j] = L[i][j];
+    }
+  }
+  if (tid < n) {  // column tid of L^-1 by forward substitution
+    const int t = tid;
+    for (int i = t; i < n; i++) {
+      double s = (i == t) ? 1.0 : 0.0;
+      for (int j = t; j < i; j++) s -= L[i][j] * X[j][t];
+      X[i][t] = s / L[i][i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < FACT_NB * FACT_NB; e += 256) {
+    const int i = e / FACT_NB, j = e % FACT_NB;
+    inv[e] = X[i][j];
+    invT[e] = X[j][i];
+  }
+}
+__global__ void k_copy_block(const double *src, long long lds_, double *dst, long long ldd, int rows, int cols) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows * cols; e += gridDim.x * blockDim.x) {
+    const int i = e / cols, j = e % cols;
+    dst[(long long)i * ldd + j] = src[(long long)i * lds_ + j];
+  }
+}
+__global__ void k_transpose(const double *src, double *dst, long long n) {  // dst = src^T, n x n
+  __shared__ double tile[32][33];
+  const long long bx = (long long)blockIdx.x * 32, by = (long long)blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const long long i = by + r, j = bx + threadIdx.x;
+    tile[r][threadIdx.x] = (i < n && j < n) ? src[i * n + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const long long i = bx + r, j = by + threadIdx.x;
+    if (i < n && j < n) dst[i * n + j] = tile[threadIdx.x][r];
+  }
+}
 __global__ void k_log(const double *x, double *y, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = log(x[i]);

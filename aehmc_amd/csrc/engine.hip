@@ -30,6 +30,8 @@ struct aehmc_ctx {
   aehmc_metric met{};
   bool has_met = false;
   double *log_sigma = nullptr;
+  double *own_sqrt_mass = nullptr;  // computed by aehmc_set_metric when the caller passes none
+  int64_t own_sqrt_mass_n = 0;
   const double *eps_c = nullptr;  // per-chain step sizes (aehmc_set_step_sizes)
   void *ws = nullptr;
   int64_t ws_bytes = 0;
@@ -122,6 +124,7 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (!ctx) return 0;
   hipSetDevice(ctx->device);
   if (ctx->log_sigma) hipFree(ctx->log_sigma);
+  if (ctx->own_sqrt_mass) hipFree(ctx->own_sqrt_mass);
   if (ctx->h_active) hipHostFree(ctx->h_active);
   if (ctx->d_flops) hipFree(ctx->d_flops);
   if (ctx->sk_partial) hipFree(ctx->sk_partial);
@@ -172,13 +175,105 @@ extern "C" int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *t) {
   return 0;
 }
 
+static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
+                const double *B, int64_t ldb, double *Cm, int64_t ldc, hipStream_t st,
+                const int *row_idx = nullptr, const int *n_rows = nullptr, int mode = 0);
+
+// metrics.py:56-58: L = cholesky(imm); mass_matrix_sqrt = solve_triangular(L, I, lower, trans)
+// = L^-T.  Blocked (64-wide) right-looking Cholesky and blocked triangular inverse; the
+// O(D^3) work is in the fp64 MFMA GEMM.  `out` [D,D] receives L^-T.
+static int dense_sqrt_mass(aehmc_ctx *ctx, const double *imm, int64_t D, double *out) {
+  const int NB = FACT_NB;
+  double *Lw = nullptr, *Li = nullptr, *small = nullptr, *Tt = nullptr;
+  int *info = nullptr;
+  HIPCHK(hipMalloc((void **)&Lw, (size_t)D * D * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&Li, (size_t)D * D * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&small, (size_t)2 * NB * NB * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&Tt, (size_t)NB * D * sizeof(double)));
+  HIPCHK(hipMalloc((void **)&info, sizeof(int)));
+  double *inv = small, *invT = small + NB * NB;
+  hipStream_t st = 0;
+  int rc = 0, h_info = 0;
+  auto done = [&](int r) {
+    hipFree(Lw); hipFree(Li); hipFree(small); hipFree(Tt); hipFree(info);
+    return r;
+  };
+  if (hipMemcpyAsync(Lw, imm, (size_t)D * D * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemsetAsync(Li, 0, (size_t)D * D * sizeof(double), st) != hipSuccess ||
+      hipMemsetAsync(info, 0, sizeof(int), st) != hipSuccess) {
+    ctx->err = "dense metric: device copy failed";
+    return done(-1);
+  }
+  for (int64_t j0 = 0; j0 < D && !rc; j0 += NB) {  // Cholesky
+    const int nb = (int)((D - j0 < NB) ? D - j0 : NB);
+    const int64_t M = D - j0 - nb;
+    hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(256), 0, st, Lw + j0 * D + j0, (long long)D, nb, 1, inv,
+                       invT, info, (int)j0);
+    if (M > 0) {
+      double *panel = Lw + (j0 + nb) * D + j0;
+      rc = gemm(ctx, M, nb, nb, panel, D, inv, NB, panel, D, st);                     // L21 = A21 L11^-T
+      if (!rc) rc = gemm(ctx, M, M, nb, panel, D, panel, D, Lw + (j0 + nb) * D + (j0 + nb), D, st, nullptr,
+                         nullptr, 1);                                                   // A22 -= L21 L21^T
+    }
+  }
+  const int64_t nblk = (D + NB - 1) / NB;
+  for (int64_t kb = nblk - 1; kb >= 0 && !rc; kb--) {  // L^-1, block column by block column
+    const int64_t j0 = kb * NB;
+    const int nb = (int)((D - j0 < NB) ? D - j0 : NB);
+    const int64_t M = D - j0 - nb;
+    hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(256), 0, st, Lw + j0 * D + j0, (long long)D, nb, 0, inv,
+                       invT, info, (int)j0);
+    hipLaunchKernelGGL(k_copy_block, dim3(16), dim3(256), 0, st, (const double *)inv, (long long)NB,
+                       Li + j0 * D + j0, (long long)D, nb, nb);
+    if (M > 0) {
+      // T^T = L11^-T L21^T  ([nb, M]);  L^-1[>k, k] = - L^-1[>k, >k] T
+      rc = gemm(ctx, nb, M, nb, invT, NB, Lw + (j0 + nb) * D + j0, D, Tt, M, st);
+      if (!rc) rc = gemm(ctx, M, nb, M, Li + (j0 + nb) * D + (j0 + nb), D, Tt, M, Li + (j0 + nb) * D + j0, D, st,
+                         nullptr, nullptr, 2);
+    }
+  }
+  if (!rc) {
+    dim3 grid((unsigned)((D + 31) / 32), (unsigned)((D + 31) / 32)), block(32, 8);
+    hipLaunchKernelGGL(k_transpose, grid, block, 0, st, (const double *)Li, out, (long long)D);
+    if (hipMemcpy(&h_info, info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess) {
+      ctx->err = "dense metric: factorisation kernels failed";
+      rc = -1;
+    } else if (h_info) {
+      ctx->err = "dense inverse mass matrix is not positive definite (pivot " + std::to_string(h_info) + ")";
+      rc = -2;
+    }
+  }
+  return done(rc);
+}
+
 extern "C" int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *m) {
   if (!ctx || !m) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
   if (m->ndim < 0 || m->ndim > 2)  // metrics.py:60-63
     FAIL("Expected a mass matrix of dimension 1 (diagonal) or 2, got " + std::to_string(m->ndim));
-  if (!m->imm || !m->sqrt_mass || m->D <= 0) FAIL("metric needs imm, sqrt_mass and D");
+  if (!m->imm || m->D <= 0) FAIL("metric needs imm and D");
   if (m->per_chain && m->ndim == 2) FAIL("per-chain dense mass matrices are not supported");
-  ctx->met = *m;
+  if (m->per_chain && !m->sqrt_mass) FAIL("per-chain metrics need sqrt_mass");
+  aehmc_metric met = *m;
+  if (!met.sqrt_mass) {  // metrics.py:45,49,56-58 computed here
+    const int64_t n = m->ndim == 0 ? 1 : (m->ndim == 1 ? m->D : m->D * m->D);
+    if (ctx->own_sqrt_mass_n < n) {
+      if (ctx->own_sqrt_mass) HIPCHK(hipFree(ctx->own_sqrt_mass));
+      ctx->own_sqrt_mass = nullptr;
+      HIPCHK(hipMalloc((void **)&ctx->own_sqrt_mass, n * sizeof(double)));
+      ctx->own_sqrt_mass_n = n;
+    }
+    if (m->ndim < 2) {
+      hipLaunchKernelGGL(k_sqrt_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, m->imm,
+                         ctx->own_sqrt_mass, (long long)n);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipDeviceSynchronize());
+    } else if (int rc = dense_sqrt_mass(ctx, m->imm, m->D, ctx->own_sqrt_mass)) {
+      return rc;
+    }
+    met.sqrt_mass = ctx->own_sqrt_mass;
+  }
+  ctx->met = met;
   ctx->has_met = true;
   return 0;
 }
@@ -331,14 +426,15 @@ static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a) {
 // ------------------------------------------------------------------ GEMM + profiling
 static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
                 const double *B, int64_t ldb, double *Cm, int64_t ldc, hipStream_t st,
-                const int *row_idx = nullptr, const int *n_rows = nullptr) {
+                const int *row_idx, const int *n_rows, int mode) {
   const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
   if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
   if (*ctx->h_err) FAIL("stream-K GEMM: a workgroup hand-off timed out (results invalid)");
   GemmStreamK sk{ctx->sk_partial, ctx->sk_flags, ctx->d_err, ++ctx->sk_epoch};
   const bool use_sk = ctx->opt_streamk && ctx->sk_grid > 0;
   HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st, row_idx, n_rows,
-                            p ? ctx->d_flops : nullptr, use_sk ? &sk : nullptr, ctx->sk_grid));
+                            p ? ctx->d_flops : nullptr, (use_sk && mode == 0) ? &sk : nullptr, ctx->sk_grid,
+                            mode));
   if (p) {
     HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
     ctx->prof_used += 2;

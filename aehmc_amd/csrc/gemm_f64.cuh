@@ -26,7 +26,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16, GEMM_LDS = GEMM_BK + 2;
-constexpr int GEMM_PANEL_W = 2;
+constexpr int GEMM_PANEL_W = 8;  // 64 concurrent tiles of an XCD = 8 x 8 super-tile
 
 struct GemmTileMap {
   int tm, tn;
@@ -85,7 +85,9 @@ __device__ __forceinline__ void gemm_load_tile(const double *__restrict__ P, int
 // row_idx / n_rows (both optional): compacted-row mode for the lock-step engine -- tile
 // row r reads A row row_idx[r] and writes C row row_idx[r], and only *n_rows rows exist
 // (chains whose transition has finished drop out of the product).
-template <bool VEC>
+// MODE 0: C = A B^T;  1: C = C - A B^T;  2: C = -A B^T  (1, 2: the blocked Cholesky /
+// triangular inverse of aehmc_set_metric)
+template <bool VEC, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
     int64_t M, int64_t N, int64_t K, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc,
@@ -114,7 +116,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < 4; j++) {
+      acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+      if (MODE == 1) {
+        const int64_t col = n0 + (wave & 1) * 64 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int64_t row = s_rows[(wave >> 1) * 64 + i * 16 + (lane >> 4) + 4 * r];
+          if (row >= 0 && col < N) acc[i][j][r] = Cm[row * ldc + col];
+        }
+      }
+    }
 
   double ra[8], rb[8];
   const int nk = (int)((K + GEMM_BK - 1) / GEMM_BK);
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
     for (int kk = 0; kk < GEMM_BK / 4; kk++) {
       double a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = lds[st][0][wm * 64 + i * 16 + fr][kk * 4 + fk];
+      for (int i = 0; i < 4; i++) a[i] = (MODE ? -1.0 : 1.0) * lds[st][0][wm * 64 + i * 16 + fr][kk * 4 + fk];
 #pragma unroll
       for (int j = 0; j < 4; j++) b[j] = lds[st][1][wn * 64 + j * 16 + fr][kk * 4 + fk];
 #pragma unroll
@@ -373,13 +385,23 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
                                      int64_t ldc, hipStream_t stream,
                                      const int *row_idx = nullptr, const int *n_rows = nullptr,
                                      unsigned long long *flop_counter = nullptr,
-                                     const GemmStreamK *sk = nullptr, int sk_grid = 0) {
+                                     const GemmStreamK *sk = nullptr, int sk_grid = 0, int mode = 0) {
   if (M <= 0 || N <= 0) return hipSuccess;
   const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
   const int total = Tm * Tn;
   const int grid = ((total + 7) / 8) * 8;
   const bool vec = (lda % 2 == 0) && (ldb % 2 == 0) && ((uintptr_t)A % 16 == 0) &&
                    ((uintptr_t)B % 16 == 0);
+  if (mode == 1) {
+    hipLaunchKernelGGL((gemm_nt_f64_kernel<false, 1>), dim3(grid), dim3(256), 0, stream, M, N, K, A, lda,
+                       B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);
+    return hipGetLastError();
+  }
+  if (mode == 2) {
+    hipLaunchKernelGGL((gemm_nt_f64_kernel<false, 2>), dim3(grid), dim3(256), 0, stream, M, N, K, A, lda,
+                       B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);
+    return hipGetLastError();
+  }
   if (vec && sk && sk_grid > 0 && total >= sk_grid) {  // enough tiles for an even (tile, k) split
     hipLaunchKernelGGL(gemm_nt_f64_streamk_kernel<true>, dim3(sk_grid), dim3(256), 0, stream, M, N, K,
                        A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter, *sk);

@@ -113,24 +113,13 @@ class Engine:
                 raise ValueError(f"dense inverse mass matrix must be [{D},{D}], got {tuple(t.shape)}")
             if not torch.allclose(t, t.T, rtol=1e-12, atol=0):
                 raise ValueError("dense inverse mass matrix must be symmetric")
-            L = torch.linalg.cholesky(t)  # metrics.py:56
-            LT = L.T.contiguous()
-            del L
-            # metrics.py:58 solve_triangular(L, I, lower=True, trans=True) = L^-T, by column
-            # blocks (one 1e4 x 1e4 trsm exhausts hipBLAS' workspace)
-            sqrt_mass = torch.empty(D, D, dtype=torch.float64, device=self.device)
-            for j in range(0, D, 1024):
-                w = min(1024, D - j)
-                rhs = torch.zeros(D, w, dtype=torch.float64, device=self.device)
-                rhs[j:j + w] = torch.eye(w, dtype=torch.float64, device=self.device)
-                sqrt_mass[:, j:j + w] = torch.linalg.solve_triangular(LT, rhs, upper=True)
-            del LT
         else:
             t = t.reshape(-1)
             if ndim == 1 and t.numel() != D:
                 raise ValueError(f"diagonal inverse mass matrix must have {D} entries")
-            sqrt_mass = torch.sqrt(torch.reciprocal(t))  # metrics.py:45,49
-        c = _lib.CMetric(ndim=ndim, D=D, imm=t.data_ptr(), sqrt_mass=sqrt_mass.data_ptr())
+        # sqrt_mass = NULL: the library forms sqrt(1/imm) / L^-T itself (metrics.py:45,49,56-58)
+        c = _lib.CMetric(ndim=ndim, D=D, imm=t.data_ptr(), sqrt_mass=None)
+        sqrt_mass = None
         self._keep["metric"] = (imm, t, sqrt_mass)
         self._check(self.lib.aehmc_set_metric(self.ctx, ct.byref(c)), "aehmc_set_metric")
         if self.metric_ndim != ndim:

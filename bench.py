@@ -151,7 +151,7 @@ def main():
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": (2.0 * flops / (2.0 * D * D) * D + D * D) * 8,
-                    "kernel": "gemm_nt_f64_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
+                    "kernel": "gemm_nt_f64_streamk_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
                     "avg_rows_per_launch": flops / (2.0 * D * D), "gemm_share_of_step_time": kern_ms / 1e3 / elapsed}
     else:
         # fused HMC kernel: algorithmic bytes = SURVEY.md 8d streaming figure 48*D B per leapfrog per chain

@@ -69,7 +69,9 @@ typedef struct {
                               chain -- what per-chain window adaptation produces; 0: shared */
   int64_t D;
   const double *imm;       /* [1] | [D] | [D,D] */
-  const double *sqrt_mass; /* [1] | [D] | [D,D] */
+  const double *sqrt_mass; /* [1] | [D] | [D,D], or NULL: aehmc_set_metric computes it on the
+                              device (dense: blocked Cholesky + triangular inverse on the fp64
+                              MFMA GEMM) into ctx-owned memory */
 } aehmc_metric;
 
 /* warm-up state of window_adaptation.run (window_adaptation.py:17-116), one row per chain:

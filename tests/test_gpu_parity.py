@@ -189,7 +189,8 @@ def check_state(info, q, U, g, res, nuts=True):
 
 
 CASES = [("scalar", "std", 1), ("diag", "std", 3), ("diag", "diag", 70), ("diag", "iso", 200),
-         ("dense", "diag", 33), ("diag", "dense", 33), ("dense", "dense", 150)]
+         ("dense", "diag", 33), ("diag", "dense", 33), ("dense", "dense", 150), ("dense", "dense", 64),
+         ("dense", "diag", 65), ("dense", "dense", 700)]
 
 
 @pytest.mark.parametrize("kind,tkind,D", CASES)
@@ -269,6 +270,19 @@ def test_dense_options_match_oracle(eng, linear, compact):
     finally:
         eng.set_option("dense_linear", 1)
         eng.set_option("compact", 1)
+
+
+def test_dense_metric_not_positive_definite_is_an_error():
+    """aehmc_set_metric factors the dense inverse mass matrix itself (blocked Cholesky on the
+    fp64 GEMM); a non-PD matrix is reported, not silently used."""
+    from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.engine import EngineError
+    tgt = targets.StdNormal()
+    state = nuts.new_state(dev(np.zeros((2, 3))), tgt)
+    kernel = nuts.new_kernel(RandomStream(seeds=[0, 1]), tgt)
+    bad = np.array([[1.0, 2.0, 0.0], [2.0, 1.0, 0.0], [0.0, 0.0, 1.0]])  # symmetric, indefinite
+    with pytest.raises(EngineError, match="positive definite"):
+        kernel(state, 0.1, bad)
 
 
 def test_hmc_fused_equals_lockstep_bitwise(eng):
