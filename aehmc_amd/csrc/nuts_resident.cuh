@@ -72,15 +72,22 @@ __device__ __forceinline__ void team_sum2(double &x, double &y, double (*red)[2 
       sx += buf[2 * w];
       sy += buf[2 * w + 1];
     }
-    x = sx;
-    y = sy;
+    // identical in every thread of the workgroup: tell the compiler (SGPRs, scalar branches)
+    x = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sx)),
+                         __builtin_amdgcn_readfirstlane(__double2loint(sx)));
+    y = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sy)),
+                         __builtin_amdgcn_readfirstlane(__double2loint(sy)));
   }
 }
 
-template <int T, int R>
+// QGL: q and dU/dq of the moving end live in LDS instead of VGPRs (one workgroup per CU
+// owns up to 160 KB: a whole D = 1e4 chain), p and the momentum sum stay in registers.
+template <int T, int R, bool QGL = false>
 __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
   using TM = Team<T>;
   __shared__ double red[2][2 * TM::NW];
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+  double *const sq = dyn_lds, *const sg = dyn_lds + (QGL ? a.D : 0);
   int flip = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -92,8 +99,19 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
   const size_t row = (size_t)c * a.D;
   const bool lead = t == 0;
 
-  double q[R], p[R], g[R], pb[R];  // moving end + sub-trajectory momentum sum
+  double q[QGL ? 1 : R], g[QGL ? 1 : R], p[R], pb[R];  // moving end + sub-trajectory momentum sum
   bool ok[R];
+// large R: keep the scheduler from interleaving all R unrolled iterations (their
+// temporaries would not fit the register file and spill)
+// element r of this thread in a [C,D] array: uniform row base (SGPRs) + 32-bit lane offset,
+// so one VGPR offset per r serves every array (64-bit per-array addresses would not fit)
+#define EI(r) ((unsigned)(t + T * (r)))
+#define AT(ptr, r) ((ptr) + row)[EI(r)]
+#define R_FENCE() do { if (R > 4) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define QGET(r) (QGL ? sq[t + T * (r)] : q[QGL ? 0 : (r)])
+#define GGET(r) (QGL ? sg[t + T * (r)] : g[QGL ? 0 : (r)])
+#define QSET(r, v) do { if (QGL) sq[t + T * (r)] = (v); else q[QGL ? 0 : (r)] = (v); } while (0)
+#define GSET(r, v) do { if (QGL) sg[t + T * (r)] = (v); else g[QGL ? 0 : (r)] = (v); } while (0)
   // imm is re-read from L1/L2 when many elements per thread would cost registers
   constexpr bool IM_REG = R <= 4;
   double imr[IM_REG ? R : 1];
@@ -104,8 +122,10 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
     const long long i = (long long)t + (long long)T * r;
     ok[r] = i < a.D;
     if (IM_REG) imr[r] = ok[r] ? a.imm[imo + (a.met_ndim == 0 ? 0 : i)] : 1.0;
-    q[r] = ok[r] ? a.q[row + i] : 0.0;
-    g[r] = ok[r] ? a.g[row + i] : 0.0;
+    if (ok[r] || !QGL) {
+      QSET(r, ok[r] ? AT(a.q, r) : 0.0);
+      GSET(r, ok[r] ? AT(a.g, r) : 0.0);
+    }
   }
 
   // ---- momentum, site #1 (nuts.py:113 -> metrics.py:65-68) ------------------------
@@ -143,20 +163,20 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const long long i = (long long)t + (long long)T * r;
-    if (!TM::SUB) p[r] = ok[r] ? a.zbuf[row + i] : 0.0;
+    if (!TM::SUB) p[r] = ok[r] ? AT(a.zbuf, r) : 0.0;
     pb[r] = 0.0;
     if (ok[r]) {
       kd += (IMM(r) * p[r]) * p[r];
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        a.end_q[e][row + i] = q[r];
-        a.end_p[e][row + i] = p[r];
-        a.end_g[e][row + i] = g[r];
+        AT(a.end_q[e], r) = QGET(r);
+        AT(a.end_p[e], r) = p[r];
+        AT(a.end_g[e], r) = GGET(r);
       }
-      a.slot_q[0][row + i] = q[r];
-      a.slot_p[0][row + i] = p[r];
-      a.slot_g[0][row + i] = g[r];
-      a.psum[row + i] = p[r];
+      AT(a.slot_q[0], r) = QGET(r);
+      AT(a.slot_p[0], r) = p[r];
+      AT(a.slot_g[0], r) = GGET(r);
+      AT(a.psum, r) = p[r];
     }
   }
   team_sum2<T>(kd, zero, red, flip);
@@ -191,17 +211,18 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
     for (int r = 0; r < R; r++) {
       if (ok[r]) {
         const long long i = (long long)t + (long long)T * r;
-        double pp = p[r] - b * g[r];
-        double qq = q[r] + aa * (IMM(r) * pp);
+        double pp = p[r] - b * GGET(r);
+        double qq = QGET(r) + aa * (IMM(r) * pp);
         double u, gg;
         target_elem(a, i, qq, u, gg);
         usum += u;
         pp = pp - b * gg;
-        q[r] = qq;
-        g[r] = gg;
+        QSET(r, qq);
+        GSET(r, gg);
         p[r] = pp;
         kd += (IMM(r) * pp) * pp;
       }
+      R_FENCE();
     }
     team_sum2<T>(usum, kd, red, flip);
     ct.U_cur = target_finish(a, usum);
@@ -228,10 +249,11 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
           const long long i = (long long)t + (long long)T * r;
           pb[r] = (step == 0) ? p[r] : pb[r] + p[r];
           if (even) {
-            ckp[i] = p[r];
-            cks[i] = pb[r];
+            ckp[EI(r)] = p[r];
+            cks[EI(r)] = pb[r];
           }
         }
+        R_FENCE();
       }
     }
     ct.tmin = tmin;
@@ -270,13 +292,14 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
           for (int r = 0; r < R; r++) {
             if (ok[r]) {
               const long long i = (long long)t + (long long)T * r;
-              double pl = kp[i], pr = p[r];
+              double pl = kp[EI(r)], pr = p[r];
               double vl = IMM(r) * pl, vr = IMM(r) * pr;
-              double sub = pb[r] - ks[i] + pl;
+              double sub = pb[r] - ks[EI(r)] + pl;
               double rho = sub - (pr + pl) / 2;
               d_l += vl * rho;
               d_r += vr * rho;
             }
+            R_FENCE();
           }
           team_sum2<T>(d_l, d_r, red, flip);
           crit = (d_l <= 0) | (d_r <= 0);
@@ -293,10 +316,11 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
       for (int r = 0; r < R; r++) {
         if (ok[r]) {
           const long long i = (long long)t + (long long)T * r;
-          pick2(a.slot_q, s)[row + i] = q[r];
-          pick2(a.slot_p, s)[row + i] = p[r];
-          pick2(a.slot_g, s)[row + i] = g[r];
+          AT(pick2(a.slot_q, s), r) = QGET(r);
+          AT(pick2(a.slot_p, s), r) = p[r];
+          AT(pick2(a.slot_g, s), r) = GGET(r);
         }
+        R_FENCE();
       }
       put2(ct.U_slot, s, ct.U_cur);
     }
@@ -323,19 +347,20 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
       for (int r = 0; r < R; r++) {
         if (ok[r]) {
           const long long i = (long long)t + (long long)T * r;
-          double pc = p[r], po = pick2(a.end_p, oth)[row + i];
+          double pc = p[r], po = AT(pick2(a.end_p, oth), r);
           double vc = IMM(r) * pc, vo = IMM(r) * po;
-          double s = a.psum[row + i] + pb[r];
-          a.psum[row + i] = s;
+          double s = AT(a.psum, r) + pb[r];
+          AT(a.psum, r) = s;
           double pl = dir ? po : pc, pr = dir ? pc : po;
           double vl = dir ? vo : vc, vr = dir ? vc : vo;
           double rho = s - (pr + pl) / 2;
           d_l += vl * rho;
           d_r += vr * rho;
-          pick2(a.end_q, dir)[row + i] = q[r];
-          pick2(a.end_p, dir)[row + i] = pc;
-          pick2(a.end_g, dir)[row + i] = g[r];
+          AT(pick2(a.end_q, dir), r) = QGET(r);
+          AT(pick2(a.end_p, dir), r) = pc;
+          AT(pick2(a.end_g, dir), r) = GGET(r);
         }
+        R_FENCE();
       }
       team_sum2<T>(d_l, d_r, red, flip);
       const bool turning = (d_l <= 0) | (d_r <= 0);
@@ -365,9 +390,9 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
         for (int r = 0; r < R; r++) {
           if (ok[r]) {
             const long long i = (long long)t + (long long)T * r;
-            a.q[row + i] = pick2(a.slot_q, s)[row + i];
-            a.g[row + i] = pick2(a.slot_g, s)[row + i];
-            if (a.out.momentum) a.out.momentum[row + i] = pick2(a.slot_p, s)[row + i];
+            AT(a.q, r) = AT(pick2(a.slot_q, s), r);
+            AT(a.g, r) = AT(pick2(a.slot_g, s), r);
+            if (a.out.momentum) AT(a.out.momentum, r) = AT(pick2(a.slot_p, s), r);
           }
         }
         if (lead) {
@@ -393,9 +418,9 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
           for (int r = 0; r < R; r++) {
             if (ok[r]) {
               const long long i = (long long)t + (long long)T * r;
-              q[r] = pick2(a.end_q, go_right)[row + i];
-              p[r] = pick2(a.end_p, go_right)[row + i];
-              g[r] = pick2(a.end_g, go_right)[row + i];
+              QSET(r, AT(pick2(a.end_q, go_right), r));
+              p[r] = AT(pick2(a.end_p, go_right), r);
+              GSET(r, AT(pick2(a.end_g, go_right), r));
             }
           }
           ct.U_cur = pick2(ct.U_end, go_right);
@@ -410,6 +435,13 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
     pcg_store(a.rng + ((size_t)c * a.nsites + 3) * 4, rng.g[3]);
   }
 #undef IMM
+#undef EI
+#undef AT
+#undef R_FENCE
+#undef QGET
+#undef GGET
+#undef QSET
+#undef GSET
 }
 
 inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
@@ -417,12 +449,18 @@ inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
          met_ndim < 2 && D <= 10240;
 }
 
-template <int T, int R>
+template <int T, int R, bool QGL = false>
 inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
   const unsigned grid = Team<T>::SUB    ? (unsigned)((a.C * T + 255) / 256)
                         : Team<T>::WAVE ? (unsigned)((a.C + 3) / 4)
                                         : (unsigned)a.C;
-  hipLaunchKernelGGL((k_nuts_resident<T, R>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a);
+  const size_t dyn = QGL ? (size_t)2 * a.D * sizeof(double) : 0;
+  if (QGL) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<T, R, QGL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((k_nuts_resident<T, R, QGL>), dim3(grid), dim3(Team<T>::BLOCK), dyn, st, a);
   return hipGetLastError();
 }
 // Team size: the smallest team that holds the chain (<= 4 elements per lane below a wave,
@@ -434,9 +472,9 @@ inline hipError_t launch_nuts_resident(const EngineArgs &a, hipStream_t st, int 
   if (D > 512) {
     if (D <= 1024) return launch_nuts_resident_tr<256, 4>(a, st);
     if (D <= 2048) return launch_nuts_resident_tr<256, 8>(a, st);
-    if (D <= 4096) return launch_nuts_resident_tr<1024, 4>(a, st);
-    if (D <= 8192) return launch_nuts_resident_tr<1024, 8>(a, st);
-    return launch_nuts_resident_tr<1024, 10>(a, st);
+    if (D <= 4096) return launch_nuts_resident_tr<512, 8, true>(a, st);
+    if (D <= 8192) return launch_nuts_resident_tr<512, 16, true>(a, st);
+    return launch_nuts_resident_tr<512, 20, true>(a, st);
   }
   const int tmin = D <= 4 ? 1 : D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64;
   int twant = 64;
