@@ -179,14 +179,14 @@ class Engine:
         return U, g
 
     def _diag(self, C, D, nuts):
+        # every array is fully written by the kernels: no memset launches
         dev = self.device
+        i64 = torch.empty(2, C, dtype=torch.int64, device=dev)
+        i32 = torch.empty(2, C, dtype=torch.int32, device=dev)
         out = dict(
             momentum=torch.empty(C, D, dtype=torch.float64, device=dev),
             acceptance_probability=torch.empty(C, dtype=torch.float64, device=dev),
-            num_doublings=torch.zeros(C, dtype=torch.int64, device=dev),
-            is_turning=torch.zeros(C, dtype=torch.int32, device=dev),
-            is_diverging=torch.zeros(C, dtype=torch.int32, device=dev),
-            n_leapfrog=torch.zeros(C, dtype=torch.int64, device=dev))
+            num_doublings=i64[0], is_turning=i32[0], is_diverging=i32[1], n_leapfrog=i64[1])
         c = _lib.CDiagnostics(**{k: v.data_ptr() for k, v in out.items()})
         return out, c
 
