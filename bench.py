@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -83,6 +83,10 @@ def main():
     from aehmc_amd.engine import get_engine
     from aehmc_amd.parallel import barrier, gather_samples, max_over_ranks, sum_over_ranks
 
+    if args.config == "c1":
+        return bench_c1(args)
+    if args.config == "c5":
+        return bench_c5(args, rank, world, device)
     C = args.chains
     eng = get_engine(device)
     seeds = [1000 + rank * C + c for c in range(C)]
@@ -178,6 +182,69 @@ def main():
         "config": {"workload": workload, "chains_total": C * world, "dim": D,
                    "leapfrogs_per_step": total_leap / args.steps},
         "roofline": roofline, "cpu_baseline": cpu}))
+
+
+def bench_c1(args):
+    """Config c1 (plumbing check): README example, one chain, NUTS, eps=1e-2 -- the reference
+    runtime (Aesara C backend) is unavailable; the value must equal README.md:53-54."""
+    from aehmc_amd import RandomStream, nuts, targets
+    target = targets.StdNormal()
+    times, pos, nl = [], None, 0
+    for _ in range(args.warmup + args.steps):
+        kernel = nuts.new_kernel(RandomStream(seed=0), target)
+        state = nuts.new_state(0.0, target)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info, _ = kernel(state, 1e-2, 1.0)
+        pos = info.state.position.item()
+        times.append(time.perf_counter() - t0)
+        nl = int(info.n_leapfrog.item())
+    dt = sum(times[args.warmup:]) / max(args.steps, 1)
+    print(json.dumps({
+        "metric": "leapfrog-steps/sec across all chains", "value": nl / dt, "unit": "leapfrog-steps/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "c1: README example, 1-D standard normal, NUTS, step_size=1e-2, single chain",
+                   "position": pos, "matches_readme_value": pos == 1.1034719409361107, "leapfrogs": nl},
+        "roofline": None, "cpu_baseline": None}))
+
+
+def bench_c5(args, rank, world, device):
+    """Config c5: regression of examples/LinearRegression.ipynb scaled to 1e5 rows, D=2, NUTS +
+    window adaptation, 8192 chains over 8 GPUs (1024 per rank by default here)."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    from aehmc_amd.parallel import barrier, gather_samples, max_over_ranks, sum_over_ranks
+    C = 1024 if args.chains == 4096 else args.chains
+    rng = np.random.default_rng(0)
+    N = 100_000
+    X = rng.normal(0, 1, size=(N,))
+    y = 3 * X + rng.normal(0, 1)
+    target = targets.LinearRegression(X, y)
+    q0 = np.array([3.0, np.log(0.5)]) + 0.05 * np.random.default_rng(1 + rank).normal(size=(C, 2))
+    kernel = nuts.new_kernel(RandomStream(seeds=[5000 + rank * C + c for c in range(C)]), target)
+    state = nuts.new_state(torch.as_tensor(q0, device=device), target)
+    t_w = time.perf_counter()
+    state, (eps, imm), _ = window_adaptation.run(kernel, state, max(args.warmup, 20))
+    torch.cuda.synchronize(device)
+    t_w = time.perf_counter() - t_w
+    barrier(device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    _, info, _, _ = kernel.sample(state, eps, imm, args.steps, keep_samples=False)
+    gathered = gather_samples(info.state.position)
+    torch.cuda.synchronize(device)
+    barrier(device)
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    total = sum_over_ranks(int(info.n_leapfrog.sum().item()), device)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "leapfrog-steps/sec across all chains", "value": total / elapsed, "unit": "leapfrog-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"c5: linear regression, {N} rows, D=2, NUTS after {max(args.warmup, 20)} "
+                                   f"window-adaptation steps ({t_w:.2f} s), {C} chains/GPU",
+                       "chains_total": int(gathered.shape[0]), "data_rows_per_s": total / elapsed * N},
+            "roofline": None, "cpu_baseline": None}))
 
 
 def cpu_baseline(config, D, q0, target, imm, eps):
