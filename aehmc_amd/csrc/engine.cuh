@@ -66,6 +66,7 @@ struct EngineArgs {
   double *psum, *psub;
   double *ckp, *cks, *ckv;          // [max_exp][C][D]
   double *vhalf, *rbuf, *zbuf;
+  double *linreg_part;  // [ceil(C/8)][S][16] slice sums of the regression target
   ChainCtl *ctl;
   // dense metric, "linear" mode: w = imm g is carried with the state so that
   // v_half = v - (eps/2) w and v' = v_half - (eps/2) w' need one metric GEMM per leapfrog
@@ -793,24 +794,46 @@ __global__ __launch_bounds__(256) void k_is_turning(EngineArgs a, const double *
 // all 8 chains; wave shuffles + a fixed-order LDS pass finish the reduction
 // (deterministic).  to_ctl: write U into ctl[c].U_cur (leapfrog) or into U[c] (new_state).
 constexpr int LINREG_CPB = 8;
-__global__ __launch_bounds__(256) void k_target_linreg(EngineArgs a, const double *q, double *g,
-                                                       double *U, int to_ctl) {
-  __shared__ double part[4][2 * LINREG_CPB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long long c0 = (long long)blockIdx.x * LINREG_CPB;
+// stage 1: workgroup (g, s) sums row slice s for the 8 chains of group g -> part[g][s][16]
+__global__ __launch_bounds__(256) void k_target_linreg(EngineArgs a, const double *q, double *part,
+                                                       int S, int to_ctl) {
+  __shared__ double red[4][2 * LINREG_CPB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long grp = blockIdx.x / S;
+  const int s = blockIdx.x % S;
+  const long long c0 = grp * LINREG_CPB;
   double w[LINREG_CPB], sxr[LINREG_CPB], srr[LINREG_CPB];
-  bool live[LINREG_CPB];
   bool any = false;
 #pragma unroll
   for (int k = 0; k < LINREG_CPB; k++) {
     const long long c = c0 + k;
-    live[k] = c < a.C && !(to_ctl && a.ctl[c].done);
-    w[k] = live[k] ? q[c * 2] : 0.0;
+    const bool live = c < a.C && !(to_ctl && a.ctl[c].done);
+    w[k] = live ? q[c * 2] : 0.0;
     sxr[k] = srr[k] = 0.0;
-    any |= live[k];
+    any |= live;
   }
   if (!any) return;
-  for (long long i = tid; i < a.N; i += 256) {
+  const long long per = (a.N + S - 1) / S;
+  const long long lo = s * per, hi = (lo + per < a.N) ? lo + per : a.N;
+  // 4 rows per thread and iteration in flight; each thread adds its rows in ascending order
+  long long i = lo + tid;
+  for (; i + 768 < hi; i += 1024) {
+    double xs[4], ys[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      xs[u] = a.X[i + 256 * u];
+      ys[u] = a.y[i + 256 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int k = 0; k < LINREG_CPB; k++) {
+        const double r = ys[u] - xs[u] * w[k];
+        sxr[k] += xs[u] * r;
+        srr[k] += r * r;
+      }
+  }
+  for (; i < hi; i += 256) {
     const double x = a.X[i], yy = a.y[i];
 #pragma unroll
     for (int k = 0; k < LINREG_CPB; k++) {
@@ -824,26 +847,37 @@ __global__ __launch_bounds__(256) void k_target_linreg(EngineArgs a, const doubl
     sxr[k] = wave_sum(sxr[k]);
     srr[k] = wave_sum(srr[k]);
     if (lane == 0) {
-      part[wave][2 * k] = sxr[k];
-      part[wave][2 * k + 1] = srr[k];
+      red[wave][2 * k] = sxr[k];
+      red[wave][2 * k + 1] = srr[k];
     }
   }
   __syncthreads();
-  if (tid < LINREG_CPB && live[tid]) {
-    const int k = tid;
-    const long long c = c0 + k;
-    const double s_xr = ((part[0][2 * k] + part[1][2 * k]) + part[2][2 * k]) + part[3][2 * k];
-    const double s_rr = ((part[0][2 * k + 1] + part[1][2 * k + 1]) + part[2][2 * k + 1]) + part[3][2 * k + 1];
-    const double ww = q[c * 2], ell = q[c * 2 + 1], n = exp(ell), n2 = n * n, N = (double)a.N;
-    const double lp_w = -0.5 * ww * ww - AEHMC_LOG_SQRT_2PI;
-    const double lp_n = log(n) - n + ell;
-    const double lp_y = -0.5 * (s_rr / n2) - N * AEHMC_LOG_SQRT_2PI - N * ell;
-    g[c * 2] = -(-ww + s_xr / n2);
-    g[c * 2 + 1] = -(2.0 - n - N + s_rr / n2);
-    const double Uv = -(lp_w + lp_n + lp_y);
-    if (to_ctl) a.ctl[c].U_cur = Uv;
-    else U[c] = Uv;
+  if (tid < 2 * LINREG_CPB)
+    part[((size_t)grp * S + s) * (2 * LINREG_CPB) + tid] =
+        ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+// stage 2: one thread per chain adds the S slice sums in order and forms U and dU/dq
+// (examples/LinearRegression.ipynb:126-166, q = [w, log n]).  to_ctl: U -> ctl[c].U_cur.
+__global__ __launch_bounds__(256) void k_linreg_finish(EngineArgs a, const double *q, double *g, double *U,
+                                                       const double *part, int S, int to_ctl) {
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C || (to_ctl && a.ctl[c].done)) return;
+  const long long grp = c / LINREG_CPB;
+  const int k = (int)(c % LINREG_CPB);
+  double s_xr = 0.0, s_rr = 0.0;
+  for (int s = 0; s < S; s++) {
+    s_xr += part[((size_t)grp * S + s) * (2 * LINREG_CPB) + 2 * k];
+    s_rr += part[((size_t)grp * S + s) * (2 * LINREG_CPB) + 2 * k + 1];
   }
+  const double ww = q[c * 2], ell = q[c * 2 + 1], n = exp(ell), n2 = n * n, N = (double)a.N;
+  const double lp_w = -0.5 * ww * ww - AEHMC_LOG_SQRT_2PI;
+  const double lp_n = log(n) - n + ell;
+  const double lp_y = -0.5 * (s_rr / n2) - N * AEHMC_LOG_SQRT_2PI - N * ell;
+  g[c * 2] = -(-ww + s_xr / n2);
+  g[c * 2 + 1] = -(2.0 - n - N + s_rr / n2);
+  const double Uv = -(lp_w + lp_n + lp_y);
+  if (to_ctl) a.ctl[c].U_cur = Uv;
+  else U[c] = Uv;
 }
 
 // leapfrog-only driver state: ctl.dir = 1, U in ctl

@@ -76,6 +76,23 @@ struct aehmc_ctx {
   } while (0)
 
 static inline dim3 chain_grid(int64_t C) { return dim3((unsigned)((C + 3) / 4)); }
+constexpr int LINREG_SMAX = 32;
+// row slices per chain group: enough workgroups (~2048) to fill the GPU
+static inline int linreg_slices(int64_t C) {
+  const int64_t groups = (C + LINREG_CPB - 1) / LINREG_CPB;
+  int64_t s = (2048 + groups - 1) / groups;
+  return (int)(s < 1 ? 1 : (s > LINREG_SMAX ? LINREG_SMAX : s));
+}
+static int launch_linreg(aehmc_ctx *ctx, const EngineArgs &a, const double *q, double *g, double *U, int to_ctl,
+                         hipStream_t st) {
+  const int S = linreg_slices(a.C);
+  const unsigned groups = (unsigned)((a.C + LINREG_CPB - 1) / LINREG_CPB);
+  hipLaunchKernelGGL(k_target_linreg, dim3(groups * S), dim3(256), 0, st, a, q, a.linreg_part, S, to_ctl);
+  hipLaunchKernelGGL(k_linreg_finish, dim3((unsigned)((a.C + 255) / 256)), dim3(256), 0, st, a, q, g, U,
+                     (const double *)a.linreg_part, S, to_ctl);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 
 // ------------------------------------------------------------------ ctx ------------
 extern "C" int aehmc_create(aehmc_ctx **out, int device) {
@@ -379,6 +396,7 @@ static int64_t ws_layout(const aehmc_ctx *ctx, int64_t C, int64_t E, char *base,
     r.cur_w = take(vec);
     r.end_w[0] = take(vec); r.end_w[1] = take(vec);
   }
+  r.linreg_part = take((((size_t)(C + LINREG_CPB - 1) / LINREG_CPB) * LINREG_SMAX * 2 * LINREG_CPB * sizeof(double) + 255) & ~(size_t)255);
   r.row_idx = reinterpret_cast<int *>(take(((size_t)C * sizeof(int) + 255) & ~(size_t)255));
   r.n_rows = reinterpret_cast<int *>(take(256));
   r.ctl = reinterpret_cast<ChainCtl *>(take(((size_t)C * sizeof(ChainCtl) + 255) & ~(size_t)255));
@@ -508,10 +526,7 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
   // targets evaluated between the stages: dense MVN (GEMM) or linear regression (row sums)
   auto target_ext = [&]() -> int {
     if (tdense) return gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr);
-    hipLaunchKernelGGL(k_target_linreg, dim3((unsigned)((C + LINREG_CPB - 1) / LINREG_CPB)), dim3(256), 0,
-                       st, a, (const double *)a.cur_q, a.cur_g, (double *)nullptr, 1);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return launch_linreg(ctx, a, a.cur_q, a.cur_g, nullptr, 1, st);
   };
   const bool text = tdense || tlin;
   if (!md && !text) {
@@ -594,10 +609,7 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
     return 0;
   }
   if (a.tkind == AEHMC_T_LINREG) {
-    hipLaunchKernelGGL(k_target_linreg, dim3((unsigned)((C + LINREG_CPB - 1) / LINREG_CPB)), dim3(256), 0,
-                       st, a, q, g, U, 0);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return launch_linreg(ctx, a, q, g, U, 0, st);
   }
   FAIL("new_state: target kind not implemented");
 }

@@ -25,3 +25,10 @@ torch.cuda.synchronize(); t2 = time.perf_counter()
 nl = int(info.n_leapfrog.sum().item())
 print(f"sampling: {S} transitions in {t2-t1:.2f} s; {nl/(t2-t1):.3e} leapfrog/s; {nl/S/C:.1f} leapfrogs/chain/transition; "
       f"data rows touched/s {nl/(t2-t1)*N:.3e}")
+nl = info.n_leapfrog.cpu().numpy()
+import numpy as np
+print("per-chain leapfrog totals over", S, "transitions: mean", nl.mean(), "median", np.median(nl), "p99", np.percentile(nl, 99), "max", nl.max())
+info1, _ = kernel(info.state._replace(momentum=None), eps, imm)
+n1 = info1.n_leapfrog.cpu().numpy()
+print("one transition: mean", n1.mean(), "max", n1.max(), "hist", np.bincount(np.minimum(np.log2(np.maximum(n1,1)).astype(int), 10)))
+print("eps quantiles", np.percentile(eps.value.cpu().numpy(), [0, 1, 50, 99, 100]))
