@@ -765,6 +765,24 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   }
   EngineArgs a;
   if (int rc = fill_args(ctx, C, 1, a)) return rc;
+  if (ctx->opt_fused_hmc && hmc_resident_supported(ctx->tgt.kind, ctx->met.ndim, D)) {
+    HmcFusedArgs f{};
+    f.C = C; f.D = D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
+    f.met_ndim = ctx->met.ndim; f.imm = ctx->met.imm; f.sqrt_mass = ctx->met.sqrt_mass;
+    f.imm_cs = ctx->met.per_chain ? (ctx->met.ndim == 0 ? 1 : D) : 0;
+    f.eps_c = ctx->eps_c;
+    f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
+    f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
+    f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;
+    const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
+    if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+    HIPCHK(launch_hmc_resident(f, a.zbuf, st));
+    if (p) {
+      HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
+      ctx->prof_used += 2;
+    }
+    return 0;
+  }
   a.eps = step_size; a.thr = divergence_threshold;
   a.rng = rng; a.nsites = 2;
   a.q = q; a.U = U; a.g = g; a.out = *out;

@@ -169,6 +169,183 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   }
 }
 
+// ---- large D: one 512-thread workgroup per chain, q and dU/dq staged in LDS ------------
+// (160 KB of LDS hold one D = 1e4 chain), p in VGPRs; all L leapfrogs of all T transitions run
+// on chip, HBM sees the transition's inputs and outputs only.  Cross-wave sums go through
+// one LDS hop; summation order therefore differs from the lock-step path (1e-13).
+template <int T, int R, int TK>
+__global__ __launch_bounds__(T) void k_hmc_resident(HmcFusedArgs a, double *zbuf) {
+  constexpr int NW = T / 64;
+  __shared__ double red[2][2 * NW];
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+  double *const sq = dyn_lds, *const sg = dyn_lds + a.D;
+  int flip = 0;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const long long c = blockIdx.x;
+  const size_t row = (size_t)c * a.D;
+  const size_t imo = (size_t)c * a.imm_cs;
+  // slots past D read element D-1 (in bounds), never store, and are skipped
+  const unsigned last = (unsigned)a.D - 1;
+#define EI(r) (((unsigned)(t + T * (r)) < last) ? (unsigned)(t + T * (r)) : last)
+#define VALID(r) ((unsigned)(t + T * (r)) <= last)
+#define MASK(r) (VALID(r) ? 1.0 : 0.0)
+  auto sum2 = [&](double &x, double &y) {
+    x = wave_sum(x);
+    y = wave_sum(y);
+    double *buf = red[flip];
+    flip ^= 1;
+    if (lane == 0) {
+      buf[2 * wave] = x;
+      buf[2 * wave + 1] = y;
+    }
+    __syncthreads();
+    double sx = buf[0], sy = buf[1];
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+      sx += buf[2 * w];
+      sy += buf[2 * w + 1];
+    }
+    x = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sx)),
+                         __builtin_amdgcn_readfirstlane(__double2loint(sx)));
+    y = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sy)),
+                         __builtin_amdgcn_readfirstlane(__double2loint(sy)));
+  };
+  double p[R], im[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    im[r] = a.imm[imo + (a.met_ndim == 0 ? 0 : EI(r))];
+    if (VALID(r)) {
+      sq[EI(r)] = (a.q + row)[EI(r)];
+      sg[EI(r)] = (a.g + row)[EI(r)];
+    }
+  }
+  __syncthreads();
+  double U = a.U[c];
+  Pcg64 g1 = pcg_load(a.rng + (size_t)c * 8), g2 = pcg_load(a.rng + (size_t)c * 8 + 4);
+  const double eps = a.eps_c ? a.eps_c[c] : a.eps;
+  const double b = 0.5 * eps, aa = 1 * eps;
+  double pa = 0.0;
+  int is_div = 0, acc = 0;
+  for (long long tr = 0; tr < a.T; tr++) {
+    if (wave == 0) {  // site #1 (hmc.py:122 -> metrics.py:65-68)
+      const double *sm = a.sqrt_mass + imo;
+      const bool scalar = a.met_ndim == 0;
+      wave_normals(g1, a.D, [=](long long i, double z) { zbuf[row + i] = (scalar ? sm[0] : sm[i]) * z; });
+    }
+    __threadfence_block();
+    __syncthreads();
+    double kd = 0.0, zero = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      p[r] = (zbuf + row)[EI(r)];
+      kd += MASK(r) * ((im[r] * p[r]) * p[r]);
+      if (a.out.momentum && VALID(r)) (a.out.momentum + row)[EI(r)] = p[r];  // kept on rejection
+    }
+    sum2(kd, zero);
+    const double H0 = U + 0.5 * kd;  // hmc.py:187
+    for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (!VALID(r)) continue;
+        double pp = p[r] - b * sg[EI(r)];
+        const double qq = sq[EI(r)] + aa * (im[r] * pp);
+        double gg;
+        if (TK == AEHMC_T_DIAG_GAUSSIAN) gg = ((qq - a.mu[EI(r)]) / a.sigma[EI(r)]) / a.sigma[EI(r)];
+        else gg = qq;
+        pp = pp - b * gg;
+        sq[EI(r)] = qq;
+        sg[EI(r)] = gg;
+        p[r] = pp;
+      }
+    }
+    double usum = 0.0;
+    kd = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const double qq = sq[EI(r)];
+      double u;
+      if (TK == AEHMC_T_STD_NORMAL) u = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
+      else if (TK == AEHMC_T_ISO_GAUSSIAN) u = qq * qq;
+      else {
+        const double z = (qq - a.mu[EI(r)]) / a.sigma[EI(r)];
+        u = 0.5 * (z * z) + a.log_sigma[EI(r)] + AEHMC_LOG_SQRT_2PI;
+      }
+      usum += MASK(r) * u;
+      const double pf = -1.0 * p[r];  // hmc.py:185
+      kd += MASK(r) * ((im[r] * pf) * pf);
+    }
+    sum2(usum, kd);
+    const double Unew = a.L > 0 ? (TK == AEHMC_T_ISO_GAUSSIAN ? 0.5 * usum : usum) : U;
+    double delta = H0 - (Unew + 0.5 * kd);
+    if (isnan(delta)) delta = -INFINITY;
+    is_div = fabs(delta) > a.thr;
+    pa = exp(delta);
+    if (pa > 1.0) pa = 1.0;
+    if (pa < 0.0) pa = 0.0;
+    acc = rng_bernoulli(g2, pa);  // hmc.py:193-195
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (!VALID(r)) continue;
+      if (acc) {  // commit: HBM holds the accepted state after every transition
+        (a.q + row)[EI(r)] = sq[EI(r)];
+        (a.g + row)[EI(r)] = sg[EI(r)];
+        if (a.out.momentum) (a.out.momentum + row)[EI(r)] = -1.0 * p[r];
+      } else {  // rejected: restore the on-chip copy from the committed state
+        sq[EI(r)] = (a.q + row)[EI(r)];
+        sg[EI(r)] = (a.g + row)[EI(r)];
+      }
+      if (a.samples) (a.samples + ((size_t)tr * a.C + c) * a.D)[EI(r)] = sq[EI(r)];
+    }
+    if (acc) U = Unew;
+    if (t == 0) {
+      if (a.acc_hist) a.acc_hist[(size_t)tr * a.C + c] = pa;
+      if (a.div_hist) a.div_hist[(size_t)tr * a.C + c] = is_div;
+    }
+    __syncthreads();  // zbuf / momentum rows are rewritten by the next transition
+  }
+  if (t == 0) {
+    pcg_store(a.rng + (size_t)c * 8, g1);
+    pcg_store(a.rng + (size_t)c * 8 + 4, g2);
+    a.U[c] = U;
+    a.out.acceptance_probability[c] = pa;
+    a.out.is_diverging[c] = is_div;
+    if (a.out.n_leapfrog) a.out.n_leapfrog[c] = a.L * a.T;
+    if (a.out.is_turning) a.out.is_turning[c] = acc;
+  }
+#undef EI
+#undef VALID
+#undef MASK
+}
+
+inline bool hmc_resident_supported(int tkind, int met_ndim, long long D) {
+  return target_is_elem_host(tkind) && met_ndim < 2 && D > 1024 && D <= 10240;
+}
+template <int T, int R>
+inline hipError_t launch_hmc_resident_r(const HmcFusedArgs &a, double *zbuf, hipStream_t st) {
+  const size_t dyn = (size_t)2 * a.D * sizeof(double);
+#define AEHMC_LAUNCH_HR(TK)                                                                              \
+  do {                                                                                                     \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_resident<T, R, TK>),          \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);              \
+    if (e != hipSuccess) return e;                                                                         \
+    hipLaunchKernelGGL((k_hmc_resident<T, R, TK>), dim3((unsigned)a.C), dim3(T), dyn, st, a, zbuf);        \
+  } while (0)
+  switch (a.tkind) {
+    case AEHMC_T_STD_NORMAL: AEHMC_LAUNCH_HR(AEHMC_T_STD_NORMAL); break;
+    case AEHMC_T_ISO_GAUSSIAN: AEHMC_LAUNCH_HR(AEHMC_T_ISO_GAUSSIAN); break;
+    default: AEHMC_LAUNCH_HR(AEHMC_T_DIAG_GAUSSIAN);
+  }
+#undef AEHMC_LAUNCH_HR
+  return hipGetLastError();
+}
+inline hipError_t launch_hmc_resident(const HmcFusedArgs &a, double *zbuf, hipStream_t st) {
+  if (a.D <= 2048) return launch_hmc_resident_r<512, 4>(a, zbuf, st);
+  if (a.D <= 4096) return launch_hmc_resident_r<512, 8>(a, zbuf, st);
+  if (a.D <= 8192) return launch_hmc_resident_r<1024, 8>(a, zbuf, st);
+  return launch_hmc_resident_r<1024, 10>(a, zbuf, st);
+}
+
 template <int R>
 inline hipError_t launch_hmc_fused_r(const HmcFusedArgs &a, hipStream_t st) {
   dim3 grid((unsigned)((a.C + 3) / 4)), block(256);

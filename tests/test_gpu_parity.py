@@ -285,6 +285,41 @@ def test_dense_metric_not_positive_definite_is_an_error():
         kernel(state, 0.1, bad)
 
 
+@pytest.mark.parametrize("D,C,tk", [(1500, 5, "diag"), (3000, 3, "std"), (5000, 3, "iso"), (10000, 3, "diag")])
+def test_hmc_resident_large_d_matches_oracle(eng, D, C, tk):
+    """D > 1024: one 512-thread workgroup per chain, q and gradient in LDS, all L steps on chip.
+    Against the oracle (1e-9) and against the lock-step path (1e-12), incl. sample()."""
+    from aehmc_amd import RandomStream, hmc
+    r = np.random.default_rng(D)
+    tgt, otgt, imm = make_case("diag", tk, D, r)
+    seeds = [800 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    eps, L = 0.2 / D ** 0.25, 11
+    metric = co.Metric(imm, D)
+    rng = co.site_states(seeds, 2)
+    q, U, g = co.new_state(otgt, q0.copy())
+    kernel = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
+    state = hmc.new_state(dev(q0), tgt)
+    for _ in range(2):
+        info, upd = kernel(state, eps, imm, L)
+        res = co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
+        check_state(info, q, U, g, res, nuts=False)
+        state = info.state._replace(momentum=None)
+    samples, info2, acc, div = kernel.sample(state, eps, imm, L, 3)
+    for t_ in range(3):
+        res = co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
+        np.testing.assert_allclose(samples[t_].cpu().numpy(), q, rtol=RTOL, atol=1e-12)
+    eng.set_option("fused_hmc", 0)  # lock-step path on the same seeds
+    k2 = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
+    s2 = hmc.new_state(dev(q0), tgt)
+    for _ in range(5):
+        i2, _ = k2(s2, eps, imm, L)
+        s2 = i2.state._replace(momentum=None)
+    eng.set_option("fused_hmc", 1)
+    np.testing.assert_allclose(info2.state.position.cpu().numpy(), i2.state.position.cpu().numpy(),
+                               rtol=1e-12, atol=1e-14)
+
+
 def test_hmc_fused_equals_lockstep_bitwise(eng):
     """The register-resident single-launch HMC kernel and the generic lock-step path run
     the same arithmetic in the same order."""
