@@ -53,7 +53,7 @@ def build_c3(D, device, rho=0.5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
@@ -110,7 +110,7 @@ def main():
         eps, L = 0.1, 32
         kernel = hmc.new_kernel(RandomStream(seeds=seeds), target)
         state = hmc.new_state(torch.as_tensor(q0, device=device), target)
-        NT = 25  # transitions per engine call (one launch on the fused path)
+        NT = 100  # transitions per engine call (100 transitions; one launch on the fused path)
         step = lambda st: (kernel.sample(st, eps, imm, L, NT, keep_samples=False)[1], None)
         workload = (f"c2: {D}-dim isotropic Gaussian, HMC L={L}, diagonal mass, {C} chains/GPU, eps={eps}; "
                     f"one step = {NT} transitions of every chain")
@@ -159,13 +159,13 @@ def main():
                     "avg_rows_per_launch": flops / (2.0 * D * D), "gemm_share_of_step_time": kern_ms / 1e3 / elapsed}
     else:
         # fused HMC kernel: algorithmic bytes = SURVEY.md 8d streaming figure 48*D B per leapfrog per chain
-        bytes_per_launch = 48.0 * D * C * 32 * 25
+        bytes_per_launch = 48.0 * D * C * 32 * 100
         avg_s = kern_ms / 1e3 / max(kern_n, 1)
         achieved = bytes_per_launch / avg_s / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS, "traffic": None, "kernel": "k_hmc_fused",
                     "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
-                    "achieved_io_only_GBs": 40.0 * D * C * 25 / avg_s / 1e9,
+                    "achieved_io_only_GBs": 40.0 * D * C * 100 / avg_s / 1e9,
                     "note": "achieved uses SURVEY 8d's streaming figure (48*D B per leapfrog); the state is "
                             "register-resident for all L steps, so frac > 1 means on-chip reuse; "
                             "achieved_io_only_GBs counts what the kernel really moves (40*D B per transition)"}
