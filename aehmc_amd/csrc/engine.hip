@@ -139,17 +139,17 @@ extern "C" int aehmc_create(aehmc_ctx **out, int device) {
 
 extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (!ctx) return 0;
-  hipSetDevice(ctx->device);
-  if (ctx->log_sigma) hipFree(ctx->log_sigma);
-  if (ctx->own_sqrt_mass) hipFree(ctx->own_sqrt_mass);
-  if (ctx->h_active) hipHostFree(ctx->h_active);
-  if (ctx->d_flops) hipFree(ctx->d_flops);
-  if (ctx->sk_partial) hipFree(ctx->sk_partial);
-  if (ctx->sk_flags) hipFree(ctx->sk_flags);
-  if (ctx->h_err) hipHostFree(ctx->h_err);
+  (void)hipSetDevice(ctx->device);
+  if (ctx->log_sigma) (void)hipFree(ctx->log_sigma);
+  if (ctx->own_sqrt_mass) (void)hipFree(ctx->own_sqrt_mass);
+  if (ctx->h_active) (void)hipHostFree(ctx->h_active);
+  if (ctx->d_flops) (void)hipFree(ctx->d_flops);
+  if (ctx->sk_partial) (void)hipFree(ctx->sk_partial);
+  if (ctx->sk_flags) (void)hipFree(ctx->sk_flags);
+  if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   for (int i = 0; i < NRING; i++)
-    if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
-  for (auto e : ctx->prof_ev) hipEventDestroy(e);
+    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
   delete ctx;
   return 0;
 }
@@ -212,7 +212,7 @@ static int dense_sqrt_mass(aehmc_ctx *ctx, const double *imm, int64_t D, double 
   hipStream_t st = 0;
   int rc = 0, h_info = 0;
   auto done = [&](int r) {
-    hipFree(Lw); hipFree(Li); hipFree(small); hipFree(Tt); hipFree(info);
+    (void)hipFree(Lw); (void)hipFree(Li); (void)hipFree(small); (void)hipFree(Tt); (void)hipFree(info);
     return r;
   };
   if (hipMemcpyAsync(Lw, imm, (size_t)D * D * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess ||

@@ -68,6 +68,6 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
                          info.acceptance_probability.reshape(C).contiguous(),
                          state.position.reshape(C, D).contiguous(), cst)
     step_size = st["step_size"].clone()
-    imm = st["imm"].clone()
+    imm, sqrt_mass = st["imm"].clone(), st["sqrt_mass"].clone()
     return state, (PerChain(layout.per_chain(step_size)),
-                   PerChain(imm.reshape(C) if scalar_position else imm)), updates
+                   PerChain(imm.reshape(C) if scalar_position else imm, sqrt_mass)), updates
