@@ -75,3 +75,18 @@ def test_nuts_sample_equals_repeated_steps():
         total = total + i2.n_leapfrog
         assert torch.equal(samples[t], i2.state.position) and torch.equal(acc[t], i2.acceptance_probability)
     assert torch.equal(info.n_leapfrog, total) and torch.equal(info.state.position, i2.state.position)
+
+
+def test_readme_example_runs():
+    """The snippet of this repo's README.md (reduced sizes)."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    C, D = 64, 10
+    target = targets.DiagGaussian(mu=torch.zeros(D), sigma=torch.ones(D))
+    srng = RandomStream(seeds=range(C))
+    kernel = nuts.new_kernel(srng, target)
+    state = nuts.new_state(torch.randn(C, D, dtype=torch.float64, device="cuda"), target)
+    state, (step_size, imm), _ = window_adaptation.run(kernel, state, num_steps=60)
+    info, updates = kernel(state, step_size, imm)
+    samples, info, acc, div = kernel.sample(info.state._replace(momentum=None), step_size, imm, 20)
+    assert samples.shape == (20, C, D) and torch.isfinite(samples).all()
+    assert acc.shape == (20, C) and srng in updates
