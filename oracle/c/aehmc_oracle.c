@@ -6,6 +6,8 @@
  * tables in tests/test_oracle_golden.py, and against oracle/np_oracle.py.
  *
  * Each function cites the reference file:line (under /root/reference) it follows.
+ * PARITY UNPINNED (no published reference value): dense-metric trajectories, and RNG
+ * consumption after a sub-trajectory whose first step diverged (trajectory.py:336).
  * The RNG restates numpy 2.2.6's PCG64 / random_standard_normal / random_binomial
  * (third party; reached by the reference through aesara RandomStream, "scheme A":
  * one spawned SeedSequence child per RNG call site) and is checked bit-for-bit

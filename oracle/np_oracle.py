@@ -14,6 +14,12 @@ Pinned against the values the reference publishes (see tests/test_oracle_golden.
 
 Every function cites the reference file:line (relative to /root/reference) it follows.
 
+PARITY UNPINNED for two things the reference publishes no value for: (1) dense-metric
+trajectories (only the exact kinetic-energy / is_turning unit cases of tests/test_metrics.py
+exist), (2) RNG consumption after a sub-trajectory whose first step diverged
+(trajectory.py:336: we assume the inner scan still executes).  For those, parity means
+"HIP == this restatement", nothing more.
+
 Third-party arithmetic that is NOT in /root/reference: aesara>=2.8.11 / aeppl>=0.1.4
 (pyproject.toml:18-19, lower bounds only).  Their RNG is restated as "scheme A":
 ``RandomStream(seed)`` keeps ``SeedSequence(seed)``; each ``srng.<dist>()`` call site,
