@@ -39,7 +39,6 @@ struct ChainCtl {
   int done, phantom;                // phantom: first step diverged, scan still runs (trajectory.py:336)
   int prop_slot;                    // which of the two proposal buffers is the main proposal
   int ndoubl, out_div, out_turn;
-  int hmc_accept;
 };
 
 struct EngineArgs {
@@ -524,7 +523,7 @@ __device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lan
   ct.tmin = ct.tmax = 0;
   ct.done = ct.phantom = 0;
   ct.prop_slot = 0;
-  ct.ndoubl = ct.out_div = ct.out_turn = ct.hmc_accept = 0;
+  ct.ndoubl = ct.out_div = ct.out_turn = 0;
   nuts_begin_expansion<MET_DENSE>(a, c, lane, ct, -1, rng);
 }
 

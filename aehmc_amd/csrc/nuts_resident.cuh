@@ -195,7 +195,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
     ct.tmin = ct.tmax = 0;
     ct.done = ct.phantom = 0;
     ct.prop_slot = 0;
-    ct.ndoubl = ct.out_div = ct.out_turn = ct.hmc_accept = 0;
+    ct.ndoubl = ct.out_div = ct.out_turn = 0;
     ct.dir = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
     ct.step = 0;
   }

@@ -590,3 +590,47 @@ def test_config5_regression_warmup_properties():
     fresh = nuts.new_state(info.state.position, tgt)
     np.testing.assert_allclose(fresh.potential_energy.cpu().numpy(),
                                info.state.potential_energy.cpu().numpy(), rtol=1e-10)
+
+
+# ------------------------------------------------------------------ full-size config c3
+@pytest.mark.timeout(600)
+def test_config3_full_size_dense_nuts():
+    """BASELINE config 3 at full size (D=1e4 dense precision + dense mass, 4096 chains), tree
+    depth capped at 3 so that the oracle can follow: chains 0 and 4095 equal the oracle; for
+    all chains the returned (U, grad) equal a fresh evaluation at the returned position, the
+    leapfrog count matches the number of expansions, and energy is conserved."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_c3
+    from aehmc_amd import RandomStream, nuts, targets
+    C, D, max_exp = 4096, 10_000, 3
+    Sigma, P = build_c3(D, torch.device("cuda"))
+    mu = torch.zeros(D, dtype=torch.float64, device="cuda")
+    tgt = targets.DenseMVN(mu, P)
+    eps = 0.5 * D ** -0.25
+    seeds = [1000 + c for c in range(C)]
+    q0 = np.random.default_rng(1234).standard_normal((C, D))
+    kernel = nuts.new_kernel(RandomStream(seeds=seeds), tgt, max_num_expansions=max_exp)
+    state = nuts.new_state(dev(q0), tgt)
+    info, _ = kernel(state, eps, Sigma)
+    nd, nl = info.num_doublings.cpu().numpy(), info.n_leapfrog.cpu().numpy()
+    full = np.cumsum([2 ** j + 1 for j in range(max_exp)])
+    assert ((nd >= 1) & (nd <= max_exp)).all()
+    assert (nl <= full[nd - 1]).all() and (nl > np.concatenate([[0], full])[nd - 1]).all()
+    assert info.acceptance_probability.mean().item() > 0.9 and not info.is_diverging.any().item()
+    fresh = nuts.new_state(info.state.position, tgt)
+    np.testing.assert_allclose(fresh.potential_energy.cpu().numpy(), info.state.potential_energy.cpu().numpy(),
+                               rtol=1e-11)
+    np.testing.assert_allclose(fresh.potential_energy_grad[:64].cpu().numpy(),
+                               info.state.potential_energy_grad[:64].cpu().numpy(), rtol=1e-9, atol=1e-9)
+    # two chains against the oracle
+    sel = [0, C - 1]
+    otgt = co.Target(co.T_DENSE_MVN, D, mu=np.zeros(D), prec=P.cpu().numpy())
+    metric = co.Metric(Sigma.cpu().numpy(), D)
+    rng = co.site_states([seeds[i] for i in sel], 4)
+    q, U, g = co.new_state(otgt, q0[sel].copy())
+    res = co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=max_exp, nthreads=2)
+    np.testing.assert_allclose(info.state.position[sel].cpu().numpy(), q, rtol=RTOL, atol=1e-11)
+    assert nl[sel].tolist() == res["n_leapfrog"].tolist() and nd[sel].tolist() == res["num_doublings"].tolist()
+    np.testing.assert_allclose(info.acceptance_probability[sel].cpu().numpy(), res["acceptance_probability"],
+                               rtol=RTOL)
