@@ -58,6 +58,7 @@ struct EngineArgs {
   // per-chain RNG [C, nsites, 4]
   uint64_t *rng;
   int nsites;
+  int z_ready;  // zbuf already holds this transition's momentum (k_draw_momentum ran first)
   // work vectors [C,D]
   double *cur_q, *cur_p, *cur_g, *cur_v, *cur_w;
   double *end_q[2], *end_p[2], *end_g[2], *end_v[2], *end_w[2];
@@ -900,6 +901,23 @@ __global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C,
   Pcg64 g = pcg_load(rng + c * 4);
   wave_normals(g, n, [=](long long i, double z) { out[c * n + i] = z; });
   if ((threadIdx.x & 63) == 0) pcg_store(rng + c * 4, g);
+}
+// Momentum draw of site #1 for every chain with one wavefront per chain (metrics.py:65-68,
+// scalar / diagonal metric): zbuf[c, i] = sqrt_mass[i] * z_i.  The workgroup-per-chain resident
+// kernels run this as a pre-pass -- inside them a single wavefront per CU would walk the stream
+// while the other waves of the workgroup wait.
+__global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites, long long C, long long D,
+                                                       const double *sqrt_mass, long long sm_cs, int met_ndim,
+                                                       double *zbuf) {
+  const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  uint64_t *gs = rng + (size_t)c * nsites * 4;
+  Pcg64 g = pcg_load(gs);
+  const double *sm = sqrt_mass + (size_t)c * sm_cs;
+  double *dst = zbuf + (size_t)c * D;
+  const bool scalar = met_ndim == 0;
+  wave_normals(g, D, [=](long long i, double z) { dst[i] = (scalar ? sm[0] : sm[i]) * z; });
+  if ((threadIdx.x & 63) == 0) pcg_store(gs, g);
 }
 __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long C, long long n,
                                                        const double *p, int32_t *out) {

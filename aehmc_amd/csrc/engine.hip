@@ -633,6 +633,12 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   if (want_resident && nuts_resident_supported(a.tkind, a.met_ndim, a.D)) {
     const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
     if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+    if (a.D > 512) {  // workgroup-per-chain teams: momentum drawn at one wavefront per chain first
+      hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, a.rng, a.nsites, (long long)C,
+                         (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf);
+      HIPCHK(hipGetLastError());
+      a.z_ready = 1;
+    }
     HIPCHK(launch_nuts_resident(a, st, ctx->opt_resident_min_team));
     if (p) {
       HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
@@ -773,10 +779,23 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     f.eps_c = ctx->eps_c;
     f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
     f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
-    f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;
+    // one launch pair per transition: the momentum draw runs at one wavefront per chain
+    // (k_draw_momentum), the workgroup-per-chain kernel then integrates and accepts
+    f.T = 1;
     const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
     if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
-    HIPCHK(launch_hmc_resident(f, a.zbuf, st));
+    for (int64_t t = 0; t < T; t++) {
+      hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, rng, 2, (long long)C, (long long)D,
+                         f.sqrt_mass, f.imm_cs, f.met_ndim, a.zbuf);
+      HIPCHK(hipGetLastError());
+      f.samples = samples ? samples + (size_t)t * C * D : nullptr;
+      f.acc_hist = acc_hist ? acc_hist + (size_t)t * C : nullptr;
+      f.div_hist = div_hist ? div_hist + (size_t)t * C : nullptr;
+      f.out.momentum = t == T - 1 ? out->momentum : nullptr;  // only the last transition's is observable
+      HIPCHK(launch_hmc_resident(f, a.zbuf, st));
+    }
+    if (T > 1 && out->n_leapfrog)
+      LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
     if (p) {
       HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
       ctx->prof_used += 2;

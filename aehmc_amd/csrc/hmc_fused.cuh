@@ -169,23 +169,24 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   }
 }
 
-// ---- large D: one 512-thread workgroup per chain, q and dU/dq staged in LDS ------------
-// (160 KB of LDS hold one D = 1e4 chain), p in VGPRs; all L leapfrogs of all T transitions run
-// on chip, HBM sees the transition's inputs and outputs only.  Cross-wave sums go through
-// one LDS hop; summation order therefore differs from the lock-step path (1e-13).
+// ---- large D: one workgroup of T threads per chain, state in VGPRs ----------------------
+// Thread t keeps elements t, t+T, ... of q, p (and dU/dq where it is not q itself) in
+// registers for all L leapfrogs of ONE transition; the momentum was drawn by k_draw_momentum
+// (one wavefront per chain) into `zbuf`.  HBM sees q, z (and dU/dq for the diagonal target)
+// once on the way in and q, dU/dq once on the way out of an accepted transition.  Cross-wave
+// sums take one LDS hop, so the summation order differs from the lock-step path (1e-13).
+// Slots past D replicate element D-1 (in bounds), are masked out of the sums and never stored.
 template <int T, int R, int TK>
-__global__ __launch_bounds__(T) void k_hmc_resident(HmcFusedArgs a, double *zbuf) {
+__global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zbuf) {
   constexpr int NW = T / 64;
+  constexpr bool DG = TK == AEHMC_T_DIAG_GAUSSIAN;  // otherwise dU/dq == q, no separate copy
   __shared__ double red[2][2 * NW];
-  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
-  double *const sq = dyn_lds, *const sg = dyn_lds + a.D;
   int flip = 0;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const long long c = blockIdx.x;
   const size_t row = (size_t)c * a.D;
   const size_t imo = (size_t)c * a.imm_cs;
-  // slots past D read element D-1 (in bounds), never store, and are skipped
   const unsigned last = (unsigned)a.D - 1;
 #define EI(r) (((unsigned)(t + T * (r)) < last) ? (unsigned)(t + T * (r)) : last)
 #define VALID(r) ((unsigned)(t + T * (r)) <= last)
@@ -211,108 +212,92 @@ __global__ __launch_bounds__(T) void k_hmc_resident(HmcFusedArgs a, double *zbuf
     y = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sy)),
                          __builtin_amdgcn_readfirstlane(__double2loint(sy)));
   };
-  double p[R], im[R];
+  double q[R], p[R], g[DG ? R : 1], im[R];
+  const double *qrow = a.q + row, *grow = a.g + row, *zrow = zbuf + row;
 #pragma unroll
-  for (int r = 0; r < R; r++) {
+  for (int r = 0; r < R; r++) {  // every load is issued before the first use
+    q[r] = qrow[EI(r)];
+    p[r] = zrow[EI(r)];
+    if (DG) g[r] = grow[EI(r)];
     im[r] = a.imm[imo + (a.met_ndim == 0 ? 0 : EI(r))];
-    if (VALID(r)) {
-      sq[EI(r)] = (a.q + row)[EI(r)];
-      sg[EI(r)] = (a.g + row)[EI(r)];
-    }
   }
-  __syncthreads();
+#define GR(r) (DG ? g[DG ? (r) : 0] : q[r])
   double U = a.U[c];
-  Pcg64 g1 = pcg_load(a.rng + (size_t)c * 8), g2 = pcg_load(a.rng + (size_t)c * 8 + 4);
+  Pcg64 g2 = pcg_load(a.rng + (size_t)c * 8 + 4);  // site #2: accept (hmc.py:194)
   const double eps = a.eps_c ? a.eps_c[c] : a.eps;
   const double b = 0.5 * eps, aa = 1 * eps;
-  double pa = 0.0;
-  int is_div = 0, acc = 0;
-  for (long long tr = 0; tr < a.T; tr++) {
-    if (wave == 0) {  // site #1 (hmc.py:122 -> metrics.py:65-68)
-      const double *sm = a.sqrt_mass + imo;
-      const bool scalar = a.met_ndim == 0;
-      wave_normals(g1, a.D, [=](long long i, double z) { zbuf[row + i] = (scalar ? sm[0] : sm[i]) * z; });
-    }
-    __threadfence_block();
-    __syncthreads();
-    double kd = 0.0, zero = 0.0;
+  double kd = 0.0, zero = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    kd += MASK(r) * ((im[r] * p[r]) * p[r]);
+    if (a.out.momentum && VALID(r)) (a.out.momentum + row)[EI(r)] = p[r];  // kept on rejection
+  }
+  sum2(kd, zero);
+  const double H0 = U + 0.5 * kd;  // hmc.py:187
+  for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      p[r] = (zbuf + row)[EI(r)];
-      kd += MASK(r) * ((im[r] * p[r]) * p[r]);
-      if (a.out.momentum && VALID(r)) (a.out.momentum + row)[EI(r)] = p[r];  // kept on rejection
+      double pp = p[r] - b * GR(r);
+      const double qq = q[r] + aa * (im[r] * pp);
+      double gg;
+      if (DG) gg = ((qq - a.mu[EI(r)]) / a.sigma[EI(r)]) / a.sigma[EI(r)];
+      else gg = qq;
+      pp = pp - b * gg;
+      q[r] = qq;
+      if (DG) g[DG ? r : 0] = gg;
+      p[r] = pp;
     }
-    sum2(kd, zero);
-    const double H0 = U + 0.5 * kd;  // hmc.py:187
-    for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
+  }
+  double usum = 0.0;
+  kd = 0.0;
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (!VALID(r)) continue;
-        double pp = p[r] - b * sg[EI(r)];
-        const double qq = sq[EI(r)] + aa * (im[r] * pp);
-        double gg;
-        if (TK == AEHMC_T_DIAG_GAUSSIAN) gg = ((qq - a.mu[EI(r)]) / a.sigma[EI(r)]) / a.sigma[EI(r)];
-        else gg = qq;
-        pp = pp - b * gg;
-        sq[EI(r)] = qq;
-        sg[EI(r)] = gg;
-        p[r] = pp;
-      }
+  for (int r = 0; r < R; r++) {
+    const double qq = q[r];
+    double u;
+    if (TK == AEHMC_T_STD_NORMAL) u = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
+    else if (TK == AEHMC_T_ISO_GAUSSIAN) u = qq * qq;
+    else {
+      const double z = (qq - a.mu[EI(r)]) / a.sigma[EI(r)];
+      u = 0.5 * (z * z) + a.log_sigma[EI(r)] + AEHMC_LOG_SQRT_2PI;
     }
-    double usum = 0.0;
-    kd = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const double qq = sq[EI(r)];
-      double u;
-      if (TK == AEHMC_T_STD_NORMAL) u = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
-      else if (TK == AEHMC_T_ISO_GAUSSIAN) u = qq * qq;
-      else {
-        const double z = (qq - a.mu[EI(r)]) / a.sigma[EI(r)];
-        u = 0.5 * (z * z) + a.log_sigma[EI(r)] + AEHMC_LOG_SQRT_2PI;
-      }
-      usum += MASK(r) * u;
-      const double pf = -1.0 * p[r];  // hmc.py:185
-      kd += MASK(r) * ((im[r] * pf) * pf);
-    }
-    sum2(usum, kd);
-    const double Unew = a.L > 0 ? (TK == AEHMC_T_ISO_GAUSSIAN ? 0.5 * usum : usum) : U;
-    double delta = H0 - (Unew + 0.5 * kd);
-    if (isnan(delta)) delta = -INFINITY;
-    is_div = fabs(delta) > a.thr;
-    pa = exp(delta);
-    if (pa > 1.0) pa = 1.0;
-    if (pa < 0.0) pa = 0.0;
-    acc = rng_bernoulli(g2, pa);  // hmc.py:193-195
+    usum += MASK(r) * u;
+    const double pf = -1.0 * p[r];  // hmc.py:185
+    kd += MASK(r) * ((im[r] * pf) * pf);
+  }
+  sum2(usum, kd);
+  const double Unew = a.L > 0 ? (TK == AEHMC_T_ISO_GAUSSIAN ? 0.5 * usum : usum) : U;
+  double delta = H0 - (Unew + 0.5 * kd);
+  if (isnan(delta)) delta = -INFINITY;
+  const int is_div = fabs(delta) > a.thr;
+  double pa = exp(delta);
+  if (pa > 1.0) pa = 1.0;
+  if (pa < 0.0) pa = 0.0;
+  const int acc = rng_bernoulli(g2, pa);  // hmc.py:193-195
+  if (acc) {  // commit; a rejected transition leaves the state in HBM untouched
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (!VALID(r)) continue;
-      if (acc) {  // commit: HBM holds the accepted state after every transition
-        (a.q + row)[EI(r)] = sq[EI(r)];
-        (a.g + row)[EI(r)] = sg[EI(r)];
-        if (a.out.momentum) (a.out.momentum + row)[EI(r)] = -1.0 * p[r];
-      } else {  // rejected: restore the on-chip copy from the committed state
-        sq[EI(r)] = (a.q + row)[EI(r)];
-        sg[EI(r)] = (a.g + row)[EI(r)];
-      }
-      if (a.samples) (a.samples + ((size_t)tr * a.C + c) * a.D)[EI(r)] = sq[EI(r)];
+      (a.q + row)[EI(r)] = q[r];
+      (a.g + row)[EI(r)] = GR(r);
+      if (a.out.momentum) (a.out.momentum + row)[EI(r)] = -1.0 * p[r];
+      if (a.samples) (a.samples + row)[EI(r)] = q[r];
     }
-    if (acc) U = Unew;
-    if (t == 0) {
-      if (a.acc_hist) a.acc_hist[(size_t)tr * a.C + c] = pa;
-      if (a.div_hist) a.div_hist[(size_t)tr * a.C + c] = is_div;
-    }
-    __syncthreads();  // zbuf / momentum rows are rewritten by the next transition
+  } else if (a.samples) {
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (VALID(r)) (a.samples + row)[EI(r)] = qrow[EI(r)];
   }
   if (t == 0) {
-    pcg_store(a.rng + (size_t)c * 8, g1);
     pcg_store(a.rng + (size_t)c * 8 + 4, g2);
-    a.U[c] = U;
+    if (acc) a.U[c] = Unew;
     a.out.acceptance_probability[c] = pa;
     a.out.is_diverging[c] = is_div;
-    if (a.out.n_leapfrog) a.out.n_leapfrog[c] = a.L * a.T;
-    if (a.out.is_turning) a.out.is_turning[c] = acc;
+    if (a.out.n_leapfrog) a.out.n_leapfrog[c] = a.L;
+    if (a.out.is_turning) a.out.is_turning[c] = acc;  // HMC: reused as the accept flag
+    if (a.acc_hist) a.acc_hist[c] = pa;
+    if (a.div_hist) a.div_hist[c] = is_div;
   }
+#undef GR
 #undef EI
 #undef VALID
 #undef MASK
@@ -322,28 +307,25 @@ inline bool hmc_resident_supported(int tkind, int met_ndim, long long D) {
   return target_is_elem_host(tkind) && met_ndim < 2 && D > 1024 && D <= 10240;
 }
 template <int T, int R>
-inline hipError_t launch_hmc_resident_r(const HmcFusedArgs &a, double *zbuf, hipStream_t st) {
-  const size_t dyn = (size_t)2 * a.D * sizeof(double);
-#define AEHMC_LAUNCH_HR(TK)                                                                              \
-  do {                                                                                                     \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_resident<T, R, TK>),          \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);              \
-    if (e != hipSuccess) return e;                                                                         \
-    hipLaunchKernelGGL((k_hmc_resident<T, R, TK>), dim3((unsigned)a.C), dim3(T), dyn, st, a, zbuf);        \
-  } while (0)
+inline hipError_t launch_hmc_wide_r(const HmcFusedArgs &a, const double *zbuf, hipStream_t st) {
   switch (a.tkind) {
-    case AEHMC_T_STD_NORMAL: AEHMC_LAUNCH_HR(AEHMC_T_STD_NORMAL); break;
-    case AEHMC_T_ISO_GAUSSIAN: AEHMC_LAUNCH_HR(AEHMC_T_ISO_GAUSSIAN); break;
-    default: AEHMC_LAUNCH_HR(AEHMC_T_DIAG_GAUSSIAN);
+    case AEHMC_T_STD_NORMAL:
+      hipLaunchKernelGGL((k_hmc_wide<T, R, AEHMC_T_STD_NORMAL>), dim3((unsigned)a.C), dim3(T), 0, st, a, zbuf);
+      break;
+    case AEHMC_T_ISO_GAUSSIAN:
+      hipLaunchKernelGGL((k_hmc_wide<T, R, AEHMC_T_ISO_GAUSSIAN>), dim3((unsigned)a.C), dim3(T), 0, st, a, zbuf);
+      break;
+    default:
+      hipLaunchKernelGGL((k_hmc_wide<T, R, AEHMC_T_DIAG_GAUSSIAN>), dim3((unsigned)a.C), dim3(T), 0, st, a, zbuf);
   }
-#undef AEHMC_LAUNCH_HR
   return hipGetLastError();
 }
-inline hipError_t launch_hmc_resident(const HmcFusedArgs &a, double *zbuf, hipStream_t st) {
-  if (a.D <= 2048) return launch_hmc_resident_r<512, 4>(a, zbuf, st);
-  if (a.D <= 4096) return launch_hmc_resident_r<512, 8>(a, zbuf, st);
-  if (a.D <= 8192) return launch_hmc_resident_r<1024, 8>(a, zbuf, st);
-  return launch_hmc_resident_r<1024, 10>(a, zbuf, st);
+// `samples`, `acc_hist`, `div_hist` point at THIS transition's slices (a.T is not used).
+inline hipError_t launch_hmc_resident(const HmcFusedArgs &a, const double *zbuf, hipStream_t st) {
+  if (a.D <= 2048) return launch_hmc_wide_r<256, 8>(a, zbuf, st);
+  if (a.D <= 4096) return launch_hmc_wide_r<512, 8>(a, zbuf, st);
+  if (a.D <= 8192) return launch_hmc_wide_r<1024, 8>(a, zbuf, st);
+  return launch_hmc_wide_r<1024, 10>(a, zbuf, st);
 }
 
 template <int R>

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
     }
     if (lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
   } else {
-    if (TM::WAVE || wave == 0) {
+    if ((TM::WAVE || wave == 0) && !(TM::MULTI && a.z_ready)) {
       const double *sm = a.sqrt_mass + imo;
       const bool scalar = a.met_ndim == 0;
       double *dst = a.zbuf;

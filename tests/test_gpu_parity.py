@@ -287,7 +287,8 @@ def test_dense_metric_not_positive_definite_is_an_error():
 
 @pytest.mark.parametrize("D,C,tk", [(1500, 5, "diag"), (3000, 3, "std"), (5000, 3, "iso"), (10000, 3, "diag")])
 def test_hmc_resident_large_d_matches_oracle(eng, D, C, tk):
-    """D > 1024: one 512-thread workgroup per chain, q and gradient in LDS, all L steps on chip.
+    """D > 1024: momentum pre-pass (one wavefront per chain) + one workgroup per chain with the
+    state in registers for all L steps.
     Against the oracle (1e-9) and against the lock-step path (1e-12), incl. sample()."""
     from aehmc_amd import RandomStream, hmc
     r = np.random.default_rng(D)
