@@ -896,10 +896,12 @@ __global__ __launch_bounds__(256) void k_ctl_get_U(EngineArgs a, double *U) {
 }
 __global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C, long long n,
                                                      double *out) {
+  __shared__ double ztab[512];
+  const ZigTabLds tab = zig_tab_to_lds(ztab);
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
   Pcg64 g = pcg_load(rng + c * 4);
-  wave_normals(g, n, [=](long long i, double z) { out[c * n + i] = z; });
+  wave_normals(g, n, [=](long long i, double z) { out[c * n + i] = z; }, tab);
   if ((threadIdx.x & 63) == 0) pcg_store(rng + c * 4, g);
 }
 // Momentum draw of site #1 for every chain with one wavefront per chain (metrics.py:65-68,
@@ -909,6 +911,8 @@ __global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C,
 __global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites, long long C, long long D,
                                                        const double *sqrt_mass, long long sm_cs, int met_ndim,
                                                        double *zbuf) {
+  __shared__ double ztab[512];
+  const ZigTabLds tab = zig_tab_to_lds(ztab);
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
   uint64_t *gs = rng + (size_t)c * nsites * 4;
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites
   const double *sm = sqrt_mass + (size_t)c * sm_cs;
   double *dst = zbuf + (size_t)c * D;
   const bool scalar = met_ndim == 0;
-  wave_normals(g, D, [=](long long i, double z) { dst[i] = (scalar ? sm[0] : sm[i]) * z; });
+  wave_normals(g, D, [=](long long i, double z) { dst[i] = (scalar ? sm[0] : sm[i]) * z; }, tab);
   if ((threadIdx.x & 63) == 0) pcg_store(gs, g);
 }
 __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long C, long long n,

@@ -47,6 +47,8 @@ inline bool hmc_fused_supported(int tkind, int met_ndim, long long D) {
 template <int R, int TK>
 __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double zlds[];  // [4 waves][R*64]
+  __shared__ double ztab[512];
+  const ZigTabLds tab = zig_tab_to_lds(ztab);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long c = (long long)blockIdx.x * 4 + w;
   if (c >= a.C) return;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   int is_div = 0, acc = 0;
 
   for (long long t = 0; t < a.T; t++) {
-    wave_normals(g1, a.D, [=](long long i, double z) { zrow[i] = z; });  // metrics.py:65-68
+    wave_normals(g1, a.D, [=](long long i, double z) { zrow[i] = z; }, tab);  // metrics.py:65-68
     __threadfence_block();
     double kd = 0.0;
 #pragma unroll

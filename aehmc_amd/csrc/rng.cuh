@@ -62,35 +62,86 @@ struct ZigDraw {
   int idx;
   bool accept;
 };
-__device__ __forceinline__ ZigDraw zig_fast(uint64_t r) {
+// where the fast path reads its two tables: constant memory (wave-uniform index -> scalar
+// loads) or a copy in LDS (per-lane index: ~5x shorter latency than the vector-memory path)
+struct ZigTabConst {
+  __device__ __forceinline__ double wi(int i) const { return c_zig_wi[i]; }
+  __device__ __forceinline__ uint64_t ki(int i) const { return c_zig_ki[i]; }
+};
+struct ZigTabLds {
+  const double *w;
+  const uint64_t *k;
+  __device__ __forceinline__ double wi(int i) const { return w[i]; }
+  __device__ __forceinline__ uint64_t ki(int i) const { return k[i]; }
+};
+// copies the fast-path tables into `lds` (512 x 8 B); every thread of the block must call it
+__device__ __forceinline__ ZigTabLds zig_tab_to_lds(double *lds) {
+  uint64_t *k = reinterpret_cast<uint64_t *>(lds + 256);
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    lds[i] = c_zig_wi[i];
+    k[i] = c_zig_ki[i];
+  }
+  __syncthreads();
+  return ZigTabLds{lds, k};
+}
+template <class Tab>
+__device__ __forceinline__ ZigDraw zig_fast(uint64_t r, const Tab &tab) {
   ZigDraw d;
   d.idx = (int)(r & 0xff);
   r >>= 8;
   int sign = (int)(r & 0x1);
   d.rabs = (r >> 1) & 0x000fffffffffffffULL;
-  double x = (double)d.rabs * c_zig_wi[d.idx];
+  double x = (double)d.rabs * tab.wi(d.idx);
   d.x = sign ? -x : x;
-  d.accept = d.rabs < c_zig_ki[d.idx];
+  d.accept = d.rabs < tab.ki(d.idx);
   return d;
 }
-// everything after a failed fast-path test of draw `d` (tail / wedge / full redraws)
-__device__ inline double zig_slow(Pcg64 &rng, ZigDraw d) {
+__device__ __forceinline__ ZigDraw zig_fast(uint64_t r) { return zig_fast(r, ZigTabConst{}); }
+// Everything after a failed fast-path test of draw `d` (tail / wedge / full redraws), over a
+// source of raw 64-bit outputs; false when the source ran dry before the draw was resolved.
+__device__ __forceinline__ double u64_to_unit(uint64_t r) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
+template <class Src>
+__device__ inline bool zig_slow_from(Src &src, ZigDraw d, double &out) {
+  uint64_t r;
   for (;;) {
     if (d.idx == 0) {
       for (;;) {
-        double xx = -AEHMC_ZIG_NOR_INV_R * log1p(-pcg_next_double(rng));
-        double yy = -log1p(-pcg_next_double(rng));
-        if (yy + yy > xx * xx)
-          return ((d.rabs >> 8) & 0x1) ? -(AEHMC_ZIG_NOR_R + xx) : AEHMC_ZIG_NOR_R + xx;
+        if (!src.next(r)) return false;
+        double xx = -AEHMC_ZIG_NOR_INV_R * log1p(-u64_to_unit(r));
+        if (!src.next(r)) return false;
+        double yy = -log1p(-u64_to_unit(r));
+        if (yy + yy > xx * xx) {
+          out = ((d.rabs >> 8) & 0x1) ? -(AEHMC_ZIG_NOR_R + xx) : AEHMC_ZIG_NOR_R + xx;
+          return true;
+        }
       }
     } else {
-      if (((c_zig_fi[d.idx - 1] - c_zig_fi[d.idx]) * pcg_next_double(rng) + c_zig_fi[d.idx]) <
-          exp(-0.5 * d.x * d.x))
-        return d.x;
+      if (!src.next(r)) return false;
+      if (((c_zig_fi[d.idx - 1] - c_zig_fi[d.idx]) * u64_to_unit(r) + c_zig_fi[d.idx]) < exp(-0.5 * d.x * d.x)) {
+        out = d.x;
+        return true;
+      }
     }
-    d = zig_fast(pcg_next64(rng));
-    if (d.accept) return d.x;
+    if (!src.next(r)) return false;
+    d = zig_fast(r);
+    if (d.accept) {
+      out = d.x;
+      return true;
+    }
   }
+}
+struct PcgSrc {  // the generator itself: never dry
+  Pcg64 &g;
+  __device__ __forceinline__ bool next(uint64_t &r) {
+    r = pcg_next64(g);
+    return true;
+  }
+};
+__device__ inline double zig_slow(Pcg64 &rng, ZigDraw d) {
+  PcgSrc src{rng};
+  double z = 0.0;
+  zig_slow_from(src, d, z);
+  return z;
 }
 __device__ inline double rng_standard_normal(Pcg64 &rng) {
   ZigDraw d = zig_fast(pcg_next64(rng));
@@ -100,12 +151,19 @@ __device__ inline double rng_standard_normal(Pcg64 &rng) {
 // ---- binomial(1, p) --------------------------------------------------------------
 __device__ inline int binomial1_inversion(Pcg64 &rng, double p) {
   double q = 1.0 - p;
+  double U = pcg_next_double(rng);
+  // qn = exp(log(q)) is q up to a few ulp, and the loop below returns 0 when U <= qn, else 1
+  // unless U - qn > p*qn/q (U within ulps of 1).  Away from those two boundaries the outcome is
+  // settled without evaluating qn; inside the guard bands (probability ~1e-12) the literal
+  // arithmetic decides, so the result always equals the literal one.
+  const double guard = 1e-12;
+  if (U < q * (1.0 - guard)) return 0;
+  if (U > q * (1.0 + guard) && U < 1.0 - guard) return 1;
   double qn = exp(1 * log(q));
   // numpy: bound = min(n, n p + 10 sqrt(n p q + 1)); with n == 1 the second term is >= 10
   const long long bound = 1;
   long long X = 0;
   double px = qn;
-  double U = pcg_next_double(rng);
   while (U > px) {
     X++;
     if (X > bound) {
@@ -137,36 +195,90 @@ __device__ __forceinline__ u128 shfl_u128(u128 v, int src) {
 }
 
 // Draws z_0..z_{n-1} exactly as n sequential Generator.normal() calls would, with the
-// 64 lanes of the wave evaluating 64 consecutive stream positions at once (LCG
-// jump-ahead); a rejected fast-path test (0.7 % of draws) is resolved serially and the
-// wave restarts behind it.  `store(i, z)` is called by exactly one lane per element.
-template <class Store>
-__device__ inline void wave_normals(Pcg64 &rng, long long n, Store store) {
+// 64 lanes of the wave evaluating 64 consecutive stream positions at once (LCG jump-ahead).
+// A rejected fast-path test (0.7 % of draws) is resolved by the scalar path reading the raw
+// outputs the following lanes already hold; those lanes are then skipped as uniforms that
+// were consumed, and the lanes behind them keep their draws (shifted down in the output).
+// Only a rejection whose redraws run past lane 63 restarts the wave behind it.
+// `store(i, z)` is called by exactly one lane per element.
+struct LaneSrc {  // raw outputs of lanes idx, idx+1, ... of the current round (wave-uniform walk)
+  uint64_t raw;
+  int idx;
+  __device__ __forceinline__ bool next(uint64_t &r) {
+    if (idx > 63) return false;
+    r = shfl_u64(raw, idx);
+    idx++;
+    return true;
+  }
+};
+template <class Store, class Tab = ZigTabConst>
+__device__ inline void wave_normals(Pcg64 &rng, long long n, Store store, const Tab &tab = Tab{}) {
   const int lane = threadIdx.x & 63;
   const u128 Ak = (((u128)c_pcg_jump[lane][0]) << 64) | (u128)c_pcg_jump[lane][1];
-  const u128 Gk = (((u128)c_pcg_jump[lane][2]) << 64) | (u128)c_pcg_jump[lane][3];
-  long long pos = 0;
+  const u128 GI = ((((u128)c_pcg_jump[lane][2]) << 64) | (u128)c_pcg_jump[lane][3]) * rng.inc;
+  long long pos = 0;  // normals delivered so far
   while (pos < n) {
-    long long rem = n - pos;
-    int need = rem < 64 ? (int)rem : 64;
-    u128 sk = Ak * rng.state + Gk * rng.inc;  // state after lane+1 steps
-    ZigDraw d = zig_fast(pcg_output(sk));
-    unsigned long long fail = __ballot(!d.accept && lane < need);
-    int f = fail ? (__ffsll((long long)fail) - 1) : need;
-    if (lane < f) store(pos + lane, d.x);
-    if (f < need) {
+    const u128 sk = Ak * rng.state + GI;  // state after lane+1 steps
+    const uint64_t raw = pcg_output(sk);
+    const ZigDraw d = zig_fast(raw, tab);
+    const unsigned long long fail = __ballot(!d.accept);
+    const long long want = n - pos;
+    if (fail == 0 && want >= 64) {  // 64 % of the rounds
+      store(pos + lane, d.x);
+      pos += 64;
+      rng.state = shfl_u128(sk, 63);
+      continue;
+    }
+    // Rejections are resolved in lane order; `dropped` collects the lanes that deliver nothing
+    // (consumed by a rejection's redraws, or cut off behind a restart), and every surviving
+    // lane stores once at the end, shifted down by the dropped lanes below it.
+    double x = d.x;
+    unsigned long long dropped = 0;
+    int cur = 0;                // rejections are looked for at lanes >= cur
+    bool serial = false;        // rng.state was advanced by the generator itself (restart)
+    int ev_f = -1, ev_end = -1; // last resolved rejection: its lane, the last lane it consumed
+    for (;;) {
+      const unsigned long long m = cur < 64 ? (fail & (~0ULL << cur)) : 0ULL;
+      if (!m) break;
+      const int f = __ffsll((long long)m) - 1;
+      const int before = f - __popcll(dropped & ((1ULL << f) - 1));  // normals delivered by lanes < f
+      if ((long long)before >= want) break;                           // the request ends before lane f
       ZigDraw df;
       df.x = __longlong_as_double((long long)shfl_u64((uint64_t)__double_as_longlong(d.x), f));
       df.rabs = shfl_u64(d.rabs, f);
       df.idx = __builtin_amdgcn_readlane(d.idx, f);
       df.accept = false;
-      rng.state = shfl_u128(sk, f);
-      double z = zig_slow(rng, df);
-      if (lane == 0) store(pos + f, z);
-      pos += f + 1;
-    } else {
-      rng.state = shfl_u128(sk, need - 1);
-      pos += need;
+      LaneSrc src{raw, f + 1};
+      double z;
+      ev_f = f;
+      if (zig_slow_from(src, df, z)) {  // lanes f+1 .. src.idx-1 were consumed
+        const int k = src.idx - (f + 1);
+        if (k) dropped |= ((1ULL << k) - 1) << (f + 1);
+        ev_end = src.idx - 1;
+        cur = src.idx;
+      } else {  // ran past lane 63: redo this draw on the generator itself, restart behind it
+        rng.state = shfl_u128(sk, f);
+        z = zig_slow(rng, df);
+        serial = true;
+        if (f < 63) dropped |= ~0ULL << (f + 1);
+        cur = 64;
+      }
+      if (lane == f) x = z;
+    }
+    const bool mine = !((dropped >> lane) & 1ULL);
+    const int o = lane - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(dropped >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)dropped, 0u));
+    const int produced = 64 - __popcll(dropped);
+    if ((long long)produced <= want) {
+      if (mine) store(pos + o, x);
+      pos += produced;
+      if (!serial) rng.state = shfl_u128(sk, 63);
+    } else {  // the request ends inside this round (never behind a restart: that lane delivers the last one)
+      if (mine && o < want) store(pos + o, x);
+      const unsigned long long lastm = __ballot(mine && o == want - 1);
+      const int L = __ffsll((long long)lastm) - 1;
+      rng.state = shfl_u128(sk, L == ev_f ? ev_end : L);
+      return;
     }
   }
 }

@@ -45,6 +45,19 @@ def test_device_rng_matches_numpy(eng):
         after = rng.cpu().numpy().view(np.uint64)[c]
         stt = g.bit_generator.state["state"]["state"]
         assert int(after[0]) == stt >> 64 and int(after[1]) == stt & (2**64 - 1)
+    # request sizes around the 64-lane round: every way a call can end (inside an accepted run,
+    # on a resolved rejection, on a restart), continuing the same streams
+    gens = [np.random.default_rng(np.random.SeedSequence(s).spawn(2)[0]) for s in seeds]
+    for g in gens:
+        g.normal(0, 1, size=n)
+    for m in list(range(1, 70)) + [127, 128, 129, 191, 1000, 4097] * 3:
+        zz = eng.rng_normals(rng, m).cpu().numpy()
+        for c, g in enumerate(gens):
+            np.testing.assert_allclose(zz[c], g.normal(0, 1, size=m), rtol=4e-16, atol=0)
+    after = rng.cpu().numpy().view(np.uint64)
+    for c, g in enumerate(gens):
+        stt = g.bit_generator.state["state"]["state"]
+        assert int(after[c][0]) == stt >> 64 and int(after[c][1]) == stt & (2**64 - 1)
     ps = np.random.default_rng(7).random((len(seeds), 20_000))
     ps[:, ::7], ps[:, ::11], ps[:, ::13] = 0.0, 1.0, 0.5
     rng2 = rng_to_device(st[:, 1].copy(), "cuda")
