@@ -629,7 +629,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   // there are enough chains to fill the GPU with sub-wavefront teams (measured crossovers,
   // tools/nuts_diag_bench.py)
   const bool want_resident = ctx->opt_resident_nuts == 1 ||
-                             (ctx->opt_resident_nuts == 2 && (a.D > 256 || C >= 16384));
+                             (ctx->opt_resident_nuts == 2 && (a.D > 256 || C >= 16384 || a.tkind == AEHMC_T_LINREG));
   if (want_resident && nuts_resident_supported(a.tkind, a.met_ndim, a.D)) {
     const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
     if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));

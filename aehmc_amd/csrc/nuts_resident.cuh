@@ -82,20 +82,32 @@ __device__ __forceinline__ void team_sum2(double &x, double &y, double (*red)[2 
 
 // QGL: q and dU/dq of the moving end live in LDS instead of VGPRs (one workgroup per CU
 // owns up to 160 KB: a whole D = 1e4 chain), p and the momentum sum stay in registers.
-template <int T, int R, bool QGL = false>
-__global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
+//
+// LR: the linear-regression target (examples/LinearRegression.ipynb:126-166, D = 2).  Its
+// gradient is a reduction over the N data rows, so the four wavefront-teams of a workgroup
+// evaluate it together: every thread streams its rows of (X, y) once per leapfrog (from L2)
+// for all four chains, and each wave keeps the tree of its own chain.  A wave whose chain
+// has finished keeps serving rows until the whole workgroup is done.
+constexpr int LR_BLOCK = 512, LR_WAVES = LR_BLOCK / 64;  // 4 chain waves + 4 waves that only serve rows
+template <int T, int R, bool QGL = false, bool LR = false>
+__global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
   using TM = Team<T>;
+  static_assert(!LR || (T == 64 && R == 1 && !QGL), "LR: one wavefront per chain, D = 2");
   __shared__ double red[2][2 * TM::NW];
+  __shared__ double lr_w[4], lr_part[LR_WAVES][8];
+  __shared__ int lr_done[4];
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   double *const sq = dyn_lds, *const sg = dyn_lds + (QGL ? a.D : 0);
   int flip = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long c = TM::SUB    ? ((long long)blockIdx.x * 256 + threadIdx.x) / T
-                      : TM::WAVE ? (long long)blockIdx.x * 4 + wave
-                                 : (long long)blockIdx.x;
+  const long long c = LR && wave >= 4 ? a.C  // row-serving wave: no chain
+                      : TM::SUB       ? ((long long)blockIdx.x * 256 + threadIdx.x) / T
+                      : TM::WAVE      ? (long long)blockIdx.x * 4 + wave
+                                      : (long long)blockIdx.x;
   const int t = TM::SUB ? (int)(threadIdx.x % T) : TM::WAVE ? lane : (int)threadIdx.x;
-  if (c >= a.C) return;  // a whole team leaves together (only workgroup teams use the barrier)
+  const bool ghost = c >= a.C;  // a whole team leaves together (only workgroup teams use the barrier) ...
+  if (ghost && !LR) return;     // ... except with LR, where it stays to serve data rows
   const size_t row = (size_t)c * a.D;
   const bool lead = t == 0;
 
@@ -117,6 +129,19 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
   double imr[IM_REG ? R : 1];
   const size_t imo = (size_t)c * a.imm_cs;
 #define IMM(r) (IM_REG ? imr[IM_REG ? (r) : 0] : a.imm[imo + (a.met_ndim == 0 ? 0 : (long long)t + (long long)T * (r))])
+  ChainRng rng = {};
+  ChainCtl ct = {};
+  double kd = 0.0, zero = 0.0;
+  if (LR && ghost) {
+    ct.done = 1;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      ok[r] = false;
+      p[r] = pb[r] = 0.0;
+      QSET(r, 0.0);
+      GSET(r, 0.0);
+    }
+  } else {
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const long long i = (long long)t + (long long)T * r;
@@ -129,7 +154,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
   }
 
   // ---- momentum, site #1 (nuts.py:113 -> metrics.py:65-68) ------------------------
-  ChainRng rng = rng_load(a, c);
+  rng = rng_load(a, c);
   if (TM::SUB) {
     // every lane of the team walks the chain's stream itself and keeps its own elements
     const double *sm = a.sqrt_mass + imo;
@@ -158,8 +183,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
   }
 
   // ---- nuts.py:113-125 ----------------------------------------------------------------
-  ChainCtl ct;
-  double kd = 0.0, zero = 0.0;
+  kd = 0.0;
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const long long i = (long long)t + (long long)T * r;
@@ -199,33 +223,125 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
     ct.dir = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
     ct.step = 0;
   }
-  const double eps = a.eps_c ? a.eps_c[c] : a.eps;
+  }
+  const double eps = (LR && ghost) ? 0.0 : (a.eps_c ? a.eps_c[c] : a.eps);
 
-  while (!ct.done) {
+  while (LR || !ct.done) {
     // ---- one leapfrog of the moving end, in registers (integrators.py:54-73) ---------
     const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
     const double b = 0.5 * step_size, aa = 1 * step_size;
     double usum = 0.0;
     kd = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (ok[r]) {
-        const long long i = (long long)t + (long long)T * r;
-        double pp = p[r] - b * GGET(r);
-        double qq = QGET(r) + aa * (IMM(r) * pp);
-        double u, gg;
-        target_elem(a, i, qq, u, gg);
-        usum += u;
-        pp = pp - b * gg;
-        QSET(r, qq);
-        GSET(r, gg);
-        p[r] = pp;
-        kd += (IMM(r) * pp) * pp;
+    if (LR) {
+      if (!ct.done && ok[0]) {
+        const double pp = p[0] - b * GGET(0);
+        QSET(0, QGET(0) + aa * (IMM(0) * pp));
+        p[0] = pp;
       }
-      R_FENCE();
+      if (lane == 0 && wave < 4) {
+        lr_w[wave] = QGET(0);
+        lr_done[wave] = ct.done;
+      }
+      __syncthreads();
+      if (lr_done[0] & lr_done[1] & lr_done[2] & lr_done[3]) break;
+      // sum(x r) and sum(r^2), r = y - x w, over all rows for the four chains of the workgroup
+      // (same per-thread order as k_target_linreg with one slice)
+      double w4[4], sxr[4], srr[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        w4[k] = lr_w[k];
+        sxr[k] = srr[k] = 0.0;
+      }
+      // Four rows per thread and batch, two register sets in ping-pong so that the next batch
+      // is in flight while this one is used; each thread adds its rows in ascending order.
+      const long long nbf = a.N / (4 * LR_BLOCK);  // batches in which every thread has 4 rows
+      const double *Xp = a.X + threadIdx.x, *yp = a.y + threadIdx.x;
+      double xa[4], ya[4], xb[4], yb[4];
+#define LR_LOAD(xd, yd, bb)                                   \
+  _Pragma("unroll") for (int u = 0; u < 4; u++) {             \
+    xd[u] = Xp[(4 * (bb) + u) * (long long)LR_BLOCK];         \
+    yd[u] = yp[(4 * (bb) + u) * (long long)LR_BLOCK];         \
+  }
+#define LR_ACC(xd, yd)                                        \
+  _Pragma("unroll") for (int u = 0; u < 4; u++)               \
+  _Pragma("unroll") for (int k = 0; k < 4; k++) {             \
+    const double rr = yd[u] - xd[u] * w4[k];                  \
+    sxr[k] += xd[u] * rr;                                     \
+    srr[k] += rr * rr;                                        \
+  }
+      long long bb = 0;
+      if (nbf > 0) { LR_LOAD(xa, ya, 0) }
+      for (; bb + 1 < nbf; bb += 2) {
+        LR_LOAD(xb, yb, bb + 1)
+        LR_ACC(xa, ya)
+        if (bb + 2 < nbf) { LR_LOAD(xa, ya, bb + 2) }
+        LR_ACC(xb, yb)
+      }
+      if (bb < nbf) { LR_ACC(xa, ya) }
+#undef LR_LOAD
+#undef LR_ACC
+      for (long long i = nbf * 4 * LR_BLOCK + threadIdx.x; i < a.N; i += LR_BLOCK) {
+        const double x = a.X[i], yy = a.y[i];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const double rr = yy - x * w4[k];
+          sxr[k] += x * rr;
+          srr[k] += rr * rr;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sxr[k] = wave_sum(sxr[k]);
+        srr[k] = wave_sum(srr[k]);
+        if (lane == 0) {
+          lr_part[wave][2 * k] = sxr[k];
+          lr_part[wave][2 * k + 1] = srr[k];
+        }
+      }
+      __syncthreads();
+      if (ct.done) continue;
+      double s_xr = lr_part[0][2 * wave], s_rr = lr_part[0][2 * wave + 1];
+#pragma unroll
+      for (int w = 1; w < LR_WAVES; w++) {
+        s_xr += lr_part[w][2 * wave];
+        s_rr += lr_part[w][2 * wave + 1];
+      }
+      // U and dU/dq as k_linreg_finish (q = [w, log n])
+      const double qv = QGET(0);
+      const double ww = __shfl(qv, 0), ell = __shfl(qv, 1), n = exp(ell), n2 = n * n, N = (double)a.N;
+      const double lp_w = -0.5 * ww * ww - AEHMC_LOG_SQRT_2PI;
+      const double lp_n = log(n) - n + ell;
+      const double lp_y = -0.5 * (s_rr / n2) - N * AEHMC_LOG_SQRT_2PI - N * ell;
+      const double gg = lane == 0 ? -(-ww + s_xr / n2) : -(2.0 - n - N + s_rr / n2);
+      ct.U_cur = -(lp_w + lp_n + lp_y);
+      if (ok[0]) {
+        const double pp = p[0] - b * gg;
+        GSET(0, gg);
+        p[0] = pp;
+        kd = (IMM(0) * pp) * pp;
+      }
+      team_sum2<T>(usum, kd, red, flip);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          const long long i = (long long)t + (long long)T * r;
+          double pp = p[r] - b * GGET(r);
+          double qq = QGET(r) + aa * (IMM(r) * pp);
+          double u, gg;
+          target_elem(a, i, qq, u, gg);
+          usum += u;
+          pp = pp - b * gg;
+          QSET(r, qq);
+          GSET(r, gg);
+          p[r] = pp;
+          kd += (IMM(r) * pp) * pp;
+        }
+        R_FENCE();
+      }
+      team_sum2<T>(usum, kd, red, flip);
+      ct.U_cur = target_finish(a, usum);
     }
-    team_sum2<T>(usum, kd, red, flip);
-    ct.U_cur = target_finish(a, usum);
 
     // ---- dynamic_integration body (trajectory.py:195-305) ------------------------------
     const int step = ct.step;
@@ -428,7 +544,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
       }
     }
   }
-  if (lead) {
+  if (lead && !(LR && ghost)) {
     if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
     pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, rng.g[1]);
     pcg_store(a.rng + ((size_t)c * a.nsites + 2) * 4, rng.g[2]);
@@ -445,22 +561,23 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
 }
 
 inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
+  if (tkind == AEHMC_T_LINREG) return met_ndim < 2 && D == 2;
   return (tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN) &&
          met_ndim < 2 && D <= 10240;
 }
 
-template <int T, int R, bool QGL = false>
+template <int T, int R, bool QGL = false, bool LR = false>
 inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
   const unsigned grid = Team<T>::SUB    ? (unsigned)((a.C * T + 255) / 256)
                         : Team<T>::WAVE ? (unsigned)((a.C + 3) / 4)
                                         : (unsigned)a.C;
   const size_t dyn = QGL ? (size_t)2 * a.D * sizeof(double) : 0;
   if (QGL) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<T, R, QGL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<T, R, QGL, LR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((k_nuts_resident<T, R, QGL>), dim3(grid), dim3(Team<T>::BLOCK), dyn, st, a);
+  hipLaunchKernelGGL((k_nuts_resident<T, R, QGL, LR>), dim3(grid), dim3(LR ? LR_BLOCK : Team<T>::BLOCK), dyn, st, a);
   return hipGetLastError();
 }
 // Team size: the smallest team that holds the chain (<= 4 elements per lane below a wave,
@@ -469,6 +586,7 @@ inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
 // control state wave-uniform (SGPRs, scalar branches).
 inline hipError_t launch_nuts_resident(const EngineArgs &a, hipStream_t st, int force_min_team = 0) {
   const long long D = a.D, C = a.C;
+  if (a.tkind == AEHMC_T_LINREG) return launch_nuts_resident_tr<64, 1, false, true>(a, st);
   if (D > 512) {
     if (D <= 1024) return launch_nuts_resident_tr<256, 4>(a, st);
     if (D <= 2048) return launch_nuts_resident_tr<256, 8>(a, st);
