@@ -52,8 +52,8 @@ struct aehmc_ctx {
   int64_t prof_n = 0;
   unsigned long long *d_flops = nullptr;  // algorithmic flops of the profiled launches
   // stream-K GEMM: persistent grid, partial-accumulator hand-off buffers
-  bool opt_streamk = true;
-  int sk_grid = 0;
+  int opt_streamk = 1;  // 0 off, 1 = 128x128 tiles (2 workgroups/CU), 2 = 128x256 tiles (1 workgroup/CU)
+  int sk_grid = 0, sk_grid_wide = 0;
   double *sk_partial = nullptr;
   int *sk_flags = nullptr;
   int sk_epoch = 0;
@@ -120,9 +120,10 @@ extern "C" int aehmc_create(aehmc_ctx **out, int device) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     int per_cu = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_nt_f64_streamk_kernel<true>, 256, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (gemm_nt_f64_streamk_kernel<true, 4>), 256, 0));
     if (per_cu > 2) per_cu = 2;
     ctx->sk_grid = (prop.multiProcessorCount * per_cu / 8) * 8;  // all workgroups co-resident
+    ctx->sk_grid_wide = (prop.multiProcessorCount / 8) * 8;       // 128 x 256 tiles: one workgroup per CU
     if (ctx->sk_grid > 0) {
       HIPCHK(hipMalloc((void **)&ctx->sk_partial, (size_t)ctx->sk_grid * 64 * 256 * sizeof(double)));
       HIPCHK(hipMalloc((void **)&ctx->sk_flags, ctx->sk_grid * sizeof(int)));
@@ -360,7 +361,7 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
     return 0;
   }
   if (!strcmp(name, "streamk")) {
-    ctx->opt_streamk = value != 0;
+    ctx->opt_streamk = (int)value;
     return 0;
   }
   if (!strcmp(name, "compact")) {
@@ -452,7 +453,7 @@ static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A
   const bool use_sk = ctx->opt_streamk && ctx->sk_grid > 0;
   HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st, row_idx, n_rows,
                             p ? ctx->d_flops : nullptr, (use_sk && mode == 0) ? &sk : nullptr, ctx->sk_grid,
-                            mode));
+                            mode, ctx->opt_streamk == 2 ? ctx->sk_grid_wide : 0));
   if (p) {
     HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
     ctx->prof_used += 2;

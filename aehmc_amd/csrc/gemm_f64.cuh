@@ -222,20 +222,25 @@ __device__ __forceinline__ void gemm_tile_coords(int t, int Tm, int Tn, int &tm,
   }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_streamk_kernel(
+// NJ = 4: 128 x 128 tiles, two workgroups per CU.  NJ = 8: 128 x 256 tiles, one workgroup per CU
+// whose four waves own 64 x 128 each (128 f64 accumulators per lane, in AGPRs): a third fewer
+// operand bytes and LDS fragment reads per MFMA.
+template <bool VEC, int NJ>
+__global__ __launch_bounds__(256, (NJ == 8 ? 1 : 2)) void gemm_nt_f64_streamk_kernel(
     int64_t M, int64_t N, int64_t K, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc,
     const int *__restrict__ row_idx, const int *__restrict__ n_rows,
     unsigned long long *__restrict__ flop_counter, GemmStreamK sk) {
-  __shared__ __attribute__((aligned(16))) double lds[2][2][GEMM_BM][GEMM_LDS];
+  constexpr int BN = NJ * 32, NB = BN / 128;  // NB: 128-row groups of the B tile
+  __shared__ __attribute__((aligned(16))) double ldsA[2][GEMM_BM][GEMM_LDS];
+  __shared__ __attribute__((aligned(16))) double ldsB[2][BN][GEMM_LDS];
   __shared__ int s_rows[GEMM_BM];
   if (n_rows) M = *n_rows;
   if (flop_counter && blockIdx.x == 0 && threadIdx.x == 0)
     atomicAdd(flop_counter, (unsigned long long)(2 * M * N * K));
   const int G = gridDim.x;                                     // multiple of 8
   const int bb = (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;  // an XCD owns a contiguous tile range
-  const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
+  const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + BN - 1) / BN);
   const long long T = (long long)Tm * Tn;
   if (T == 0) return;
   const int nk = (int)((K + GEMM_BK - 1) / GEMM_BK);
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_streamk_kernel(
   auto pass = [&](int t, int kb, int ke, int mode) {
     int tm, tn;
     gemm_tile_coords(t, Tm, Tn, tm, tn);
-    const int64_t m0 = (int64_t)tm * GEMM_BM, n0 = (int64_t)tn * GEMM_BN;
+    const int64_t m0 = (int64_t)tm * GEMM_BM, n0 = (int64_t)tn * BN;
     __syncthreads();  // previous pass is done with s_rows / LDS
     if (tid < GEMM_BM) {
       const int64_t r = m0 + tid;
@@ -257,8 +262,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_streamk_kernel(
     }
     __syncthreads();
     const int64_t a_row = s_rows[tid >> 1];
-    const int64_t b_row = (n0 + (tid >> 1)) < N ? n0 + (tid >> 1) : -1;
-    d4_t acc[4][4];
+    int64_t b_row[NB];
+#pragma unroll
+    for (int g = 0; g < NB; g++) b_row[g] = (n0 + g * 128 + (tid >> 1)) < N ? n0 + g * 128 + (tid >> 1) : -1;
+    d4_t acc[4][NJ];
     if (mode == 2) {
       if (tid == 0) {
         const long long t0 = clock64();
@@ -273,64 +280,71 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_streamk_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();
-      const double *src = sk.partial + (size_t)(bb - 1) * (64 * 256);
+      const double *src = sk.partial + (size_t)(bb - 1) * (NJ * 16 * 256);
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) acc[i][j][r] = src[((i * 4 + j) * 4 + r) * 256 + tid];
+          for (int r = 0; r < 4; r++) acc[i][j][r] = src[((i * NJ + j) * 4 + r) * 256 + tid];
     } else {
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NJ; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
     }
-    double ra[8], rb[8];
+    double ra[8], rb[NB][8];
     gemm_load_tile<VEC>(A, lda, a_row, (int64_t)kb * GEMM_BK, K, tid, ra);
-    gemm_load_tile<VEC>(B, ldb, b_row, (int64_t)kb * GEMM_BK, K, tid, rb);
+#pragma unroll
+    for (int g = 0; g < NB; g++) gemm_load_tile<VEC>(B, ldb, b_row[g], (int64_t)kb * GEMM_BK, K, tid, rb[g]);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      *reinterpret_cast<d2_t *>(&lds[0][0][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
-      *reinterpret_cast<d2_t *>(&lds[0][1][srow][scol + 2 * i]) = (d2_t){rb[2 * i], rb[2 * i + 1]};
+      *reinterpret_cast<d2_t *>(&ldsA[0][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
+#pragma unroll
+      for (int g = 0; g < NB; g++)
+        *reinterpret_cast<d2_t *>(&ldsB[0][g * 128 + srow][scol + 2 * i]) = (d2_t){rb[g][2 * i], rb[g][2 * i + 1]};
     }
     __syncthreads();
     for (int kt = kb; kt < ke; kt++) {
       const int st = (kt - kb) & 1;
       if (kt + 1 < ke) {
         gemm_load_tile<VEC>(A, lda, a_row, (int64_t)(kt + 1) * GEMM_BK, K, tid, ra);
-        gemm_load_tile<VEC>(B, ldb, b_row, (int64_t)(kt + 1) * GEMM_BK, K, tid, rb);
+#pragma unroll
+        for (int g = 0; g < NB; g++)
+          gemm_load_tile<VEC>(B, ldb, b_row[g], (int64_t)(kt + 1) * GEMM_BK, K, tid, rb[g]);
       }
 #pragma unroll
       for (int kk = 0; kk < GEMM_BK / 4; kk++) {
-        double a[4], b[4];
+        double a[4], b[NJ];
 #pragma unroll
-        for (int i = 0; i < 4; i++) a[i] = lds[st][0][wm * 64 + i * 16 + fr][kk * 4 + fk];
+        for (int i = 0; i < 4; i++) a[i] = ldsA[st][wm * 64 + i * 16 + fr][kk * 4 + fk];
 #pragma unroll
-        for (int j = 0; j < 4; j++) b[j] = lds[st][1][wn * 64 + j * 16 + fr][kk * 4 + fk];
+        for (int j = 0; j < NJ; j++) b[j] = ldsB[st][wn * (BN / 2) + j * 16 + fr][kk * 4 + fk];
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-          for (int j = 0; j < 4; j++)
+          for (int j = 0; j < NJ; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
       }
       if (kt + 1 < ke) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          *reinterpret_cast<d2_t *>(&lds[st ^ 1][0][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
-          *reinterpret_cast<d2_t *>(&lds[st ^ 1][1][srow][scol + 2 * i]) = (d2_t){rb[2 * i], rb[2 * i + 1]};
+          *reinterpret_cast<d2_t *>(&ldsA[st ^ 1][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
+#pragma unroll
+          for (int g = 0; g < NB; g++)
+            *reinterpret_cast<d2_t *>(&ldsB[st ^ 1][g * 128 + srow][scol + 2 * i]) = (d2_t){rb[g][2 * i], rb[g][2 * i + 1]};
         }
       }
       __syncthreads();
     }
     if (mode == 1) {
-      double *dst = sk.partial + (size_t)bb * (64 * 256);
+      double *dst = sk.partial + (size_t)bb * (NJ * 16 * 256);
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) dst[((i * 4 + j) * 4 + r) * 256 + tid] = acc[i][j][r];
+          for (int r = 0; r < 4; r++) dst[((i * NJ + j) * 4 + r) * 256 + tid] = acc[i][j][r];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {
@@ -342,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_streamk_kernel(
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int64_t col = n0 + wn * 64 + j * 16 + fr;
+        for (int j = 0; j < NJ; j++) {
+          const int64_t col = n0 + wn * (BN / 2) + j * 16 + fr;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int64_t row = s_rows[wm * 64 + i * 16 + fk + 4 * r];
@@ -357,10 +371,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_streamk_kernel(
   const long long W = (total + G - 1) / G;
   // Whole tiles, strided over the grid (the one-tile-per-workgroup order, which keeps the
   // workgroups of an XCD on one column panel at a time) when there are fewer tiles than
-  // workgroups or when the last round is nearly full anyway; contiguous (tile, k) ranges cost
-  // L2 locality (measured: -11 % at 4.94 rounds) and only pay when a round would be wasted.
+  // workgroups or when the last round is full to within 4 %; contiguous (tile, k) ranges cost
+  // L2 locality (measured: -11 % at 4.94 rounds) and only pay when part of a round would be wasted.
   const long long rounds = (T + G - 1) / G;
-  if (W < nk || (rounds * G - T) * 100 < 15 * (long long)G) {
+  if (W < nk || (rounds * G - T) * 100 < 4 * (long long)G) {
     for (long long t = blockIdx.x; t < T; t += G) {
       // same tile -> XCD assignment as gemm_tile_of_block within each round
       const long long base = (t / G) * G, left = (T - base < G) ? T - base : G;
@@ -369,7 +383,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_streamk_kernel(
     }
     return;
   }
-  const long long it0 = (long long)bb * W, it1 = (it0 + W < total) ? it0 + W : total;
+  // Hybrid schedule: all but the last 1..2 rounds run as whole tiles in the strided order above
+  // (an XCD's workgroups share operand panels in L2); only the remaining G..2G-1 tiles are cut
+  // into even contiguous (tile, k) ranges, so every workgroup ends at the same time and a tile
+  // is shared by at most three workgroups.
+  const long long Tdp = (T / G - 1) * G;  // >= 0: the launcher requires T >= G
+  for (long long t = blockIdx.x; t < Tdp; t += G) {
+    const long long base = (t / G) * G, chunk = G / 8, slot = (t - base) / 8, x = (t - base) % 8;
+    pass((int)(base + x * chunk + slot), 0, nk, 0);
+  }
+  const long long total_sk = (T - Tdp) * nk, Wsk = (total_sk + G - 1) / G;
+  const long long it0 = Tdp * nk + (long long)bb * Wsk;
+  const long long it1 = (it0 + Wsk < total) ? it0 + Wsk : total;
   if (it0 >= it1) return;
   const int tf = (int)(it0 / nk), ks = (int)(it0 % nk);
   const int tl = (int)((it1 - 1) / nk), ke = (int)((it1 - 1) % nk) + 1;
@@ -385,7 +410,8 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
                                      int64_t ldc, hipStream_t stream,
                                      const int *row_idx = nullptr, const int *n_rows = nullptr,
                                      unsigned long long *flop_counter = nullptr,
-                                     const GemmStreamK *sk = nullptr, int sk_grid = 0, int mode = 0) {
+                                     const GemmStreamK *sk = nullptr, int sk_grid = 0, int mode = 0,
+                                     int sk_grid_wide = 0) {
   if (M <= 0 || N <= 0) return hipSuccess;
   const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
   const int total = Tm * Tn;
@@ -402,8 +428,13 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
                        B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);
     return hipGetLastError();
   }
+  if (vec && sk && sk_grid_wide > 0 && Tm * (int)((N + 255) / 256) >= sk_grid_wide) {  // 128 x 256 tiles
+    hipLaunchKernelGGL((gemm_nt_f64_streamk_kernel<true, 8>), dim3(sk_grid_wide), dim3(256), 0, stream, M, N, K,
+                       A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter, *sk);
+    return hipGetLastError();
+  }
   if (vec && sk && sk_grid > 0 && total >= sk_grid) {  // enough tiles for an even (tile, k) split
-    hipLaunchKernelGGL(gemm_nt_f64_streamk_kernel<true>, dim3(sk_grid), dim3(256), 0, stream, M, N, K,
+    hipLaunchKernelGGL((gemm_nt_f64_streamk_kernel<true, 4>), dim3(sk_grid), dim3(256), 0, stream, M, N, K,
                        A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter, *sk);
     return hipGetLastError();
   }

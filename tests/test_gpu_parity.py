@@ -79,14 +79,17 @@ def test_gemm_f64_mfma(eng, M, N, K):
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("M,N,K", [(1100, 8000, 200), (1408, 6000, 96), (2900, 2560, 1000), (4096, 1300, 50)])
-def test_gemm_streamk_bitwise_equals_tiled(eng, M, N, K):
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(1100, 8000, 200), (1408, 6000, 96), (2900, 2560, 1000), (4096, 1300, 50),
+                                   (3000, 9000, 40)])
+def test_gemm_streamk_bitwise_equals_tiled(eng, M, N, K, mode):
     """Stream-K splits tiles between neighbouring workgroups but continues the same k-chain
-    from the published partial accumulators: bit-identical to the one-tile-per-workgroup kernel.
-    Also with a compacted (gathered) row list."""
+    from the published partial accumulators: bit-identical to the one-tile-per-workgroup kernel,
+    in the whole-tile rounds, in the split tail and in the strided mode alike (mode 2: the
+    128 x 256-tile variant).  Also with a compacted (gathered) row list."""
     r = np.random.default_rng(M + N + K)
     A, B = dev(r.normal(size=(M, K))), dev(r.normal(size=(N, K)))
-    eng.set_option("streamk", 1)
+    eng.set_option("streamk", mode)
     out1 = eng.gemm_nt(A, B)
     out1b = eng.gemm_nt(A, B)   # second launch: new epoch, flags of the first one are stale
     eng.set_option("streamk", 0)
@@ -131,12 +134,14 @@ def test_g2_g3_regression_on_gpu(regression_data):
     assert info.acceptance_probability.item() == 1.0 and not info.is_diverging.item()
 
 
-@pytest.mark.parametrize("metric_kind", ["diag", "dense"])
-def test_regression_nuts_matches_oracle(regression_data, metric_kind):
-    """NUTS on the notebook's regression posterior (notebook cell 36 settings), 12 chains."""
+@pytest.mark.parametrize("metric_kind,C,resident", [("diag", 12, 2), ("diag", 6, 2), ("diag", 5, 0), ("dense", 12, 2)])
+def test_regression_nuts_matches_oracle(eng, regression_data, metric_kind, C, resident):
+    """NUTS on the notebook's regression posterior (notebook cell 36 settings).  Diagonal metric:
+    the workgroup-cooperative resident kernel (4 chains per workgroup; C = 6 leaves a workgroup
+    half empty) or, with resident_nuts=0, the lock-step kernels; dense metric: lock-step."""
     from aehmc_amd import RandomStream, nuts, targets
     X, y = regression_data
-    C = 12
+    eng.set_option("resident_nuts", resident)
     r = np.random.default_rng(2)
     tgt, otgt = targets.LinearRegression(X, y), co.Target(co.T_LINREG, 2, X=X, y=y)
     imm = np.array([2.13e-05, 4.43e-05])
@@ -156,6 +161,7 @@ def test_regression_nuts_matches_oracle(regression_data, metric_kind):
         # sums over 1e4 rows in a different order: 1e-9 on the state, exact discrete outputs
         check_state(info, q, U, g, res)
         state = info.state._replace(momentum=None)
+    eng.set_option("resident_nuts", 2)
 
 
 # ------------------------------------------------------------------ helpers
