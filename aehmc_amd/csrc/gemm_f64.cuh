@@ -188,18 +188,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(
 }
 
 // ---- stream-K variant -------------------------------------------------------------
-// A persistent grid of G = 2 x #CU workgroups splits the (tile, k) iteration space evenly,
-// so a launch whose tile count is not a multiple of G (e.g. 2900 live chains: 1817 tiles =
-// 3.55 rounds of 512) no longer pays for a partly empty last round.  A tile cut between
-// two neighbouring workgroups is summed IN ORDER: the workgroup that owns the head of the
-// tile (k = 0 .. ke) computes it first and publishes its accumulators; the owner of the tail
-// loads them as its initial accumulator and continues the same k-chain -- bitwise the same
-// result as the unsplit kernel, no atomics.  Hand-off: plain stores -> s_waitcnt vmcnt(0)
-// -> barrier -> agent-scope release -> flag; consumer: relaxed poll -> agent-scope acquire
-// -> barrier -> plain loads (cdna_hip_programming.md, Guideline 16).  Every spin is bounded.
-// When fewer than G tiles exist (W < nk) the grid simply strides over whole tiles.
+// A persistent grid of G workgroups (2 per CU).  A launch whose tile count is not a multiple
+// of G (e.g. 2900 live chains: 1817 tiles = 3.55 rounds of 512) would pay for a partly empty
+// last round; here all but the last 1..2 rounds run as whole tiles in the XCD-aware strided
+// order and the remaining G..2G-1 tiles are cut into even contiguous (tile, k) ranges, so every
+// workgroup finishes together.  A tile cut between two neighbouring workgroups is summed IN
+// ORDER: the workgroup that owns the head of the tile (k = 0 .. ke) computes it first and
+// publishes its accumulators; the owner of the tail loads them as its initial accumulator and
+// continues the same k-chain -- bitwise the same result as the unsplit kernel, no atomics.
+// Hand-off: plain stores -> s_waitcnt vmcnt(0) -> barrier -> agent-scope release -> flag;
+// consumer: relaxed poll -> agent-scope acquire -> barrier -> plain loads
+// (cdna_hip_programming.md, Guideline 16).  Every spin is bounded.  When fewer than G tiles
+// exist (W < nk), or the last round is full to within 4 %, the grid strides over whole tiles.
 struct GemmStreamK {
-  double *partial;  // [G][64][256] accumulators of head segments
+  double *partial;  // [G][16 * NJ][256] accumulators of head segments
   int *flags;       // [G] epoch of the last publish
   int *err;         // set to 1 if a bounded spin expired (host-visible)
   int epoch;

@@ -1,5 +1,7 @@
 // Fused, register-resident HMC transition (gfx950): one chain per wavefront, the whole
-// hmc.new_kernel(...)(state, eps, imm, L) call in ONE launch.
+// hmc.new_kernel(...)(state, eps, imm, L) call in ONE launch (k_hmc_fused, D <= 1024); for
+// 1024 < D <= 10240 one workgroup per chain with the state in VGPRs, fed by a momentum
+// pre-pass (k_hmc_wide, further down).
 //
 // Covers diagonal / scalar metrics with coordinate-wise targets and D <= 1024 (config
 // "100-dim isotropic Gaussian, HMC with 32 leapfrog steps, 4096 chains").  Lane l keeps
