@@ -90,3 +90,45 @@ def test_error_paths():
     bad = nuts.new_kernel(RandomStream(seeds=[0, 1]), tgt, max_num_expansions=0)
     with pytest.raises(EngineError):
         bad(state, 0.1, np.ones(3))
+
+
+# ------------------------------------------------------------------ per-chain parameters
+@pytest.mark.parametrize("kind,D", [("hmc", 70), ("hmc", 1500), ("nuts", 70), ("nuts", 600), ("nuts-linreg", 2)])
+def test_per_chain_parameters_equal_single_chain_runs(kind, D):
+    """PerChain step sizes and diagonal inverse mass matrices (what per-chain window adaptation
+    produces; the reference runs one chain per compiled function): chain c of a batch equals
+    chain c run alone with its own scalar step size and vector -- on the fused / wide HMC
+    kernels, the lock-step and resident NUTS kernels and the regression workgroups."""
+    from aehmc_amd import PerChain, RandomStream, hmc, nuts, targets
+    r = np.random.default_rng(D)
+    C = 5
+    if kind == "nuts-linreg":
+        X = r.normal(size=4000)
+        tgt = targets.LinearRegression(X, 3 * X + r.normal(size=4000))
+        q0 = np.array([3.0, 0.0]) + 0.01 * r.normal(size=(C, 2))
+        eps = 0.02 * (0.5 + r.random(C))
+        imm = 1e-3 * (0.5 + r.random((C, 2)))
+    else:
+        tgt = targets.DiagGaussian(r.normal(size=D), 0.5 + r.random(D))
+        q0 = r.normal(size=(C, D))
+        eps = 0.3 / D ** 0.25 * (0.5 + r.random(C))
+        imm = 0.5 + r.random((C, D))
+    seeds = [900 + c for c in range(C)]
+    mod = hmc if kind == "hmc" else nuts
+    extra = (9,) if kind == "hmc" else ()
+
+    def run(seed_list, q, e, m):
+        kernel = mod.new_kernel(RandomStream(seeds=seed_list), tgt)
+        state = mod.new_state(torch.as_tensor(q, device="cuda"), tgt)
+        outs = []
+        for _ in range(3):
+            info, _ = kernel(state, e, m, *extra)
+            state = info.state._replace(momentum=None)
+            outs.append((info.state.position.clone(), info.acceptance_probability.clone()))
+        return outs
+
+    batch = run(seeds, q0, PerChain(torch.as_tensor(eps, device="cuda")), PerChain(torch.as_tensor(imm, device="cuda")))
+    for c in range(C):
+        single = run([seeds[c]], q0[c:c + 1], float(eps[c]), torch.as_tensor(imm[c], device="cuda"))
+        for (qb, ab), (qs, a_s) in zip(batch, single):
+            assert torch.equal(qb[c], qs[0]) and torch.equal(ab[c], a_s[0])
