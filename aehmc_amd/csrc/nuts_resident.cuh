@@ -186,7 +186,6 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
   kd = 0.0;
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    const long long i = (long long)t + (long long)T * r;
     if (!TM::SUB) p[r] = ok[r] ? AT(a.zbuf, r) : 0.0;
     pb[r] = 0.0;
     if (ok[r]) {
@@ -362,7 +361,6 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 #pragma unroll
       for (int r = 0; r < R; r++) {
         if (ok[r]) {
-          const long long i = (long long)t + (long long)T * r;
           pb[r] = (step == 0) ? p[r] : pb[r] + p[r];
           if (even) {
             ckp[EI(r)] = p[r];
@@ -407,7 +405,6 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 #pragma unroll
           for (int r = 0; r < R; r++) {
             if (ok[r]) {
-              const long long i = (long long)t + (long long)T * r;
               double pl = kp[EI(r)], pr = p[r];
               double vl = IMM(r) * pl, vr = IMM(r) * pr;
               double sub = pb[r] - ks[EI(r)] + pl;
@@ -431,7 +428,6 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 #pragma unroll
       for (int r = 0; r < R; r++) {
         if (ok[r]) {
-          const long long i = (long long)t + (long long)T * r;
           AT(pick2(a.slot_q, s), r) = QGET(r);
           AT(pick2(a.slot_p, s), r) = p[r];
           AT(pick2(a.slot_g, s), r) = GGET(r);
@@ -462,7 +458,6 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 #pragma unroll
       for (int r = 0; r < R; r++) {
         if (ok[r]) {
-          const long long i = (long long)t + (long long)T * r;
           double pc = p[r], po = AT(pick2(a.end_p, oth), r);
           double vc = IMM(r) * pc, vo = IMM(r) * po;
           double s = AT(a.psum, r) + pb[r];
@@ -505,7 +500,6 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 #pragma unroll
         for (int r = 0; r < R; r++) {
           if (ok[r]) {
-            const long long i = (long long)t + (long long)T * r;
             AT(a.q, r) = AT(pick2(a.slot_q, s), r);
             AT(a.g, r) = AT(pick2(a.slot_g, s), r);
             if (a.out.momentum) AT(a.out.momentum, r) = AT(pick2(a.slot_p, s), r);
@@ -533,7 +527,6 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 #pragma unroll
           for (int r = 0; r < R; r++) {
             if (ok[r]) {
-              const long long i = (long long)t + (long long)T * r;
               QSET(r, AT(pick2(a.end_q, go_right), r));
               p[r] = AT(pick2(a.end_p, go_right), r);
               GSET(r, AT(pick2(a.end_g, go_right), r));
