@@ -52,7 +52,7 @@ struct aehmc_ctx {
   int64_t prof_n = 0;
   unsigned long long *d_flops = nullptr;  // algorithmic flops of the profiled launches
   // stream-K GEMM: persistent grid, partial-accumulator hand-off buffers
-  int opt_streamk = 1;  // 0 off, 1 = 128x128 tiles (2 workgroups/CU), 2 = 128x256 tiles (1 workgroup/CU)
+  int opt_streamk = 2;  // 0 off, 1 = 128x128 tiles (2 workgroups/CU), 2 = 128x256 tiles, software-pipelined (1 workgroup/CU)
   int sk_grid = 0, sk_grid_wide = 0;
   double *sk_partial = nullptr;
   int *sk_flags = nullptr;

@@ -18,6 +18,7 @@
 // then private to one XCD's L2 while the A panels are shared chip-wide through MALL.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace aehmc {
@@ -295,50 +296,164 @@ __global__ __launch_bounds__(256, (NJ == 8 ? 1 : 2)) void gemm_nt_f64_streamk_ke
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
     }
-    double ra[8], rb[NB][8];
-    gemm_load_tile<VEC>(A, lda, a_row, (int64_t)kb * GEMM_BK, K, tid, ra);
+    if constexpr (NJ == 8) {
+      // ---- software-pipelined K loop for the one-wave-per-SIMD tile (K % 16 == 0, 16-byte
+      // aligned operands: checked by the launcher).  Nothing hides a stall here, so every
+      // non-MFMA instruction is placed between MFMAs: fragments of k-step kk+1 are read while
+      // the MFMAs of kk run, the next K-tile is fetched during kk = 0, stored to the other LDS
+      // stage during kk = 2, and the barrier sits before kk = 3, whose MFMAs cover the first
+      // fragment reads of the next tile.  Loads are branch-free: rows past M / N re-read a
+      // valid row (their results are never stored), the prefetch index is clamped.
+      const int64_t a_ld = a_row >= 0 ? a_row : (int64_t)s_rows[0];
+      const double *pa = A + a_ld * lda + (tid & 1) * 8;
+      const double *pb[NB];
 #pragma unroll
-    for (int g = 0; g < NB; g++) gemm_load_tile<VEC>(B, ldb, b_row[g], (int64_t)kb * GEMM_BK, K, tid, rb[g]);
+      for (int g = 0; g < NB; g++) pb[g] = B + (b_row[g] >= 0 ? b_row[g] : N - 1) * ldb + (tid & 1) * 8;
+      // Three register sets of global prefetch, used in rotation: a set is consumed (stored to LDS)
+      // in phase 2 of every third tile and refilled, three loads per phase, over the four phases
+      // that follow -- every load has at least two whole K-tiles (~8 us) to arrive, and a workgroup's demand
+      // on L2 / HBM is even in time instead of a burst per tile (with bursts, the slowest of the
+      // four waves stalls the barrier of every tile: 67 instead of 74 TFLOP/s).
+      constexpr int NL = 4 + 4 * NB;  // 16-byte loads per thread and K-tile (12)
+      d2_t gs[3][NL];
+      auto gload1 = [&](auto set_tag, int l, int kt) {  // load number l of tile kt into set
+        constexpr int S = decltype(set_tag)::value;
+        const int ktc = kt < ke ? kt : ke - 1;
+        if (l < 4) gs[S][l] = *reinterpret_cast<const d2_t *>(pa + (int64_t)ktc * GEMM_BK + 2 * l);
+        else gs[S][l] = *reinterpret_cast<const d2_t *>(pb[(l - 4) / 4] + (int64_t)ktc * GEMM_BK + 2 * ((l - 4) % 4));
+      };
+      auto lstore = [&](auto set_tag, int st) {
+        constexpr int S = decltype(set_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      *reinterpret_cast<d2_t *>(&ldsA[0][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
+        for (int i = 0; i < 4; i++) {
+          *reinterpret_cast<d2_t *>(&ldsA[st][srow][scol + 2 * i]) = gs[S][i];
 #pragma unroll
-      for (int g = 0; g < NB; g++)
-        *reinterpret_cast<d2_t *>(&ldsB[0][g * 128 + srow][scol + 2 * i]) = (d2_t){rb[g][2 * i], rb[g][2 * i + 1]};
-    }
-    __syncthreads();
-    for (int kt = kb; kt < ke; kt++) {
-      const int st = (kt - kb) & 1;
-      if (kt + 1 < ke) {
-        gemm_load_tile<VEC>(A, lda, a_row, (int64_t)(kt + 1) * GEMM_BK, K, tid, ra);
+          for (int g = 0; g < NB; g++) *reinterpret_cast<d2_t *>(&ldsB[st][g * 128 + srow][scol + 2 * i]) = gs[S][4 + 4 * g + i];
+        }
+      };
+      double fa[2][4], fb[2][NJ];
+      auto fread = [&](int buf, int st, int kk) {
 #pragma unroll
-        for (int g = 0; g < NB; g++)
-          gemm_load_tile<VEC>(B, ldb, b_row[g], (int64_t)(kt + 1) * GEMM_BK, K, tid, rb[g]);
-      }
+        for (int i = 0; i < 4; i++) fa[buf][i] = ldsA[st][wm * 64 + i * 16 + fr][kk * 4 + fk];
 #pragma unroll
-      for (int kk = 0; kk < GEMM_BK / 4; kk++) {
-        double a[4], b[NJ];
-#pragma unroll
-        for (int i = 0; i < 4; i++) a[i] = ldsA[st][wm * 64 + i * 16 + fr][kk * 4 + fk];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) b[j] = ldsB[st][wn * (BN / 2) + j * 16 + fr][kk * 4 + fk];
+        for (int j = 0; j < NJ; j++) fb[buf][j] = ldsB[st][wn * (BN / 2) + j * 16 + fr][kk * 4 + fk];
+      };
+      auto mfmas = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
           for (int j = 0; j < NJ; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+      };
+      // scheduling recipe of one phase: n_a x {1 MFMA, 1 op of class a}, then n_b x {k MFMA, 1 op
+      // of class b} spread over the remaining MFMAs
+#define GEMM_SCHED(mask_a, n_a, mask_b, n_b)                                       \
+  _Pragma("unroll") for (int z = 0; z < (n_a); z++) {                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+    __builtin_amdgcn_sched_group_barrier((mask_a), 1, 0);                          \
+  }                                                                                \
+  _Pragma("unroll") for (int z = 0; z < (n_b); z++) {                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, (4 * NJ - (n_a)) / ((n_b) + 1), 0); \
+    __builtin_amdgcn_sched_group_barrier((mask_b), 1, 0);                          \
+  }                                                                                \
+  __builtin_amdgcn_sched_group_barrier(0x008, 4 * NJ - (n_a) - (n_b) * ((4 * NJ - (n_a)) / ((n_b) + 1)), 0);
+      constexpr int Q = NL / 4;  // loads per phase
+      using S0 = std::integral_constant<int, 0>;
+      using S1 = std::integral_constant<int, 1>;
+      using S2 = std::integral_constant<int, 2>;
+      // prologue: tile kb -> LDS stage 0 (through set 0); tile kb+1 -> set 0, tile kb+2 -> set 1,
+      // first quarter of tile kb+3 -> set 2
+#pragma unroll
+      for (int l = 0; l < NL; l++) gload1(S0{}, l, kb);
+      lstore(S0{}, 0);
+#pragma unroll
+      for (int l = 0; l < NL; l++) gload1(S0{}, l, kb + 1);
+#pragma unroll
+      for (int l = 0; l < NL; l++) gload1(S1{}, l, kb + 2);
+#pragma unroll
+      for (int l = 0; l < Q; l++) gload1(S2{}, l, kb + 3);
+      __syncthreads();
+      fread(0, 0, 0);
+      // one K-tile: `cons` holds tile kt+1 and is stored to LDS in phase 2; `fill` (the set consumed
+      // one tile earlier) takes the last three quarters of tile kt+3 in phases 0-2; after its store
+      // `cons` takes the first quarter of tile kt+4
+      auto tile = [&](auto cons, auto fill, int kt) {
+        const int st = (kt - kb) & 1;
+#pragma unroll
+        for (int l = 0; l < Q; l++) gload1(fill, Q + l, kt + 3);  // phase 0
+        fread(1, st, 1);
+        mfmas(0);
+        GEMM_SCHED(0x100, 4 + NJ, 0x020, Q)
+#pragma unroll
+        for (int l = 0; l < Q; l++) gload1(fill, 2 * Q + l, kt + 3);  // phase 1
+        fread(0, st, 2);
+        mfmas(1);
+        GEMM_SCHED(0x100, 4 + NJ, 0x020, Q)
+        lstore(cons, st ^ 1);  // phase 2
+        fread(1, st, 3);
+#pragma unroll
+        for (int l = 0; l < Q; l++) gload1(fill, 3 * Q + l, kt + 3);
+        mfmas(0);
+        GEMM_SCHED(0x200, NL, 0x100, 4 + NJ)
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < Q; l++) gload1(cons, l, kt + 4);  // phase 3
+        fread(0, st ^ 1, 0);
+        mfmas(1);
+        GEMM_SCHED(0x100, 4 + NJ, 0x020, Q)
+      };
+      for (int kt = kb; kt < ke; kt += 3) {
+        tile(S0{}, S2{}, kt);
+        if (kt + 1 < ke) tile(S1{}, S0{}, kt + 1);
+        if (kt + 2 < ke) tile(S2{}, S1{}, kt + 2);
       }
-      if (kt + 1 < ke) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          *reinterpret_cast<d2_t *>(&ldsA[st ^ 1][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
-#pragma unroll
-          for (int g = 0; g < NB; g++)
-            *reinterpret_cast<d2_t *>(&ldsB[st ^ 1][g * 128 + srow][scol + 2 * i]) = (d2_t){rb[g][2 * i], rb[g][2 * i + 1]};
-        }
+#undef GEMM_SCHED
+    } else {
+    double ra[8], rb[NB][8];
+      gemm_load_tile<VEC>(A, lda, a_row, (int64_t)kb * GEMM_BK, K, tid, ra);
+  #pragma unroll
+      for (int g = 0; g < NB; g++) gemm_load_tile<VEC>(B, ldb, b_row[g], (int64_t)kb * GEMM_BK, K, tid, rb[g]);
+  #pragma unroll
+      for (int i = 0; i < 4; i++) {
+        *reinterpret_cast<d2_t *>(&ldsA[0][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
+  #pragma unroll
+        for (int g = 0; g < NB; g++)
+          *reinterpret_cast<d2_t *>(&ldsB[0][g * 128 + srow][scol + 2 * i]) = (d2_t){rb[g][2 * i], rb[g][2 * i + 1]};
       }
       __syncthreads();
-    }
+      for (int kt = kb; kt < ke; kt++) {
+        const int st = (kt - kb) & 1;
+        if (kt + 1 < ke) {
+          gemm_load_tile<VEC>(A, lda, a_row, (int64_t)(kt + 1) * GEMM_BK, K, tid, ra);
+  #pragma unroll
+          for (int g = 0; g < NB; g++)
+            gemm_load_tile<VEC>(B, ldb, b_row[g], (int64_t)(kt + 1) * GEMM_BK, K, tid, rb[g]);
+        }
+  #pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 4; kk++) {
+          double a[4], b[NJ];
+  #pragma unroll
+          for (int i = 0; i < 4; i++) a[i] = ldsA[st][wm * 64 + i * 16 + fr][kk * 4 + fk];
+  #pragma unroll
+          for (int j = 0; j < NJ; j++) b[j] = ldsB[st][wn * (BN / 2) + j * 16 + fr][kk * 4 + fk];
+  #pragma unroll
+          for (int i = 0; i < 4; i++)
+  #pragma unroll
+            for (int j = 0; j < NJ; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < ke) {
+  #pragma unroll
+          for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<d2_t *>(&ldsA[st ^ 1][srow][scol + 2 * i]) = (d2_t){ra[2 * i], ra[2 * i + 1]};
+  #pragma unroll
+            for (int g = 0; g < NB; g++)
+              *reinterpret_cast<d2_t *>(&ldsB[st ^ 1][g * 128 + srow][scol + 2 * i]) = (d2_t){rb[g][2 * i], rb[g][2 * i + 1]};
+          }
+        }
+        __syncthreads();
+      }
+}
     if (mode == 1) {
       double *dst = sk.partial + (size_t)bb * (NJ * 16 * 256);
 #pragma unroll
@@ -430,7 +545,7 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
                        B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);
     return hipGetLastError();
   }
-  if (vec && sk && sk_grid_wide > 0 && Tm * (int)((N + 255) / 256) >= sk_grid_wide) {  // 128 x 256 tiles
+  if (vec && sk && sk_grid_wide > 0 && K % GEMM_BK == 0 && Tm * (int)((N + 255) / 256) >= sk_grid_wide) {  // 128 x 256 tiles
     hipLaunchKernelGGL((gemm_nt_f64_streamk_kernel<true, 8>), dim3(sk_grid_wide), dim3(256), 0, stream, M, N, K,
                        A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter, *sk);
     return hipGetLastError();

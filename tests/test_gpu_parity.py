@@ -94,7 +94,7 @@ def test_gemm_streamk_bitwise_equals_tiled(eng, M, N, K, mode):
     out1b = eng.gemm_nt(A, B)   # second launch: new epoch, flags of the first one are stale
     eng.set_option("streamk", 0)
     out0 = eng.gemm_nt(A, B)
-    eng.set_option("streamk", 1)
+    eng.set_option("streamk", 2)
     assert torch.equal(out1, out0) and torch.equal(out1b, out0)
     np.testing.assert_allclose(out1.cpu().numpy(), A.cpu().numpy() @ B.cpu().numpy().T, rtol=1e-12,
                                atol=1e-12 * np.sqrt(K))
