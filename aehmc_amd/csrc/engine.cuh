@@ -152,6 +152,35 @@ __device__ __forceinline__ double vel_diag(const EngineArgs &a, long long c, lon
   return a.imm[c * a.imm_cs + (a.met_ndim == 0 ? 0 : i)] * p;
 }
 
+// One wavefront's pass over the D elements of its chain, four elements per lane in flight:
+// `load(i)` returns what element i needs from memory, `use(i, loaded)` computes and stores.
+// All loads of a batch are issued before its first store (the pointers in EngineArgs may
+// alias as far as the compiler knows, so a plain loop waits for every load before the next
+// store and streams at a quarter of HBM speed).  Each lane still visits its elements in
+// ascending order: sums are bit-identical to the plain loop.
+template <class Load, class Use>
+__device__ __forceinline__ void wave_pass(long long D, int lane, Load load, Use use) {
+  constexpr int UN = 4;
+  for (long long i0 = lane; i0 < D; i0 += 64 * UN) {
+    decltype(load(0LL)) vals[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long long i = i0 + 64 * u;
+      vals[u] = load(i < D ? i : i0);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long long i = i0 + 64 * u;
+      if (i < D) use(i, vals[u]);
+    }
+  }
+}
+struct Ld2 { double a, b; };
+struct Ld3 { double a, b, c; };
+struct Ld4 { double a, b, c, d; };
+struct Ld5 { double a, b, c, d, e; };
+struct Ld6 { double a, b, c, d, e, f; };
+
 // ---------------------------------------------------------------------------------
 // Leapfrog stages (integrators.py:54-73).  DO1: p_half = p - (0.5 eps) g.
 // DO2: q' = q + (1 eps) v_half, then the target at q' (coordinate-wise targets inline;
@@ -212,28 +241,39 @@ __device__ __forceinline__ bool leap_linear(const EngineArgs &a, long long c, in
   const bool elem = target_is_elem(a.tkind);
   const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
   double usum = 0.0;
-  for (long long i = lane; i < a.D; i += 64) {
-    if (PHASE == 12) {
-      double p = a.cur_p[row + i] - b * a.cur_g[row + i];
-      double v = a.cur_v[row + i] - b * a.cur_w[row + i];
-      a.cur_p[row + i] = p;
-      a.cur_v[row + i] = v;
-      double q = a.cur_q[row + i] + aa * v;
-      a.cur_q[row + i] = q;
-      if (elem) {
-        double u, gnew;
-        target_elem(a, i, q, u, gnew);
-        usum += u;
-        a.cur_g[row + i] = gnew;
-      } else if (tdense) {
-        a.rbuf[row + i] = q - a.mu[i];
-      }
-    } else {
-      double gi = a.cur_g[row + i];
-      if (tdense) usum += a.rbuf[row + i] * gi;
-      a.cur_p[row + i] = a.cur_p[row + i] - b * gi;
-      a.cur_v[row + i] = a.cur_v[row + i] - b * a.cur_w[row + i];
-    }
+  if (PHASE == 12) {
+    wave_pass(a.D, lane,
+              [&](long long i) {
+                return Ld6{a.cur_p[row + i], a.cur_g[row + i], a.cur_v[row + i], a.cur_w[row + i], a.cur_q[row + i],
+                           tdense ? a.mu[i] : 0.0};
+              },
+              [&](long long i, const Ld6 &x) {
+                double p = x.a - b * x.b;
+                double v = x.c - b * x.d;
+                a.cur_p[row + i] = p;
+                a.cur_v[row + i] = v;
+                double q = x.e + aa * v;
+                a.cur_q[row + i] = q;
+                if (elem) {
+                  double u, gnew;
+                  target_elem(a, i, q, u, gnew);
+                  usum += u;
+                  a.cur_g[row + i] = gnew;
+                } else if (tdense) {
+                  a.rbuf[row + i] = q - x.f;
+                }
+              });
+  } else {
+    wave_pass(a.D, lane,
+              [&](long long i) {
+                return Ld5{a.cur_g[row + i], tdense ? a.rbuf[row + i] : 0.0, a.cur_p[row + i], a.cur_v[row + i],
+                           a.cur_w[row + i]};
+              },
+              [&](long long i, const Ld5 &x) {
+                if (tdense) usum += x.b * x.a;
+                a.cur_p[row + i] = x.c - b * x.a;
+                a.cur_v[row + i] = x.d - b * x.e;
+              });
   }
   if ((PHASE == 12 && elem) || (PHASE == 3 && tdense)) {
     U_out = target_finish(a, wave_sum(usum));
@@ -397,18 +437,22 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
   double *cks = a.cks + ((size_t)tmax * a.C + c) * a.D;
   double *ckv = MET_DENSE ? a.ckv + ((size_t)tmax * a.C + c) * a.D : nullptr;
   double kd = 0.0;
-  for (long long i = lane; i < a.D; i += 64) {
-    double p = a.cur_p[row + i];
-    double v = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, c, i, p);
-    kd += v * p;
-    double s = (step == 0) ? p : a.psub[row + i] + p;  // trajectory.py:278,243
-    a.psub[row + i] = s;
-    if (even) {  // termination.py:115-124
-      ckp[i] = p;
-      cks[i] = s;
-      if (MET_DENSE) ckv[i] = v;
-    }
-  }
+  wave_pass(a.D, lane,
+            [&](long long i) {
+              return Ld3{a.cur_p[row + i], MET_DENSE ? a.cur_v[row + i] : 0.0, step == 0 ? 0.0 : a.psub[row + i]};
+            },
+            [&](long long i, const Ld3 &x) {
+              double p = x.a;
+              double v = MET_DENSE ? x.b : vel_diag(a, c, i, p);
+              kd += v * p;
+              double s = (step == 0) ? p : x.c + p;  // trajectory.py:278,243
+              a.psub[row + i] = s;
+              if (even) {  // termination.py:115-124
+                ckp[i] = p;
+                cks[i] = s;
+                if (MET_DENSE) ckv[i] = v;
+              }
+            });
   kd = wave_sum(kd);
   ct.tmin = tmin;
   ct.tmax = tmax;
@@ -450,15 +494,20 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
         const double *ks = a.cks + ((size_t)idx * a.C + c) * a.D;
         const double *kv = MET_DENSE ? a.ckv + ((size_t)idx * a.C + c) * a.D : nullptr;
         double d_l = 0.0, d_r = 0.0;
-        for (long long i = lane; i < a.D; i += 64) {
-          double pl = kp[i], pr = a.cur_p[row + i];
-          double vl = MET_DENSE ? kv[i] : vel_diag(a, c, i, pl);
-          double vr = MET_DENSE ? a.cur_v[row + i] : vel_diag(a, c, i, pr);
-          double sub = a.psub[row + i] - ks[i] + pl;
-          double rho = sub - (pr + pl) / 2;
-          d_l += vl * rho;
-          d_r += vr * rho;
-        }
+        wave_pass(a.D, lane,
+                  [&](long long i) {
+                    return Ld6{kp[i], a.cur_p[row + i], MET_DENSE ? kv[i] : 0.0, MET_DENSE ? a.cur_v[row + i] : 0.0,
+                               a.psub[row + i], ks[i]};
+                  },
+                  [&](long long i, const Ld6 &x) {
+                    double pl = x.a, pr = x.b;
+                    double vl = MET_DENSE ? x.c : vel_diag(a, c, i, pl);
+                    double vr = MET_DENSE ? x.d : vel_diag(a, c, i, pr);
+                    double sub = x.e - x.f + pl;
+                    double rho = sub - (pr + pl) / 2;
+                    d_l += vl * rho;
+                    d_r += vr * rho;
+                  });
         d_l = wave_sum(d_l);
         d_r = wave_sum(d_r);
         crit = (d_l <= 0) | (d_r <= 0);
