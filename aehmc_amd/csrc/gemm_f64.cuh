@@ -8,14 +8,16 @@
 // one lock-step leapfrog, one [C,D] x [D,D] product.  Rows = chains, so every output
 // element's k-summation order is independent of how many chains are batched.
 //
-// Tiling (v_mfma_f64_16x16x4_f64, wave64): 128x128 block tile, BK = 16, 256 threads =
-// 4 waves in a 2x2 arrangement, each wave owning a 64x64 sub-tile = 4x4 MFMA tiles
-// (64 f64 accumulators / lane).  LDS rows are padded to 18 doubles so that the 32
-// lanes of a ds_read_b64 group (16 rows x 2 k) hit 32 distinct 8-byte slots.  Two LDS
-// stages, one barrier per K-tile; global loads for tile t+1 are issued before the MFMAs
-// of tile t.  Block ids are dealt to XCDs round-robin by the hardware, so each XCD is
-// given a contiguous run of column panels (all row tiles x 2 column tiles): a B panel is
-// then private to one XCD's L2 while the A panels are shared chip-wide through MALL.
+// Tiling (v_mfma_f64_16x16x4_f64, wave64), BK = 16, LDS rows padded to 18 doubles, two LDS
+// stages, one barrier per K-tile, 256 threads = 4 waves in a 2x2 arrangement:
+//   gemm_nt_f64_streamk_kernel<.., 8>  128x256 tile, one workgroup per CU, each wave 64x128 =
+//       4x8 MFMA tiles (128 f64 accumulators / lane, in AGPRs), software-pipelined K loop --
+//       the default for the chain-batched products (73 TFLOP/s at 4096 x 1e4 x 1e4);
+//   gemm_nt_f64_streamk_kernel<.., 4>  128x128 tile, two workgroups per CU, compiler-scheduled;
+//   gemm_nt_f64_kernel                 one 128x128 tile per workgroup (few tiles; modes for the
+//       blocked Cholesky / triangular inverse).
+// Block ids are dealt to XCDs round-robin by the hardware, so each XCD is given a contiguous
+// run of tiles that share operand panels in its L2.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
