@@ -123,10 +123,11 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *  "dense_linear" 1 dense metric: carry w = imm g with the state so that
  *                   v_half = v - (eps/2) w, v' = v_half - (eps/2) w' (one metric GEMM per
  *                   leapfrog); 0 forms imm p_half and imm p' directly as metrics.py:71 does
- *  "streamk" 1      fp64 GEMM: persistent grid; whole tiles for all but the last 1..2 rounds, the
+ *  "streamk" 2      fp64 GEMM: persistent grid; whole tiles for all but the last 1..2 rounds, the
  *                   rest of the (tile, k) space split evenly; a tile cut between two workgroups is
- *                   accumulated in k order (bitwise equal to 0).  2: the same with 128 x 256 tiles
- *                   and one workgroup per CU (measured slower; kept for experiments)
+ *                   accumulated in k order (bitwise equal to 0).  2: 128 x 256 tiles, one
+ *                   workgroup per CU, software-pipelined K loop (default); 1: 128 x 128 tiles,
+ *                   two workgroups per CU; 0: one tile per workgroup
  *  "compact" 1      NUTS: chains whose transition has finished drop out of the GEMMs */
 int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value);
 
