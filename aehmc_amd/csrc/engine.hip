@@ -625,12 +625,16 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   a.eps = step_size; a.thr = divergence_threshold;
   a.rng = rng; a.nsites = 4;
   a.q = q; a.U = U; a.g = g; a.out = *out;
-  // auto: the resident kernel has a fixed latency of one chain's whole tree (~1.3 ms), so it
-  // wins once the state no longer fits the lock-step kernels' on-chip reuse (D > 256) or
-  // there are enough chains to fill the GPU with sub-wavefront teams (measured crossovers,
-  // tools/nuts_diag_bench.py)
-  const bool want_resident = ctx->opt_resident_nuts == 1 ||
-                             (ctx->opt_resident_nuts == 2 && (a.D > 256 || C >= 16384 || a.tkind == AEHMC_T_LINREG));
+  // auto (measured crossovers, tools/nuts_diag_bench.py): the resident kernel wins when the state
+  // no longer fits the lock-step kernels' on-chip reuse (D > 256), when there are enough chains
+  // to fill the GPU with sub-wavefront teams (C >= 16384), and in the latency regime -- up to
+  // 2048 chains all teams are resident at once and one launch replaces one launch per leapfrog;
+  // a few thousand chains of small D run faster in lock step.  The regression target always
+  // takes its workgroup-cooperative resident kernel.
+  const bool want_resident =
+      ctx->opt_resident_nuts == 1 ||
+      (ctx->opt_resident_nuts == 2 &&
+       (a.D > 256 || C >= 16384 || (C >= 8 && C <= 2048) || a.tkind == AEHMC_T_LINREG));
   if (want_resident && nuts_resident_supported(a.tkind, a.met_ndim, a.D)) {
     const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
     if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
