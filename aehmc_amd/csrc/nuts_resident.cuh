@@ -126,6 +126,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 #define GSET(r, v) do { if (QGL) sg[t + T * (r)] = (v); else g[QGL ? 0 : (r)] = (v); } while (0)
   // imm is re-read from L1/L2 when many elements per thread would cost registers
   constexpr bool IM_REG = R <= 4;
+  constexpr int BR = R > 4 ? 4 : R;  // elements whose global operands are in flight together
   double imr[IM_REG ? R : 1];
   const size_t imo = (size_t)c * a.imm_cs;
 #define IMM(r) (IM_REG ? imr[IM_REG ? (r) : 0] : a.imm[imo + (a.met_ndim == 0 ? 0 : (long long)t + (long long)T * (r))])
@@ -321,20 +322,29 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
       }
       team_sum2<T>(usum, kd, red, flip);
     } else {
+      // (global operands -- imm when it is not in registers -- are fetched BR elements at a
+      // time: one round trip per batch instead of one per element)
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (ok[r]) {
-          const long long i = (long long)t + (long long)T * r;
-          double pp = p[r] - b * GGET(r);
-          double qq = QGET(r) + aa * (IMM(r) * pp);
-          double u, gg;
-          target_elem(a, i, qq, u, gg);
-          usum += u;
-          pp = pp - b * gg;
-          QSET(r, qq);
-          GSET(r, gg);
-          p[r] = pp;
-          kd += (IMM(r) * pp) * pp;
+      for (int r0 = 0; r0 < R; r0 += BR) {
+        double imv[BR];
+#pragma unroll
+        for (int u = 0; u < BR; u++) imv[u] = (r0 + u < R && ok[r0 + u < R ? r0 + u : 0]) ? IMM(r0 + u) : 0.0;
+#pragma unroll
+        for (int u = 0; u < BR; u++) {
+          const int r = r0 + u;
+          if (r < R && ok[r < R ? r : 0]) {
+            const long long i = (long long)t + (long long)T * r;
+            double pp = p[r] - b * GGET(r);
+            double qq = QGET(r) + aa * (imv[u] * pp);
+            double uu, gg;
+            target_elem(a, i, qq, uu, gg);
+            usum += uu;
+            pp = pp - b * gg;
+            QSET(r, qq);
+            GSET(r, gg);
+            p[r] = pp;
+            kd += (imv[u] * pp) * pp;
+          }
         }
         R_FENCE();
       }
@@ -403,14 +413,27 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
           const double *ks = a.cks + ((size_t)idx * a.C + c) * a.D;
           double d_l = 0.0, d_r = 0.0;
 #pragma unroll
-          for (int r = 0; r < R; r++) {
-            if (ok[r]) {
-              double pl = kp[EI(r)], pr = p[r];
-              double vl = IMM(r) * pl, vr = IMM(r) * pr;
-              double sub = pb[r] - ks[EI(r)] + pl;
-              double rho = sub - (pr + pl) / 2;
-              d_l += vl * rho;
-              d_r += vr * rho;
+          for (int r0 = 0; r0 < R; r0 += BR) {
+            double kpv[BR], ksv[BR], imv[BR];
+#pragma unroll
+            for (int u = 0; u < BR; u++) {
+              const int r = r0 + u < R ? r0 + u : 0;
+              const bool on = r0 + u < R && ok[r];
+              kpv[u] = on ? kp[EI(r)] : 0.0;
+              ksv[u] = on ? ks[EI(r)] : 0.0;
+              imv[u] = on ? IMM(r) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < BR; u++) {
+              const int r = r0 + u < R ? r0 + u : 0;
+              if (r0 + u < R && ok[r]) {
+                double pl = kpv[u], pr = p[r];
+                double vl = imv[u] * pl, vr = imv[u] * pr;
+                double sub = pb[r] - ksv[u] + pl;
+                double rho = sub - (pr + pl) / 2;
+                d_l += vl * rho;
+                d_r += vr * rho;
+              }
             }
             R_FENCE();
           }
@@ -456,11 +479,23 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
       const int dir = ct.dir, oth = 1 - dir;
       double d_l = 0.0, d_r = 0.0;
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (ok[r]) {
-          double pc = p[r], po = AT(pick2(a.end_p, oth), r);
-          double vc = IMM(r) * pc, vo = IMM(r) * po;
-          double s = AT(a.psum, r) + pb[r];
+      for (int r0 = 0; r0 < R; r0 += BR) {
+        double pov[BR], psv[BR], imv[BR];
+#pragma unroll
+        for (int u = 0; u < BR; u++) {
+          const int r = r0 + u < R ? r0 + u : 0;
+          const bool on = r0 + u < R && ok[r];
+          pov[u] = on ? AT(pick2(a.end_p, oth), r) : 0.0;
+          psv[u] = on ? AT(a.psum, r) : 0.0;
+          imv[u] = on ? IMM(r) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < BR; u++) {
+        const int r = r0 + u < R ? r0 + u : 0;
+        if (r0 + u < R && ok[r]) {
+          double pc = p[r], po = pov[u];
+          double vc = imv[u] * pc, vo = imv[u] * po;
+          double s = psv[u] + pb[r];
           AT(a.psum, r) = s;
           double pl = dir ? po : pc, pr = dir ? pc : po;
           double vl = dir ? vo : vc, vr = dir ? vc : vo;
@@ -470,6 +505,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
           AT(pick2(a.end_q, dir), r) = QGET(r);
           AT(pick2(a.end_p, dir), r) = pc;
           AT(pick2(a.end_g, dir), r) = GGET(r);
+        }
         }
         R_FENCE();
       }
