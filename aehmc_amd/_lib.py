@@ -24,7 +24,7 @@ class CMetric(ct.Structure):
 class CAdaptState(ct.Structure):
     _fields_ = [(n, ct.c_void_p) for n in ("da_step", "da_x", "da_x_avg", "da_g_avg", "da_mu",
                                            "wc_mean", "wc_m2", "wc_n", "step_size", "imm",
-                                           "sqrt_mass")]
+                                           "sqrt_mass")] + [("full", ct.c_int32)]
 
 
 class CDiagnostics(ct.Structure):
@@ -42,6 +42,7 @@ SYMBOLS = {
     "aehmc_set_target": (_I, [_P, ct.POINTER(CTarget)]),
     "aehmc_set_metric": (_I, [_P, ct.POINTER(CMetric)]),
     "aehmc_set_step_sizes": (_I, [_P, _P]),
+    "aehmc_metric_sqrt_per_chain": (_I, [_P, _I64, _I64, _P, _P, _P]),
     "aehmc_adapt_init": (_I, [_P, _I64, _I64, _D, ct.POINTER(CAdaptState), _P]),
     "aehmc_adapt_update": (_I, [_P, _I64, _I64, ct.c_int32, ct.c_int32, ct.c_int32, _D, _P, _P,
                                 ct.POINTER(CAdaptState), _P]),

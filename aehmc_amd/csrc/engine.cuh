@@ -983,6 +983,71 @@ __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long 
   }
   if ((threadIdx.x & 63) == 0) pcg_store(rng + c * 4, g);
 }
+// ---- per-chain dense metric (what is_mass_matrix_full window adaptation produces) --------
+// Small models only (D <= AEHMC_PC_DENSE_MAX_D): every chain owns a D x D inverse mass matrix,
+// so the metric products are per-chain mat-vecs instead of one GEMM over all chains.
+constexpr int AEHMC_PC_DENSE_MAX_D = 64;
+// out[c, i] = sum_j mats[c, i, j] x[c, j]  (j ascending); one wavefront per (live) chain
+__global__ __launch_bounds__(256) void k_matvec_pc(const double *mats, const double *x, double *out, long long C,
+                                                   long long D, const int *row_idx, const int *n_rows) {
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  long long c = w;
+  if (row_idx) {
+    if (w >= *n_rows) return;
+    c = row_idx[w];
+  } else if (w >= C) {
+    return;
+  }
+  const double *m = mats + (size_t)c * D * D, *xr = x + (size_t)c * D;
+  for (long long i = lane; i < D; i += 64) {
+    double s = 0.0;
+    for (long long j = 0; j < D; j++) s += m[i * D + j] * xr[j];
+    out[(size_t)c * D + i] = s;
+  }
+}
+// L = chol(A) (lower) and S = L^-T for one D x D matrix held in LDS by one wavefront
+// (metrics.py:56-58).  `A` is overwritten by L; returns false if A is not positive definite.
+__device__ inline bool wave_chol_inv_t(double *A, double *S, int D, int lane) {
+  bool ok = true;
+  for (int k = 0; k < D; k++) {  // right-looking Cholesky, column k
+    const double akk = A[k * D + k];
+    if (!(akk > 0.0)) ok = false;
+    const double lkk = sqrt(akk);
+    for (int i = k + lane; i < D; i += 64) A[i * D + k] = (i == k) ? lkk : A[i * D + k] / lkk;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int idx = lane; idx < (D - k - 1) * (D - k - 1); idx += 64) {
+      const int i = k + 1 + idx / (D - k - 1), j = k + 1 + idx % (D - k - 1);
+      if (j <= i) A[i * D + j] = A[i * D + j] - A[i * D + k] * A[j * D + k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  // X = L^-1 by forward substitution, one column per lane; S = X^T
+  for (int col = lane; col < D; col += 64) {
+    for (int i = 0; i < D; i++) {
+      double v = (i == col) ? 1.0 : 0.0;
+      for (int j = col; j < i; j++) v = v - A[i * D + j] * S[col * D + j];  // S[col][j] = X[j][col]
+      S[col * D + i] = (i < col) ? 0.0 : v / A[i * D + i];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  return ok;
+}
+// sqrt_mass[c] = chol(imm[c])^-T for every chain; *err = 1 if a matrix is not positive definite
+__global__ __launch_bounds__(64) void k_chol_inv_pc(const double *imm, double *sqrt_mass, long long C, int D,
+                                                     int *err) {
+  extern __shared__ __attribute__((aligned(16))) double pc_lds[];  // A [D*D], S [D*D]
+  const int lane = threadIdx.x;
+  const long long c = blockIdx.x;
+  double *A = pc_lds, *S = pc_lds + D * D;
+  for (int i = lane; i < D * D; i += 64) A[i] = imm[(size_t)c * D * D + i];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const bool ok = wave_chol_inv_t(A, S, D, lane);
+  // S holds X^T laid out as S[col][i] = X[i][col] = (L^-1)[i][col] = (L^-T)[col][i]: row-major L^-T
+  for (int i = lane; i < D * D; i += 64) sqrt_mass[(size_t)c * D * D + i] = S[i];
+  if (!ok && lane == 0) *err = 1;
+}
+
 // ---- window adaptation (window_adaptation.py:119-227), one wave per chain ---------
 struct AdaptArgs {
   long long C, D;
@@ -995,6 +1060,15 @@ __global__ __launch_bounds__(256) void k_adapt_init(AdaptArgs a, double initial_
   const int lane = threadIdx.x & 63;
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= a.C) return;
+  if (a.s.full) {  // mass_matrix.py:56-57: identity
+    for (long long i = lane; i < a.D; i += 64) a.s.wc_mean[c * a.D + i] = 0.0;
+    for (long long i = lane; i < a.D * a.D; i += 64) {
+      const double e = (i / a.D == i % a.D) ? 1.0 : 0.0;
+      a.s.wc_m2[c * a.D * a.D + i] = 0.0;
+      a.s.imm[c * a.D * a.D + i] = e;
+      a.s.sqrt_mass[c * a.D * a.D + i] = e;
+    }
+  } else
   for (long long i = lane; i < a.D; i += 64) {  // mass_matrix.py:37-61
     a.s.wc_mean[c * a.D + i] = 0.0;
     a.s.wc_m2[c * a.D + i] = 0.0;
@@ -1028,6 +1102,51 @@ __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
   step += 1;
   double step_size = exp(x);
   long long n = a.s.wc_n[c];
+  if (a.s.full) {
+    // full covariance (algorithms.py:187-197 with np.outer, mass_matrix.py:83-118); D <= 64:
+    // delta / updated delta of the whole position sit in LDS, the D x D arrays in HBM
+    __shared__ double fl_delta[4][AEHMC_PC_DENSE_MAX_D], fl_ud[4][AEHMC_PC_DENSE_MAX_D];
+    extern __shared__ __attribute__((aligned(16))) double ad_lds[];  // [4 waves][2 D*D] at a window end
+    const int wv = threadIdx.x >> 6;
+    const long long DD = a.D * a.D;
+    if (a.stage != 0) {
+      n += 1;
+      for (long long i = lane; i < a.D; i += 64) {
+        const double v = a.position[c * a.D + i];
+        double mean = a.s.wc_mean[c * a.D + i];
+        const double delta = v - mean;
+        mean = mean + delta / (double)n;
+        a.s.wc_mean[c * a.D + i] = mean;
+        fl_delta[wv][i] = delta;
+        fl_ud[wv][i] = v - mean;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (long long idx = lane; idx < DD; idx += 64)
+        a.s.wc_m2[c * DD + idx] = a.s.wc_m2[c * DD + idx] + fl_ud[wv][idx / a.D] * fl_delta[wv][idx % a.D];
+    }
+    if (a.window_end) {
+      const double nn = (double)n;
+      double *A = ad_lds + (size_t)wv * 2 * DD, *S = A + DD;
+      for (long long idx = lane; idx < DD; idx += 64) {
+        const double cov = a.s.wc_m2[c * DD + idx] / (double)(n - 1);
+        double imm = (nn / (nn + 5)) * cov;
+        if (idx / a.D == idx % a.D) imm = imm + 1e-3 * (5 / (nn + 5));  // shrinkage * eye
+        a.s.imm[c * DD + idx] = imm;
+        A[idx] = imm;
+        a.s.wc_m2[c * DD + idx] = 0.0;
+      }
+      for (long long i = lane; i < a.D; i += 64) a.s.wc_mean[c * a.D + i] = 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      wave_chol_inv_t(A, S, (int)a.D, lane);  // a non-PD estimate leaves NaNs, as the reference's cholesky would
+      for (long long idx = lane; idx < DD; idx += 64) a.s.sqrt_mass[c * DD + idx] = S[idx];
+      n = 0;
+      mu = step_size;
+      step = 1;
+      x = 0.0;
+      x_avg = 0.0;
+      g_avg = 0.0;
+    }
+  } else {
   if (a.stage != 0) {  // Welford update with the new position (algorithms.py:187-197)
     n += 1;
     for (long long i = lane; i < a.D; i += 64) {
@@ -1056,6 +1175,7 @@ __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
     x = 0.0;
     x_avg = 0.0;
     g_avg = 0.0;
+  }
   }
   if (a.last) step_size = exp(x_avg);  // window_adaptation.py:184-190
   if (lane == 0) {

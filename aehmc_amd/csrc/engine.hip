@@ -270,8 +270,10 @@ extern "C" int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *m) {
   if (m->ndim < 0 || m->ndim > 2)  // metrics.py:60-63
     FAIL("Expected a mass matrix of dimension 1 (diagonal) or 2, got " + std::to_string(m->ndim));
   if (!m->imm || m->D <= 0) FAIL("metric needs imm and D");
-  if (m->per_chain && m->ndim == 2) FAIL("per-chain dense mass matrices are not supported");
-  if (m->per_chain && !m->sqrt_mass) FAIL("per-chain metrics need sqrt_mass");
+  if (m->per_chain && m->ndim == 2 && m->D > AEHMC_PC_DENSE_MAX_D)
+    FAIL("per-chain dense mass matrices are supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
+  if (m->per_chain && !m->sqrt_mass)
+    FAIL("per-chain metrics need sqrt_mass (dense: aehmc_metric_sqrt_per_chain)");
   aehmc_metric met = *m;
   if (!met.sqrt_mass) {  // metrics.py:45,49,56-58 computed here
     const int64_t n = m->ndim == 0 ? 1 : (m->ndim == 1 ? m->D : m->D * m->D);
@@ -293,6 +295,25 @@ extern "C" int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *m) {
   }
   ctx->met = met;
   ctx->has_met = true;
+  return 0;
+}
+
+extern "C" int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D, const double *imm,
+                                           double *sqrt_mass, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!imm || !sqrt_mass || C <= 0 || D <= 0) FAIL("metric_sqrt_per_chain: bad arguments");
+  if (D > AEHMC_PC_DENSE_MAX_D)
+    FAIL("per-chain dense mass matrices are supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
+  *ctx->h_err = 0;
+  hipLaunchKernelGGL(k_chol_inv_pc, dim3((unsigned)C), dim3(64), (size_t)2 * D * D * sizeof(double),
+                     (hipStream_t)stream, imm, sqrt_mass, (long long)C, (int)D, ctx->d_err);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  if (*ctx->h_err) {
+    *ctx->h_err = 0;
+    FAIL("inverse mass matrix of some chain is not positive definite");
+  }
   return 0;
 }
 
@@ -318,6 +339,8 @@ extern "C" int aehmc_adapt_init(aehmc_ctx *ctx, int64_t C, int64_t D, double ini
   HIPCHK(hipSetDevice(ctx->device));
   AdaptArgs a;
   if (int rc = adapt_args(ctx, C, D, state, a)) return rc;
+  if (state->full && D > AEHMC_PC_DENSE_MAX_D)
+    FAIL("full mass-matrix adaptation is supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
   hipLaunchKernelGGL(k_adapt_init, chain_grid(C), dim3(256), 0, (hipStream_t)stream, a, initial_step_size);
   HIPCHK(hipGetLastError());
   return 0;
@@ -333,7 +356,14 @@ extern "C" int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t 
   if (!p_accept || !position) FAIL("adaptation: acceptance_probability / position missing");
   a.stage = stage; a.window_end = is_window_end; a.last = is_last; a.target = target;
   a.p_accept = p_accept; a.position = position;
-  hipLaunchKernelGGL(k_adapt_update, chain_grid(C), dim3(256), 0, (hipStream_t)stream, a);
+  if (state->full) {  // one wavefront per workgroup: the window-end factorisation holds two D x D matrices in LDS
+    if (D > AEHMC_PC_DENSE_MAX_D)
+      FAIL("full mass-matrix adaptation is supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
+    hipLaunchKernelGGL(k_adapt_update, dim3((unsigned)C), dim3(64), (size_t)2 * D * D * sizeof(double),
+                       (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(k_adapt_update, chain_grid(C), dim3(256), 0, (hipStream_t)stream, a);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -461,6 +491,20 @@ static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A
   return 0;
 }
 
+// X [C,D] times the metric matrix `mat` (imm or sqrt_mass): one GEMM over all chains when the
+// matrix is shared, per-chain mat-vecs when every chain has its own (is_mass_matrix_full)
+static int metric_mul(aehmc_ctx *ctx, int64_t C, const double *X, const double *mat, double *out,
+                      hipStream_t st, const int *row_idx = nullptr, const int *n_rows = nullptr) {
+  const int64_t D = ctx->met.D;
+  if (ctx->met.per_chain) {
+    hipLaunchKernelGGL(k_matvec_pc, chain_grid(C), dim3(256), 0, st, mat, X, out, (long long)C, (long long)D,
+                       row_idx, n_rows);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  return gemm(ctx, C, D, D, X, D, mat, D, out, D, st, row_idx, n_rows);
+}
+
 extern "C" int aehmc_profile_enable(aehmc_ctx *ctx, int enable) {
   if (!ctx) return -2;
   HIPCHK(hipSetDevice(ctx->device));
@@ -546,14 +590,14 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
     LAUNCH((k_step_linear<12, false>), C, st, a);
     if (text)
       if (target_ext()) return -1;
-    if (gemm(ctx, C, D, D, a.cur_g, D, ctx->met.imm, D, a.cur_w, D, st, ri, nr)) return -1;
+    if (metric_mul(ctx, C, a.cur_g, ctx->met.imm, a.cur_w, st, ri, nr)) return -1;
     if (book) LAUNCH((k_step_linear<3, true>), C, st, a);
     else LAUNCH((k_step_linear<3, false>), C, st, a);
     return 0;
   }
   // dense metric, literal: v_half = imm p_half and v' = imm p' formed directly
   LAUNCH((k_step<true, false, false, true, false>), C, st, a);
-  if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.vhalf, D, st, ri, nr)) return -1;
+  if (metric_mul(ctx, C, a.cur_p, ctx->met.imm, a.vhalf, st, ri, nr)) return -1;
   if (!text) {
     LAUNCH((k_step<false, true, true, true, false>), C, st, a);
   } else {
@@ -562,7 +606,7 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
     LAUNCH((k_step<false, false, true, true, false>), C, st, a);
   }
   if (need_v || book)
-    if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.cur_v, D, st, ri, nr)) return -1;
+    if (metric_mul(ctx, C, a.cur_p, ctx->met.imm, a.cur_v, st, ri, nr)) return -1;
   if (book) LAUNCH((k_step<false, false, false, true, true>), C, st, a);
   return 0;
 }
@@ -577,10 +621,10 @@ static int launch_begin(aehmc_ctx *ctx, const EngineArgs &a, bool nuts, hipStrea
     return 0;
   }
   LAUNCH(k_nuts_draw<true>, C, st, a);
-  if (gemm(ctx, C, D, D, a.zbuf, D, ctx->met.sqrt_mass, D, a.cur_p, D, st)) return -1;  // p = L^-T z
-  if (gemm(ctx, C, D, D, a.cur_p, D, ctx->met.imm, D, a.cur_v, D, st)) return -1;
+  if (metric_mul(ctx, C, a.zbuf, ctx->met.sqrt_mass, a.cur_p, st)) return -1;  // p = L^-T z
+  if (metric_mul(ctx, C, a.cur_p, ctx->met.imm, a.cur_v, st)) return -1;
   if (a.linear)  // w0 = imm g0
-    if (gemm(ctx, C, D, D, a.g, D, ctx->met.imm, D, a.cur_w, D, st)) return -1;
+    if (metric_mul(ctx, C, a.g, ctx->met.imm, a.cur_w, st)) return -1;
   if (nuts) LAUNCH(k_nuts_init<true>, C, st, a);
   else LAUNCH(k_hmc_init<true>, C, st, a);
   return 0;
@@ -874,7 +918,7 @@ extern "C" int aehmc_kinetic_energy(aehmc_ctx *ctx, int64_t C, const double *p, 
   EngineArgs a;
   if (int rc = fill_args(ctx, C, 1, a)) return rc;
   if (a.met_ndim == 2) {
-    if (gemm(ctx, C, a.D, a.D, p, a.D, ctx->met.imm, a.D, a.vhalf, a.D, st)) return -1;
+    if (metric_mul(ctx, C, p, ctx->met.imm, a.vhalf, st)) return -1;
   } else {
     LAUNCH(k_vel_diag, C, st, a, p, a.vhalf);
   }
@@ -890,8 +934,8 @@ extern "C" int aehmc_is_turning(aehmc_ctx *ctx, int64_t C, const double *pl, con
   EngineArgs a;
   if (int rc = fill_args(ctx, C, 1, a)) return rc;
   if (a.met_ndim == 2) {
-    if (gemm(ctx, C, a.D, a.D, pl, a.D, ctx->met.imm, a.D, a.vhalf, a.D, st)) return -1;
-    if (gemm(ctx, C, a.D, a.D, pr, a.D, ctx->met.imm, a.D, a.zbuf, a.D, st)) return -1;
+    if (metric_mul(ctx, C, pl, ctx->met.imm, a.vhalf, st)) return -1;
+    if (metric_mul(ctx, C, pr, ctx->met.imm, a.zbuf, st)) return -1;
   } else {
     LAUNCH(k_vel_diag, C, st, a, pl, a.vhalf);
     LAUNCH(k_vel_diag, C, st, a, pr, a.zbuf);

@@ -134,10 +134,22 @@ class Engine:
             ndim = 1
             if t.shape[1] != D:
                 raise ValueError(f"per-chain diagonal inverse mass matrix must be [C,{D}]")
+        elif t.ndim == 3:    # [C, D, D] dense metrics (is_mass_matrix_full adaptation)
+            ndim = 2
+            if t.shape[1:] != (D, D):
+                raise ValueError(f"per-chain dense inverse mass matrix must be [C,{D},{D}]")
         else:
-            raise ValueError("PerChain inverse mass matrix must be [C] or [C, D]")
-        sm = _dev_f64(pc.sqrt_mass, self.device).reshape(t.shape) if pc.sqrt_mass is not None \
-            else torch.sqrt(torch.reciprocal(t))
+            raise ValueError("PerChain inverse mass matrix must be [C], [C, D] or [C, D, D]")
+        if pc.sqrt_mass is not None:
+            sm = _dev_f64(pc.sqrt_mass, self.device).reshape(t.shape)
+        elif ndim == 2:      # L^-T per chain (metrics.py:56-58), on the device
+            t = t.contiguous()
+            sm = torch.empty_like(t)
+            self._check(self.lib.aehmc_metric_sqrt_per_chain(self.ctx, t.shape[0], D, t.data_ptr(),
+                                                             sm.data_ptr(), self.stream),
+                        "aehmc_metric_sqrt_per_chain")
+        else:
+            sm = torch.sqrt(torch.reciprocal(t))
         c = _lib.CMetric(ndim=ndim, per_chain=1, D=D, imm=t.data_ptr(), sqrt_mass=sm.data_ptr())
         self._keep["metric"] = (pc, t, sm)
         self._check(self.lib.aehmc_set_metric(self.ctx, ct.byref(c)), "aehmc_set_metric")
@@ -287,15 +299,16 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ warm-up
-    def adapt_alloc(self, C, D):
+    def adapt_alloc(self, C, D, full=False):
         dev, f64, i64 = self.device, torch.float64, torch.int64
+        mat = (C, D, D) if full else (C, D)
         st = dict(da_step=torch.empty(C, dtype=i64, device=dev), da_x=torch.empty(C, dtype=f64, device=dev),
                   da_x_avg=torch.empty(C, dtype=f64, device=dev), da_g_avg=torch.empty(C, dtype=f64, device=dev),
                   da_mu=torch.empty(C, dtype=f64, device=dev), wc_mean=torch.empty(C, D, dtype=f64, device=dev),
-                  wc_m2=torch.empty(C, D, dtype=f64, device=dev), wc_n=torch.empty(C, dtype=i64, device=dev),
-                  step_size=torch.empty(C, dtype=f64, device=dev), imm=torch.empty(C, D, dtype=f64, device=dev),
-                  sqrt_mass=torch.empty(C, D, dtype=f64, device=dev))
-        return st, _lib.CAdaptState(**{k: v.data_ptr() for k, v in st.items()})
+                  wc_m2=torch.empty(mat, dtype=f64, device=dev), wc_n=torch.empty(C, dtype=i64, device=dev),
+                  step_size=torch.empty(C, dtype=f64, device=dev), imm=torch.empty(mat, dtype=f64, device=dev),
+                  sqrt_mass=torch.empty(mat, dtype=f64, device=dev))
+        return st, _lib.CAdaptState(full=int(bool(full)), **{k: v.data_ptr() for k, v in st.items()})
 
     def adapt_init(self, C, D, initial_step_size, cstate):
         self._check(self.lib.aehmc_adapt_init(self.ctx, C, D, float(initial_step_size), ct.byref(cstate),

@@ -1,5 +1,5 @@
-"""Stan-style window adaptation of the step size and the (diagonal) inverse mass matrix,
-one adaptation per chain (reference: aehmc/window_adaptation.py, step_size.py,
+"""Stan-style window adaptation of the step size and the inverse mass matrix (diagonal, or
+dense per chain with ``is_mass_matrix_full`` for D <= 64), one adaptation per chain (reference: aehmc/window_adaptation.py, step_size.py,
 mass_matrix.py, algorithms.py).  The schedule is host logic; the per-chain dual-averaging /
 Welford updates run in one HIP kernel per warm-up step (`aehmc_adapt_update`)."""
 from __future__ import annotations
@@ -41,11 +41,8 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     """Warm a (NUTS) kernel up for ``num_steps`` transitions (reference:
     aehmc/window_adaptation.py:17-116).  Returns ``(last_chain_state, (step_size,
     inverse_mass_matrix), updates)`` where the parameters are ``PerChain`` values -- one
-    step size and one diagonal inverse mass matrix per chain, exactly as running the
+    step size and one (diagonal or dense) inverse mass matrix per chain, exactly as running the
     reference once per chain would produce -- to be passed back to ``kernel``."""
-    if is_mass_matrix_full:
-        raise NotImplementedError("per-chain dense mass-matrix adaptation is not supported; "
-                                  "use the diagonal adaptation")
     eng = get_engine()
     pos = initial_state.position
     srng_chains = getattr(kernel, "num_chains", None)
@@ -53,7 +50,11 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     layout = Layout(tuple(pos.shape), batched, srng_chains or (pos.shape[0] if batched else 1))
     C, D = layout.C, layout.D
     scalar_position = (len(layout.user_shape) - (1 if batched else 0)) == 0
-    st, cst = eng.adapt_alloc(C, D)
+    full = bool(is_mass_matrix_full) and not scalar_position  # mass_matrix.py:54-57: a scalar stays a scalar
+    if full and D > 64:
+        raise NotImplementedError("is_mass_matrix_full keeps one dense matrix per chain and is supported "
+                                  "up to D = 64; use the diagonal adaptation for larger models")
+    st, cst = eng.adapt_alloc(C, D, full)
     eng.adapt_init(C, D, float(initial_step_size), cst)
     schedule = build_schedule(int(num_steps))
 

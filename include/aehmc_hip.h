@@ -65,8 +65,10 @@ typedef struct {
  * L^-T with imm = L L^T (metrics.py:56-58).  Dense imm must be symmetric. */
 typedef struct {
   int32_t ndim;
-  int32_t per_chain;       /* 1: imm / sqrt_mass are [C,1] (ndim 0) or [C,D] (ndim 1), one row per
-                              chain -- what per-chain window adaptation produces; 0: shared */
+  int32_t per_chain;       /* 1: imm / sqrt_mass are [C,1] (ndim 0), [C,D] (ndim 1) or [C,D,D]
+                              (ndim 2, D <= 64), one per chain -- what per-chain window
+                              adaptation produces; sqrt_mass must be given
+                              (aehmc_metric_sqrt_per_chain computes the dense one); 0: shared */
   int64_t D;
   const double *imm;       /* [1] | [D] | [D,D] */
   const double *sqrt_mass; /* [1] | [D] | [D,D], or NULL: aehmc_set_metric computes it on the
@@ -84,6 +86,8 @@ typedef struct {
   int64_t *wc_n;                         /* [C] */
   double *step_size;                     /* [C] */
   double *imm, *sqrt_mass;               /* [C,D] */
+  int32_t full;                          /* 1: is_mass_matrix_full -- wc_m2, imm and sqrt_mass are
+                                            [C,D,D] (full covariance per chain, D <= 64) */
 } aehmc_adapt_state;
 
 /* per-transition outputs == trajectory.py:379-384 Diagnostics (+ n_leapfrog) */
@@ -187,6 +191,10 @@ int aehmc_nuts_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size
                       double *q, double *U, double *g, const aehmc_diagnostics *out, double *samples,
                       double *acceptance_history, int32_t *divergence_history,
                       int64_t *n_leapfrog_total, void *stream);
+
+/* sqrt_mass[c] = chol(imm[c])^-T (metrics.py:56-58) for C dense D x D matrices, D <= 64 */
+int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D, const double *imm, double *sqrt_mass,
+                                void *stream);
 
 /* ---- building blocks exported for known-answer tests / callers that want them ---- */
 

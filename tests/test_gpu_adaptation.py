@@ -109,3 +109,125 @@ def test_window_adaptation_statistics():
     # the contract, so only the reference's own loose assertions are checked here.
     info, _ = kernel(last, eps, imm)
     assert torch.isfinite(info.state.position).all()
+
+
+# ------------------------------------------------------------------ is_mass_matrix_full (dense, per chain)
+def test_metric_sqrt_per_chain_matches_numpy():
+    """metrics.py:56-58 for a batch of small dense matrices: L^-T with imm = L L^T."""
+    from aehmc_amd import PerChain
+    from aehmc_amd.engine import EngineError, get_engine
+    eng = get_engine()
+    r = np.random.default_rng(3)
+    for D in (1, 2, 5, 17, 64):
+        C = 7
+        A = r.normal(size=(C, D, D))
+        imm = A @ A.transpose(0, 2, 1) / D + 0.5 * np.eye(D)
+        eng.set_metric(PerChain(torch.as_tensor(imm, device="cuda")), D)
+        S = eng._keep["metric"][2].cpu().numpy()
+        for c in range(C):
+            ref = np.linalg.inv(np.linalg.cholesky(imm[c])).T
+            np.testing.assert_allclose(S[c], ref, rtol=1e-10, atol=1e-12)
+    bad = np.stack([np.eye(3), np.diag([1.0, -1.0, 1.0])])
+    with pytest.raises(EngineError, match="positive definite"):
+        eng.set_metric(PerChain(torch.as_tensor(bad, device="cuda")), 3)
+    with pytest.raises(EngineError, match="up to D = 64"):
+        eng.set_metric(PerChain(torch.eye(65, dtype=torch.float64, device="cuda").repeat(2, 1, 1)), 65)
+
+
+@pytest.mark.parametrize("kind", ["nuts", "hmc"])
+@pytest.mark.parametrize("linear", [1, 0])
+def test_per_chain_dense_metric_matches_oracle(kind, linear):
+    """Every chain with its own dense inverse mass matrix (per-chain mat-vecs instead of the
+    chain-batched GEMM): chain c equals the oracle run with matrix c."""
+    from aehmc_amd import PerChain, RandomStream, hmc, nuts, targets
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    eng.set_option("dense_linear", linear)
+    try:
+        r = np.random.default_rng(21)
+        C, D = 6, 5
+        mu, sigma = r.normal(size=D), 0.5 + r.random(D)
+        tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
+        A = r.normal(size=(C, D, D))
+        imm = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D)
+        imm = 0.5 * (imm + imm.transpose(0, 2, 1))
+        eps = 0.3 * (0.5 + r.random(C))
+        seeds = [70 + c for c in range(C)]
+        q0 = r.normal(size=(C, D))
+        mod = nuts if kind == "nuts" else hmc
+        extra = () if kind == "nuts" else (7,)
+        kernel = mod.new_kernel(RandomStream(seeds=seeds), tgt)
+        state = mod.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+        outs = []
+        for _ in range(3):
+            info, _ = kernel(state, PerChain(torch.as_tensor(eps, device="cuda")),
+                             PerChain(torch.as_tensor(imm, device="cuda")), *extra)
+            state = info.state._replace(momentum=None)
+            outs.append(info)
+        for c in range(C):
+            rng = co.site_states([seeds[c]], 4 if kind == "nuts" else 2)
+            metric = co.Metric(imm[c], D)
+            q, U, g = co.new_state(otgt, q0[c:c + 1].copy())
+            for info in outs:
+                if kind == "nuts":
+                    res = co.nuts_step(otgt, metric, rng, float(eps[c]), q, U, g)
+                    assert info.n_leapfrog[c].item() == res["n_leapfrog"][0]
+                else:
+                    res = co.hmc_step(otgt, metric, rng, float(eps[c]), 7, q, U, g)
+                np.testing.assert_allclose(info.state.position[c].cpu().numpy(), q[0], rtol=1e-9, atol=1e-11)
+                assert info.acceptance_probability[c].item() == pytest.approx(res["acceptance_probability"][0], rel=1e-9)
+    finally:
+        eng.set_option("dense_linear", 1)
+
+
+def test_adapt_update_kernel_full_matches_oracle():
+    """is_mass_matrix_full: Welford with np.outer, shrinkage on the diagonal, L^-T at window ends."""
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    C, D, num_steps = 4, 6, 200
+    r = np.random.default_rng(12)
+    st, cst = eng.adapt_alloc(C, D, full=True)
+    eng.adapt_init(C, D, 0.5, cst)
+    init, update = na.window_adaptation(num_steps, is_mass_matrix_full=True, initial_step_size=0.5)
+    ref = [init(np.zeros(D)) for _ in range(C)]
+    np.testing.assert_array_equal(st["imm"][0].cpu().numpy(), np.eye(D))
+    mix = r.normal(size=(D, D))
+    for i, (stage, wend) in enumerate(na.build_schedule(num_steps)):
+        pa = r.random(C)
+        pos = r.normal(size=(C, D)) @ mix
+        eng.adapt_update(C, D, stage, wend, i == num_steps - 1, 0.8, torch.as_tensor(pa, device="cuda"),
+                         torch.as_tensor(pos, device="cuda"), cst)
+        ref = [update(i, ws, pr, pos[c], pa[c]) for c, (ws, pr) in enumerate(ref)]
+        if wend or i % 41 == 0 or i == num_steps - 1:
+            for c, ((da, mm), (eps, imm)) in enumerate(ref):
+                assert st["step_size"][c].item() == pytest.approx(eps, rel=1e-12)
+                np.testing.assert_allclose(st["imm"][c].cpu().numpy(), imm, rtol=1e-11, atol=1e-14)
+                np.testing.assert_allclose(st["wc_m2"][c].cpu().numpy(), mm[1], rtol=1e-11, atol=1e-12)
+                assert st["wc_n"][c].item() == mm[2]
+                np.testing.assert_allclose(st["sqrt_mass"][c].cpu().numpy(),
+                                           np.linalg.inv(np.linalg.cholesky(imm)).T, rtol=1e-9, atol=1e-11)
+
+
+def test_window_adaptation_full_matches_oracle():
+    """End to end with is_mass_matrix_full=True on identical seeds (60 steps, see above)."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    C, D, num_steps = 3, 3, 60
+    r = np.random.default_rng(8)
+    mu, sigma = r.normal(size=D), 0.5 + 2 * r.random(D)
+    tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
+    seeds = [400 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    kernel = nuts.new_kernel(RandomStream(seeds=seeds), tgt)
+    state = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt, num_chains=C)
+    last, (eps, imm), _ = window_adaptation.run(kernel, state, num_steps, is_mass_matrix_full=True)
+    assert imm.value.shape == (C, D, D)
+    for c in range(C):
+        ok = OracleNuts(otgt, seeds[c], D)
+        Uo, go = no.DiagGaussian(mu, sigma)(q0[c])
+        st = no.IntegratorState(q0[c], None, Uo, go)
+        st, (eps_o, imm_o) = na.run(ok, st, num_steps, is_mass_matrix_full=True)
+        assert eps.value[c].item() == pytest.approx(eps_o, rel=1e-6)
+        np.testing.assert_allclose(imm.value[c].cpu().numpy(), imm_o, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(last.position[c].cpu().numpy(), st.position, rtol=1e-6, atol=1e-9)
+    info, _ = kernel(last, eps, imm)  # the adapted parameters go straight back into the kernel
+    assert np.isfinite(info.state.position.cpu().numpy()).all()
