@@ -168,8 +168,12 @@ def main():
         bytes_per_launch = 48.0 * D * C * 32 * 100
         avg_s = kern_ms / 1e3 / max(kern_n, 1)
         achieved = bytes_per_launch / avg_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1", "c2_pmc_summary.json")
+        if os.path.exists(pmc) and D == 100 and C == 4096:  # measured offline (separate rocprofv3 --pmc passes)
+            traffic = json.load(open(pmc))["hmc_fused_summary"]["traffic_bytes_per_launch_avg"]
         roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": achieved / PEAK_HBM_GBS, "traffic": None, "kernel": "k_hmc_fused",
+                    "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "kernel": "k_hmc_fused",
                     "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
                     "achieved_io_only_GBs": 40.0 * D * C * 100 / avg_s / 1e9,
                     "note": "achieved uses SURVEY 8d's streaming figure (48*D B per leapfrog); the state is "

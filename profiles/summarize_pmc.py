@@ -43,3 +43,20 @@ out["gemm_summary"] = {
 os.makedirs(dst, exist_ok=True)
 json.dump(out, open(os.path.join(dst, "c3_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out["gemm_summary"], indent=1))
+
+# c2: the fused HMC kernel (100 transitions of 4096 chains per launch)
+if os.path.isdir(os.path.join(src, "pmc_fetch_c2")):
+    f2, w2 = per_kernel(os.path.join(src, "pmc_fetch_c2"), "FETCH_SIZE"), per_kernel(os.path.join(src, "pmc_write_c2"), "WRITE_SIZE")
+    name = next(k for k in f2 if "k_hmc_fused" in k)
+    c2 = {"FETCH_SIZE": f2, "WRITE_SIZE": w2,
+          "hmc_fused_summary": {
+              "kernel": name, "launches": f2[name]["launches"],
+              "fetch_bytes_avg_x2_gfx950": 2 * f2[name]["avg_KB_per_launch"] * 1024,
+              "write_bytes_avg": w2[name]["avg_KB_per_launch"] * 1024,
+              "traffic_bytes_per_launch_avg": (2 * f2[name]["avg_KB_per_launch"] + w2[name]["avg_KB_per_launch"]) * 1024,
+              "io_bytes_per_launch_expected": 4096 * 100 * 8 * (2 + 2) + 100 * 4096 * 12,
+              "note": "one launch = 100 transitions x 4096 chains, state in registers: expected I/O is q, g in and out once "
+                      "(13 MB) plus the acceptance / divergence history (4.9 MB); FETCH_SIZE doubled as above (the kernel's "
+                      "8-byte-per-lane loads are outside the guide's calibration)"}}
+    json.dump(c2, open(os.path.join(dst, "c2_pmc_summary.json"), "w"), indent=1)
+    print(json.dumps(c2["hmc_fused_summary"], indent=1))
