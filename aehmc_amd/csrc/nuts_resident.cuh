@@ -89,6 +89,7 @@ __device__ __forceinline__ void team_sum2(double &x, double &y, double (*red)[2 
 // for all four chains, and each wave keeps the tree of its own chain.  A wave whose chain
 // has finished keeps serving rows until the whole workgroup is done.
 constexpr int LR_BLOCK = 512, LR_WAVES = LR_BLOCK / 64;  // 4 chain waves + 4 waves that only serve rows
+constexpr int LR_CHUNK = 256, LR_RING = 4;               // rows per chunk, chunks in flight per wave (128 KB of LDS)
 template <int T, int R, bool QGL = false, bool LR = false>
 __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
   using TM = Team<T>;
@@ -252,41 +253,64 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
         w4[k] = lr_w[k];
         sxr[k] = srr[k] = 0.0;
       }
-      // Four rows per thread and batch, two register sets in ping-pong so that the next batch
-      // is in flight while this one is used; each thread adds its rows in ascending order.
-      const long long nbf = a.N / (4 * LR_BLOCK);  // batches in which every thread has 4 rows
-      const double *Xp = a.X + threadIdx.x, *yp = a.y + threadIdx.x;
-      double xa[4], ya[4], xb[4], yb[4];
-#define LR_LOAD(xd, yd, bb)                                   \
-  _Pragma("unroll") for (int u = 0; u < 4; u++) {             \
-    xd[u] = Xp[(4 * (bb) + u) * (long long)LR_BLOCK];         \
-    yd[u] = yp[(4 * (bb) + u) * (long long)LR_BLOCK];         \
-  }
-#define LR_ACC(xd, yd)                                        \
-  _Pragma("unroll") for (int u = 0; u < 4; u++)               \
-  _Pragma("unroll") for (int k = 0; k < 4; k++) {             \
-    const double rr = yd[u] - xd[u] * w4[k];                  \
-    sxr[k] += xd[u] * rr;                                     \
-    srr[k] += rr * rr;                                        \
-  }
-      long long bb = 0;
-      if (nbf > 0) { LR_LOAD(xa, ya, 0) }
-      for (; bb + 1 < nbf; bb += 2) {
-        LR_LOAD(xb, yb, bb + 1)
-        LR_ACC(xa, ya)
-        if (bb + 2 < nbf) { LR_LOAD(xa, ya, bb + 2) }
-        LR_ACC(xb, yb)
-      }
-      if (bb < nbf) { LR_ACC(xa, ya) }
-#undef LR_LOAD
-#undef LR_ACC
-      for (long long i = nbf * 4 * LR_BLOCK + threadIdx.x; i < a.N; i += LR_BLOCK) {
-        const double x = a.X[i], yy = a.y[i];
+      // The rows stream through a wave-private LDS ring filled by LDS-DMA (global_load_lds, 16 B per
+      // lane: one instruction lands 128 consecutive doubles): a chunk is 256 rows of X and of y
+      // (4 x 1 KB), LR_RING chunks per wave are in flight, so a chunk has ~3 chunk-times (> 1 us) to
+      // arrive and no VGPR holds data in flight.  Lane l adds rows r0+l, r0+64+l, r0+128+l, r0+192+l of
+      // its wave's chunks in ascending order.
+      {
+        double *const ring = dyn_lds + (size_t)wave * (LR_RING * LR_CHUNK * 2);
+        const int nchunks = (int)(a.N / LR_CHUNK);                      // full chunks
+        const int nm = wave < nchunks ? (nchunks - wave + LR_WAVES - 1) / LR_WAVES : 0;  // this wave's
+        auto issue = [&](int m) {
+          const long long r0 = (long long)(wave + LR_WAVES * m) * LR_CHUNK;
+          double *slot = ring + (size_t)(m % LR_RING) * (LR_CHUNK * 2);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const double rr = yy - x * w4[k];
-          sxr[k] += x * rr;
-          srr[k] += rr * rr;
+          for (int h = 0; h < LR_CHUNK / 128; h++) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(a.X + r0 + 128 * h + 2 * lane),
+                (__attribute__((address_space(3))) void *)(slot + 128 * h), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(a.y + r0 + 128 * h + 2 * lane),
+                (__attribute__((address_space(3))) void *)(slot + LR_CHUNK + 128 * h), 16, 0, 0);
+          }
+        };
+        constexpr int PER = 2 * (LR_CHUNK / 128);  // DMA instructions per chunk
+        for (int m = 0; m < LR_RING - 1 && m < nm; m++) issue(m);
+        for (int m = 0; m < nm; m++) {
+          if (m + LR_RING - 1 < nm) {
+            issue(m + LR_RING - 1);  // into the slot read in the previous step (its values are in registers)
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (((LR_RING - 1) * PER) & 0xF) | ((((LR_RING - 1) * PER) >> 4) << 14));
+          } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the tail of the stream
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const double *slot = ring + (size_t)(m % LR_RING) * (LR_CHUNK * 2);
+          double xs[LR_CHUNK / 64], ys[LR_CHUNK / 64];
+#pragma unroll
+          for (int u = 0; u < LR_CHUNK / 64; u++) {
+            xs[u] = slot[64 * u + lane];
+            ys[u] = slot[LR_CHUNK + 64 * u + lane];
+          }
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the slot may be refilled from here on
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < LR_CHUNK / 64; u++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const double rr = ys[u] - xs[u] * w4[k];
+              sxr[k] += xs[u] * rr;
+              srr[k] += rr * rr;
+            }
+        }
+        for (long long i = (long long)nchunks * LR_CHUNK + threadIdx.x; i < a.N; i += LR_BLOCK) {  // last < 256 rows
+          const double x = a.X[i], yy = a.y[i];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const double rr = yy - x * w4[k];
+            sxr[k] += x * rr;
+            srr[k] += rr * rr;
+          }
         }
       }
 #pragma unroll
@@ -600,8 +624,9 @@ inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
   const unsigned grid = Team<T>::SUB    ? (unsigned)((a.C * T + 255) / 256)
                         : Team<T>::WAVE ? (unsigned)((a.C + 3) / 4)
                                         : (unsigned)a.C;
-  const size_t dyn = QGL ? (size_t)2 * a.D * sizeof(double) : 0;
-  if (QGL) {
+  const size_t dyn = QGL ? (size_t)2 * a.D * sizeof(double)
+                     : LR ? (size_t)LR_WAVES * LR_RING * LR_CHUNK * 2 * sizeof(double) : 0;
+  if (QGL || LR) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<T, R, QGL, LR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     if (e != hipSuccess) return e;
