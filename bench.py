@@ -55,7 +55,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs; c4 = c3 with 32768 chains split over the ranks (strong scaling)")
     ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -83,6 +84,9 @@ def main():
     from aehmc_amd.engine import get_engine
     from aehmc_amd.parallel import barrier, gather_samples, max_over_ranks, sum_over_ranks
 
+    strong = args.config == "c4"
+    if strong:  # config 4: 32768 chains sharded across the GPUs of the node
+        args.config, args.chains = "c3", 32768 // world
     if args.config == "c1":
         return bench_c1(args)
     if args.config == "c5":
@@ -187,7 +191,8 @@ def main():
     print(json.dumps({
         "metric": "leapfrog-steps/sec across all chains", "value": value, "unit": "leapfrog-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "chains_total": C * world, "dim": D,
                    "leapfrogs_per_step": total_leap / args.steps},
