@@ -54,6 +54,7 @@ struct aehmc_ctx {
   // stream-K GEMM: persistent grid, partial-accumulator hand-off buffers
   int opt_streamk = 2;  // 0 off, 1 = 128x128 tiles (2 workgroups/CU), 2 = 128x256 tiles, software-pipelined (1 workgroup/CU)
   int sk_grid = 0, sk_grid_wide = 0;
+  int64_t rows_hint = 0;  // > 0: upper bound on the live-row count of compacted GEMMs (from the last poll)
   double *sk_partial = nullptr;
   int *sk_flags = nullptr;
   int sk_epoch = 0;
@@ -481,6 +482,10 @@ static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A
   if (*ctx->h_err) FAIL("stream-K GEMM: a workgroup hand-off timed out (results invalid)");
   GemmStreamK sk{ctx->sk_partial, ctx->sk_flags, ctx->d_err, ++ctx->sk_epoch};
   const bool use_sk = ctx->opt_streamk && ctx->sk_grid > 0;
+  // the kernels read the exact row count on the device; the host only picks the kernel and the
+  // grid, from an upper bound: live chains never increase within a transition, so the count seen
+  // at the last poll bounds every later launch (few rows left: smaller tiles, no persistent grid)
+  if (n_rows && ctx->rows_hint > 0 && ctx->rows_hint < M) M = ctx->rows_hint;
   HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st, row_idx, n_rows,
                             p ? ctx->d_flops : nullptr, (use_sk && mode == 0) ? &sk : nullptr, ctx->sk_grid,
                             mode, ctx->opt_streamk == 2 ? ctx->sk_grid_wide : 0));
@@ -705,6 +710,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     }
     return 0;
   }
+  ctx->rows_hint = 0;
   if (int rc = launch_begin(ctx, a, true, st)) return rc;
   long long maxsteps = 0;
   for (int j = 0; j < max_num_expansions; j++) maxsteps += (1LL << j) + 1;  // 2**j + 1 per expansion
@@ -722,6 +728,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       int slot = (batch - 2) % NRING;
       HIPCHK(hipEventSynchronize(ctx->ev[slot]));
       if (ctx->h_active[slot] == 0) break;
+      if (compact) ctx->rows_hint = ctx->h_active[slot];
     }
     const int slot = batch % NRING;
     for (int k = 0; k < STEP_BATCH && s < maxsteps; k++, s++) {
@@ -741,6 +748,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     HIPCHK(hipEventRecord(ctx->ev[slot], st));
     batch++;
   }
+  ctx->rows_hint = 0;
   return 0;
 }
 

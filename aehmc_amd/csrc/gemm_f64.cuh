@@ -524,6 +524,96 @@ __global__ __launch_bounds__(256, (NJ == 8 ? 1 : 2)) void gemm_nt_f64_streamk_ke
   if (has_tail) pass(tf, ks, nk, 2);
 }
 
+// ---- tail kernel: a handful of rows (M <= 16 NI) --------------------------------------
+// Late in a NUTS transition only the deepest trees are still alive; the product is then bound
+// by streaming B (D x D) once, not by MFMAs, and one 128 x 128 tile per workgroup would put
+// 79 workgroups on the GPU with one K-tile in flight each (1.07 ms for 8 rows at D = 1e4).
+// Here one WAVE owns 16 output columns (16 rows of B) and all NI row blocks: per K-tile it
+// fetches its 2 KB of B and NI x 2 KB of A in full 128-byte lines (lane = (row, 32-byte
+// quarter)), P K-tiles ahead in registers, passes them through a wave-private LDS tile into
+// MFMA fragment order and issues 4 NI MFMAs -- the same MFMA sequence per 16 x 16 block as
+// every other kernel here, hence the same bits.  No barriers; ~2.4 waves per CU.
+template <int NI, int P>
+__global__ __launch_bounds__(256) void gemm_nt_f64_tail_kernel(
+    int64_t M, int64_t N, int64_t K, const double *__restrict__ A, int64_t lda,
+    const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc,
+    const int *__restrict__ row_idx, const int *__restrict__ n_rows,
+    unsigned long long *__restrict__ flop_counter) {
+  __shared__ __attribute__((aligned(16))) double tB[4][16][GEMM_LDS];
+  __shared__ __attribute__((aligned(16))) double tA[4][NI][16][GEMM_LDS];
+  if (n_rows) M = *n_rows;
+  if (flop_counter && blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(flop_counter, (unsigned long long)(2 * M * N * K));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  if (M <= 0 || n0 >= N) return;
+  const int r = lane >> 2, kq = lane & 3;  // staging role: row r, doubles 4 kq .. 4 kq + 3 of the K-tile
+  const int fr = lane & 15, fk = lane >> 4;  // MFMA role
+  const double *pb = B + ((n0 + r) < N ? n0 + r : N - 1) * ldb + 4 * kq;
+  const double *pa[NI];
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const int64_t m = 16 * i + r;
+    const int64_t row = m < M ? (row_idx ? (int64_t)row_idx[m] : m) : (row_idx ? (int64_t)row_idx[0] : 0);
+    pa[i] = A + row * lda + 4 * kq;
+  }
+  const int nk = (int)((K + GEMM_BK - 1) / GEMM_BK);
+  d2_t gb[P][2], ga[P][NI][2];
+  auto fetch = [&](int s, int kt) {  // K-tile kt -> register stage s (zeros past K; kt clamped past the end)
+    const int ktc = kt < nk ? kt : nk - 1;
+    const int64_t k0 = (int64_t)ktc * GEMM_BK + 4 * kq;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const bool inb = k0 + 2 * h + 2 <= K;
+      const int64_t off = (int64_t)ktc * GEMM_BK + (inb ? 2 * h : -4 * kq);  // in bounds: column 0 of the tile
+      d2_t v = *reinterpret_cast<const d2_t *>(pb + off);
+      gb[s][h] = inb ? v : (d2_t){(k0 + 2 * h < K) ? pb[(int64_t)ktc * GEMM_BK + 2 * h] : 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < NI; i++) {
+        d2_t w = *reinterpret_cast<const d2_t *>(pa[i] + off);
+        ga[s][i][h] = inb ? w : (d2_t){(k0 + 2 * h < K) ? pa[i][(int64_t)ktc * GEMM_BK + 2 * h] : 0.0, 0.0};
+      }
+    }
+  };
+  d4_t acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; i++) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < P; s++) fetch(s, s);
+  for (int kt0 = 0; kt0 < nk; kt0 += P) {
+#pragma unroll
+    for (int s = 0; s < P; s++) {
+      const int kt = kt0 + s;
+      if (kt < nk) {  // wave-uniform
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          *reinterpret_cast<d2_t *>(&tB[wave][r][4 * kq + 2 * h]) = gb[s][h];
+#pragma unroll
+          for (int i = 0; i < NI; i++) *reinterpret_cast<d2_t *>(&tA[wave][i][r][4 * kq + 2 * h]) = ga[s][i][h];
+        }
+        fetch(s, kt + P);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // LDS is in order within a wave
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 4; kk++) {
+          const double b = tB[wave][fr][kk * 4 + fk];
+#pragma unroll
+          for (int i = 0; i < NI; i++)
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(tA[wave][i][fr][kk * 4 + fk], b, acc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    }
+  }
+  const int64_t col = n0 + fr;
+#pragma unroll
+  for (int i = 0; i < NI; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int64_t m = 16 * i + fk + 4 * q;
+      if (m < M && col < N) Cm[(row_idx ? (int64_t)row_idx[m] : m) * ldc + col] = acc[i][q];
+    }
+}
+
 inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const double *A,
                                      int64_t lda, const double *B, int64_t ldb, double *Cm,
                                      int64_t ldc, hipStream_t stream,
@@ -537,6 +627,22 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
   const int grid = ((total + 7) / 8) * 8;
   const bool vec = (lda % 2 == 0) && (ldb % 2 == 0) && ((uintptr_t)A % 16 == 0) &&
                    ((uintptr_t)B % 16 == 0);
+  if (mode == 0 && vec && M <= 128) {  // a few rows: bandwidth-bound tail kernel, one wave per 16 columns
+    const dim3 tg((unsigned)((N + 63) / 64));
+    if (M <= 16)
+      hipLaunchKernelGGL((gemm_nt_f64_tail_kernel<1, 6>), tg, dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc,
+                         row_idx, n_rows, flop_counter);
+    else if (M <= 32)
+      hipLaunchKernelGGL((gemm_nt_f64_tail_kernel<2, 4>), tg, dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc,
+                         row_idx, n_rows, flop_counter);
+    else if (M <= 64)
+      hipLaunchKernelGGL((gemm_nt_f64_tail_kernel<4, 3>), tg, dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc,
+                         row_idx, n_rows, flop_counter);
+    else
+      hipLaunchKernelGGL((gemm_nt_f64_tail_kernel<8, 2>), tg, dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc,
+                         row_idx, n_rows, flop_counter);
+    return hipGetLastError();
+  }
   if (mode == 1) {
     hipLaunchKernelGGL((gemm_nt_f64_kernel<false, 1>), dim3(grid), dim3(256), 0, stream, M, N, K, A, lda,
                        B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);
