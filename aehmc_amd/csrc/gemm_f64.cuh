@@ -230,8 +230,10 @@ __device__ __forceinline__ void gemm_tile_coords(int t, int Tm, int Tn, int &tm,
 // NJ = 4: 128 x 128 tiles, two workgroups per CU.  NJ = 8: 128 x 256 tiles, one workgroup per CU
 // whose four waves own 64 x 128 each (128 f64 accumulators per lane, in AGPRs): a third fewer
 // operand bytes and LDS fragment reads per MFMA.
-template <bool VEC, int NJ>
-__global__ __launch_bounds__(256, (NJ == 8 ? 1 : 2)) void gemm_nt_f64_streamk_kernel(
+// PIPE: the software-pipelined K loop at one workgroup per CU (NJ = 8 always; NJ = 4 for launches
+// with too few wide tiles to fill the CUs)
+template <bool VEC, int NJ, bool PIPE = (NJ == 8)>
+__global__ __launch_bounds__(256, (PIPE ? 1 : 2)) void gemm_nt_f64_streamk_kernel(
     int64_t M, int64_t N, int64_t K, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc,
     const int *__restrict__ row_idx, const int *__restrict__ n_rows,
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256, (NJ == 8 ? 1 : 2)) void gemm_nt_f64_streamk_ke
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
     }
-    if constexpr (NJ == 8) {
+    if constexpr (PIPE) {
       // ---- software-pipelined K loop for the one-wave-per-SIMD tile (K % 16 == 0, 16-byte
       // aligned operands: checked by the launcher).  Nothing hides a stall here, so every
       // non-MFMA instruction is placed between MFMAs: fragments of k-step kk+1 are read while
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256, (NJ == 8 ? 1 : 2)) void gemm_nt_f64_streamk_ke
   // workgroups or when the last round is full to within 4 %; contiguous (tile, k) ranges cost
   // L2 locality (measured: -11 % at 4.94 rounds) and only pay when part of a round would be wasted.
   const long long rounds = (T + G - 1) / G;
-  if (W < nk || (rounds * G - T) * 100 < 4 * (long long)G) {
+  if (T < G || W < nk || (rounds * G - T) * 100 < 4 * (long long)G) {
     for (long long t = blockIdx.x; t < T; t += G) {
       // same tile -> XCD assignment as gemm_tile_of_block within each round
       const long long base = (t / G) * G, left = (T - base < G) ? T - base : G;
@@ -656,6 +658,13 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
   if (vec && sk && sk_grid_wide > 0 && K % GEMM_BK == 0 && Tm * (int)((N + 255) / 256) >= sk_grid_wide) {  // 128 x 256 tiles
     hipLaunchKernelGGL((gemm_nt_f64_streamk_kernel<true, 8>), dim3(sk_grid_wide), dim3(256), 0, stream, M, N, K,
                        A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter, *sk);
+    return hipGetLastError();
+  }
+  if (vec && sk && sk_grid_wide > 0 && K % GEMM_BK == 0 && M > 128) {
+    // 129 .. ~768 rows: too few 128 x 256 tiles for the CUs -- 128 x 128 tiles on the pipelined loop, one
+    // workgroup per CU (one tile each, or even (tile, k) ranges once there are more tiles than CUs)
+    hipLaunchKernelGGL((gemm_nt_f64_streamk_kernel<true, 4, true>), dim3(sk_grid_wide), dim3(256), 0, stream, M, N,
+                       K, A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter, *sk);
     return hipGetLastError();
   }
   if (vec && sk && sk_grid > 0 && total >= sk_grid) {  // enough tiles for an even (tile, k) split
