@@ -180,6 +180,7 @@ struct Ld3 { double a, b, c; };
 struct Ld4 { double a, b, c, d; };
 struct Ld5 { double a, b, c, d, e; };
 struct Ld6 { double a, b, c, d, e, f; };
+struct Ld9 { double a, b, c, d, e, f, g, h, i; };
 
 // ---------------------------------------------------------------------------------
 // Leapfrog stages (integrators.py:54-73).  DO1: p_half = p - (0.5 eps) g.
@@ -417,7 +418,12 @@ __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c,
 }
 
 // dynamic_integration.integrate body, one step: trajectory.py:195-305
-template <bool MET_DENSE>
+// FUSE3 (dense metric, linear mode): the pass below also performs the last leapfrog stage
+// (leap_linear<3>: p' = p_half - b g', v' = v_half - b w', U' for the dense target) on the fly and
+// the first U-turn level of an odd step, so p', v' and the running momentum sum are not read back
+// (3.5 of the ~22 vectors this kernel moves per chain and step).  Every lane adds the same terms in
+// the same order as the separate passes: identical bits.
+template <bool MET_DENSE, bool FUSE3 = false>
 __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, ChainCtl &ct,
                                  ChainRng &rng) {
   const size_t row = (size_t)c * a.D;
@@ -437,6 +443,46 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
   double *cks = a.cks + ((size_t)tmax * a.C + c) * a.D;
   double *ckv = MET_DENSE ? a.ckv + ((size_t)tmax * a.C + c) * a.D : nullptr;
   double kd = 0.0;
+  double f_dl = 0.0, f_dr = 0.0;  // FUSE3: U-turn dots of level tmax (odd steps)
+  const bool f_turn = FUSE3 && step >= 1 && tmax >= tmin;
+  if (FUSE3) {
+    const double step_size = (ct.dir ? 1.0 : -1.0) * (a.eps_c ? a.eps_c[c] : a.eps);
+    const double b = 0.5 * step_size;
+    const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
+    const double *kp = a.ckp + ((size_t)tmax * a.C + c) * a.D;
+    const double *ks = a.cks + ((size_t)tmax * a.C + c) * a.D;
+    const double *kv = a.ckv + ((size_t)tmax * a.C + c) * a.D;
+    double usum = 0.0;
+    wave_pass(a.D, lane,
+              [&](long long i) {
+                return Ld9{a.cur_g[row + i], tdense ? a.rbuf[row + i] : 0.0, a.cur_p[row + i], a.cur_v[row + i],
+                           a.cur_w[row + i], step == 0 ? 0.0 : a.psub[row + i],
+                           f_turn ? kp[i] : 0.0, f_turn ? kv[i] : 0.0, f_turn ? ks[i] : 0.0};
+              },
+              [&](long long i, const Ld9 &x) {
+                if (tdense) usum += x.b * x.a;          // leap_linear<3>
+                const double p = x.c - b * x.a;
+                const double v = x.d - b * x.e;
+                a.cur_p[row + i] = p;
+                a.cur_v[row + i] = v;
+                kd += v * p;                            // bookkeeping pass 1
+                const double s = (step == 0) ? p : x.f + p;
+                a.psub[row + i] = s;
+                if (even) {
+                  ckp[i] = p;
+                  cks[i] = s;
+                  ckv[i] = v;
+                }
+                if (f_turn) {                           // first level of is_iterative_turning
+                  const double pl = x.g, vl = x.h;
+                  const double sub = s - x.i + pl;
+                  const double rho = sub - (p + pl) / 2;
+                  f_dl += vl * rho;
+                  f_dr += v * rho;
+                }
+              });
+    if (tdense) ct.U_cur = target_finish(a, wave_sum(usum));
+  } else
   wave_pass(a.D, lane,
             [&](long long i) {
               return Ld3{a.cur_p[row + i], MET_DENSE ? a.cur_v[row + i] : 0.0, step == 0 ? 0.0 : a.psub[row + i]};
@@ -494,6 +540,10 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
         const double *ks = a.cks + ((size_t)idx * a.C + c) * a.D;
         const double *kv = MET_DENSE ? a.ckv + ((size_t)idx * a.C + c) * a.D : nullptr;
         double d_l = 0.0, d_r = 0.0;
+        if (FUSE3 && idx == tmax) {
+          d_l = f_dl;
+          d_r = f_dr;
+        } else
         wave_pass(a.D, lane,
                   [&](long long i) {
                     return Ld6{kp[i], a.cur_p[row + i], MET_DENSE ? kv[i] : 0.0, MET_DENSE ? a.cur_v[row + i] : 0.0,
@@ -668,6 +718,13 @@ __global__ __launch_bounds__(256) void k_step_linear(EngineArgs a) {
   ChainCtl ct = a.ctl[c];
   if (ct.done) return;
   double U_new = 0.0;
+  if (PHASE == 3 && BOOK) {  // last leapfrog stage fused into the bookkeeping pass
+    ChainRng rng = rng_load(a, c);
+    nuts_book<true, true>(a, c, lane, ct, rng);
+    rng_store(a, c, lane, rng, 1, 3);
+    if (lane == 0) a.ctl[c] = ct;
+    return;
+  }
   bool has_U = leap_linear<PHASE>(a, c, lane, ct.dir, U_new);
   if (BOOK) {
     if (has_U) ct.U_cur = U_new;
