@@ -418,12 +418,14 @@ __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c,
 }
 
 // dynamic_integration.integrate body, one step: trajectory.py:195-305
-// FUSE3 (dense metric, linear mode): the pass below also performs the last leapfrog stage
+// FUSE = 1 (dense metric, linear mode): the pass below also performs the last leapfrog stage
 // (leap_linear<3>: p' = p_half - b g', v' = v_half - b w', U' for the dense target) on the fly and
 // the first U-turn level of an odd step, so p', v' and the running momentum sum are not read back
-// (3.5 of the ~22 vectors this kernel moves per chain and step).  Every lane adds the same terms in
+// (3.5 of the ~22 vectors this kernel moves per chain and step).  FUSE = 2 (diagonal / scalar
+// metric, coordinate-wise target): the whole leapfrog (leap_stages<1,1,1>) runs inside that pass --
+// one trip to memory per step instead of three dependent ones.  Every lane adds the same terms in
 // the same order as the separate passes: identical bits.
-template <bool MET_DENSE, bool FUSE3 = false>
+template <bool MET_DENSE, int FUSE = 0>
 __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, ChainCtl &ct,
                                  ChainRng &rng) {
   const size_t row = (size_t)c * a.D;
@@ -444,8 +446,48 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
   double *ckv = MET_DENSE ? a.ckv + ((size_t)tmax * a.C + c) * a.D : nullptr;
   double kd = 0.0;
   double f_dl = 0.0, f_dr = 0.0;  // FUSE3: U-turn dots of level tmax (odd steps)
-  const bool f_turn = FUSE3 && step >= 1 && tmax >= tmin;
-  if (FUSE3) {
+  constexpr bool FUSE3 = FUSE == 1;
+  const bool f_turn = FUSE != 0 && step >= 1 && tmax >= tmin;
+  if (FUSE == 2) {
+    const double step_size = (ct.dir ? 1.0 : -1.0) * (a.eps_c ? a.eps_c[c] : a.eps);
+    const double b = 0.5 * step_size, aa = 1 * step_size;
+    const double *kp = a.ckp + ((size_t)tmax * a.C + c) * a.D;
+    const double *ks = a.cks + ((size_t)tmax * a.C + c) * a.D;
+    double usum = 0.0;
+    wave_pass(a.D, lane,
+              [&](long long i) {
+                return Ld6{a.cur_p[row + i], a.cur_g[row + i], a.cur_q[row + i], step == 0 ? 0.0 : a.psub[row + i],
+                           f_turn ? kp[i] : 0.0, f_turn ? ks[i] : 0.0};
+              },
+              [&](long long i, const Ld6 &x) {
+                double p = x.a - b * x.b;                       // leap_stages<1,1,1>
+                const double q = x.c + aa * vel_diag(a, c, i, p);
+                a.cur_q[row + i] = q;
+                double u, gnew;
+                target_elem(a, i, q, u, gnew);
+                usum += u;
+                a.cur_g[row + i] = gnew;
+                p = p - b * gnew;
+                a.cur_p[row + i] = p;
+                const double v = vel_diag(a, c, i, p);          // bookkeeping pass 1
+                kd += v * p;
+                const double s2 = (step == 0) ? p : x.d + p;
+                a.psub[row + i] = s2;
+                if (even) {
+                  ckp[i] = p;
+                  cks[i] = s2;
+                }
+                if (f_turn) {                                   // first level of is_iterative_turning
+                  const double pl = x.e;
+                  const double vl = vel_diag(a, c, i, pl);
+                  const double sub = s2 - x.f + pl;
+                  const double rho = sub - (p + pl) / 2;
+                  f_dl += vl * rho;
+                  f_dr += v * rho;
+                }
+              });
+    ct.U_cur = target_finish(a, wave_sum(usum));
+  } else if (FUSE3) {
     const double step_size = (ct.dir ? 1.0 : -1.0) * (a.eps_c ? a.eps_c[c] : a.eps);
     const double b = 0.5 * step_size;
     const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
@@ -540,7 +582,7 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
         const double *ks = a.cks + ((size_t)idx * a.C + c) * a.D;
         const double *kv = MET_DENSE ? a.ckv + ((size_t)idx * a.C + c) * a.D : nullptr;
         double d_l = 0.0, d_r = 0.0;
-        if (FUSE3 && idx == tmax) {
+        if (FUSE != 0 && idx == tmax) {
           d_l = f_dl;
           d_r = f_dr;
         } else
@@ -700,6 +742,13 @@ __global__ __launch_bounds__(256) void k_step(EngineArgs a) {
   if (ct.done) return;
   double U_new = 0.0;
   bool has_U = false;
+  if (DO1 && DO2 && DO3 && !MET_DENSE && BOOK) {  // diagonal metric, coordinate-wise target: one fused pass
+    ChainRng rng = rng_load(a, c);
+    nuts_book<false, 2>(a, c, lane, ct, rng);
+    rng_store(a, c, lane, rng, 1, 3);
+    if (lane == 0) a.ctl[c] = ct;
+    return;
+  }
   if (DO1 || DO2 || DO3) has_U = leap_stages<DO1, DO2, DO3, MET_DENSE>(a, c, lane, ct.dir, U_new);
   if (BOOK) {
     if (has_U) ct.U_cur = U_new;
@@ -720,7 +769,7 @@ __global__ __launch_bounds__(256) void k_step_linear(EngineArgs a) {
   double U_new = 0.0;
   if (PHASE == 3 && BOOK) {  // last leapfrog stage fused into the bookkeeping pass
     ChainRng rng = rng_load(a, c);
-    nuts_book<true, true>(a, c, lane, ct, rng);
+    nuts_book<true, 1>(a, c, lane, ct, rng);
     rng_store(a, c, lane, rng, 1, 3);
     if (lane == 0) a.ctl[c] = ct;
     return;
