@@ -307,6 +307,8 @@ extern "C" int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D,
   if (D > AEHMC_PC_DENSE_MAX_D)
     FAIL("per-chain dense mass matrices are supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
   *ctx->h_err = 0;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_inv_pc),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * D * D * sizeof(double))));
   hipLaunchKernelGGL(k_chol_inv_pc, dim3((unsigned)C), dim3(64), (size_t)2 * D * D * sizeof(double),
                      (hipStream_t)stream, imm, sqrt_mass, (long long)C, (int)D, ctx->d_err);
   HIPCHK(hipGetLastError());
@@ -360,8 +362,10 @@ extern "C" int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t 
   if (state->full) {  // one wavefront per workgroup: the window-end factorisation holds two D x D matrices in LDS
     if (D > AEHMC_PC_DENSE_MAX_D)
       FAIL("full mass-matrix adaptation is supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
-    hipLaunchKernelGGL(k_adapt_update, dim3((unsigned)C), dim3(64), (size_t)2 * D * D * sizeof(double),
-                       (hipStream_t)stream, a);
+    const size_t dyn = (size_t)2 * D * D * sizeof(double);  // up to 64 KB next to 4 KB of static LDS
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_adapt_update),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(k_adapt_update, dim3((unsigned)C), dim3(64), dyn, (hipStream_t)stream, a);
   } else {
     hipLaunchKernelGGL(k_adapt_update, chain_grid(C), dim3(256), 0, (hipStream_t)stream, a);
   }

@@ -208,6 +208,30 @@ def test_adapt_update_kernel_full_matches_oracle():
                                            np.linalg.inv(np.linalg.cholesky(imm)).T, rtol=1e-9, atol=1e-11)
 
 
+def test_adapt_update_kernel_full_at_the_size_limit():
+    """D = 64 (the largest per-chain dense metric): two D x D matrices per wavefront in LDS at a
+    window end."""
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    C, D, num_steps = 3, 64, 120
+    r = np.random.default_rng(13)
+    st, cst = eng.adapt_alloc(C, D, full=True)
+    eng.adapt_init(C, D, 1.0, cst)
+    init, update = na.window_adaptation(num_steps, is_mass_matrix_full=True, initial_step_size=1.0)
+    ref = [init(np.zeros(D)) for _ in range(C)]
+    mix = r.normal(size=(D, D)) / np.sqrt(D) + np.eye(D)
+    for i, (stage, wend) in enumerate(na.build_schedule(num_steps)):
+        pa = r.random(C)
+        pos = r.normal(size=(C, D)) @ mix
+        eng.adapt_update(C, D, stage, wend, i == num_steps - 1, 0.8, torch.as_tensor(pa, device="cuda"),
+                         torch.as_tensor(pos, device="cuda"), cst)
+        ref = [update(i, ws, pr, pos[c], pa[c]) for c, (ws, pr) in enumerate(ref)]
+    for c, ((da, mm), (eps, imm)) in enumerate(ref):
+        np.testing.assert_allclose(st["imm"][c].cpu().numpy(), imm, rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(st["sqrt_mass"][c].cpu().numpy(), np.linalg.inv(np.linalg.cholesky(imm)).T,
+                                   rtol=1e-8, atol=1e-10)
+
+
 def test_window_adaptation_full_matches_oracle():
     """End to end with is_mass_matrix_full=True on identical seeds (60 steps, see above)."""
     from aehmc_amd import RandomStream, nuts, targets, window_adaptation
