@@ -135,8 +135,8 @@ def test_metric_sqrt_per_chain_matches_numpy():
 
 
 @pytest.mark.parametrize("kind", ["nuts", "hmc"])
-@pytest.mark.parametrize("linear", [1, 0])
-def test_per_chain_dense_metric_matches_oracle(kind, linear):
+@pytest.mark.parametrize("linear,D", [(1, 5), (0, 5), (1, 64)])
+def test_per_chain_dense_metric_matches_oracle(kind, linear, D):
     """Every chain with its own dense inverse mass matrix (per-chain mat-vecs instead of the
     chain-batched GEMM): chain c equals the oracle run with matrix c."""
     from aehmc_amd import PerChain, RandomStream, hmc, nuts, targets
@@ -145,13 +145,13 @@ def test_per_chain_dense_metric_matches_oracle(kind, linear):
     eng.set_option("dense_linear", linear)
     try:
         r = np.random.default_rng(21)
-        C, D = 6, 5
+        C = 6
         mu, sigma = r.normal(size=D), 0.5 + r.random(D)
         tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
         A = r.normal(size=(C, D, D))
         imm = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D)
         imm = 0.5 * (imm + imm.transpose(0, 2, 1))
-        eps = 0.3 * (0.5 + r.random(C))
+        eps = 0.3 * (0.5 + r.random(C)) * (5 / D) ** 0.25
         seeds = [70 + c for c in range(C)]
         q0 = r.normal(size=(C, D))
         mod = nuts if kind == "nuts" else hmc
