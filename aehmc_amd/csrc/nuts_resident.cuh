@@ -615,8 +615,10 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 
 inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
   if (tkind == AEHMC_T_LINREG) return met_ndim < 2 && D == 2;
+  // (D = 1e4 needs 160 000 of the CU's 163 840 bytes of LDS for q and dU/dq; the kernel's small
+  //  static arrays leave room for D up to 10176)
   return (tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN) &&
-         met_ndim < 2 && D <= 10240;
+         met_ndim < 2 && D <= 10176;
 }
 
 template <int T, int R, bool QGL = false, bool LR = false>

@@ -114,7 +114,7 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *  "resident_nuts" 2 register-resident single-launch NUTS (a team of 1..64 lanes, or a
  *                   256/1024-thread workgroup for large D, keeps the chain's moving state in
  *                   VGPRs for the whole tree) for diagonal/scalar metrics, coordinate-wise
- *                   targets, D <= 10240, and the regression target (four chains per workgroup
+ *                   targets, D <= 10176, and the regression target (four chains per workgroup
  *                   share each pass over the data rows).  2 = auto (used when D > 256,
  *                   C >= 16384 or 8 <= C <= 2048, where it beats the lock-step path, and always
  *                   for the regression target), 1 = always, 0 = never

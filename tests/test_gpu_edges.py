@@ -132,3 +132,31 @@ def test_per_chain_parameters_equal_single_chain_runs(kind, D):
         single = run([seeds[c]], q0[c:c + 1], float(eps[c]), torch.as_tensor(imm[c], device="cuda"))
         for (qb, ab), (qs, a_s) in zip(batch, single):
             assert torch.equal(qb[c], qs[0]) and torch.equal(ab[c], a_s[0])
+
+
+@pytest.mark.parametrize("D", [1025, 10176, 10240, 10241])
+def test_kernel_family_boundaries_at_large_d(D):
+    """D at the edges of the wide-HMC (1025..10240) and resident-NUTS (..10176, LDS-bound) ranges:
+    each side of a boundary runs (resident or lock-step) and agrees with the other path."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    C = 3
+    tgt = targets.IsoGaussian()
+    imm = torch.ones(D, dtype=torch.float64, device="cuda")
+    q0 = torch.as_tensor(np.random.default_rng(D).standard_normal((C, D)), device="cuda")
+    try:
+        for mod, extra in ((hmc, (5,)), (nuts, ())):
+            outs = []
+            for opt in (1, 0):
+                eng.set_option("fused_hmc", opt)
+                eng.set_option("resident_nuts", 2 if opt else 0)
+                k = mod.new_kernel(RandomStream(seeds=[1, 2, 3]), tgt)
+                info, _ = k(mod.new_state(q0, tgt), 0.05, imm, *extra)
+                outs.append(info)
+            np.testing.assert_allclose(outs[0].state.position.cpu().numpy(), outs[1].state.position.cpu().numpy(),
+                                       rtol=1e-12, atol=1e-14)
+            assert torch.equal(outs[0].n_leapfrog, outs[1].n_leapfrog)
+    finally:
+        eng.set_option("fused_hmc", 1)
+        eng.set_option("resident_nuts", 2)
