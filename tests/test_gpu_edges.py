@@ -134,7 +134,7 @@ def test_per_chain_parameters_equal_single_chain_runs(kind, D):
             assert torch.equal(qb[c], qs[0]) and torch.equal(ab[c], a_s[0])
 
 
-@pytest.mark.parametrize("D", [1025, 10176, 10240, 10241])
+@pytest.mark.parametrize("D", [256, 257, 512, 513, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 8193, 10176, 10240, 10241])
 def test_kernel_family_boundaries_at_large_d(D):
     """D at the edges of the wide-HMC (1025..10240) and resident-NUTS (..10176, LDS-bound) ranges:
     each side of a boundary runs (resident or lock-step) and agrees with the other path."""
