@@ -160,3 +160,28 @@ def test_kernel_family_boundaries_at_large_d(D):
     finally:
         eng.set_option("fused_hmc", 1)
         eng.set_option("resident_nuts", 2)
+
+
+@pytest.mark.parametrize("C,D", [(7, 3), (8, 3), (2048, 3), (2049, 3), (16384, 2), (16383, 100)])
+def test_auto_kernel_choice_boundaries_in_chain_count(C, D):
+    """The automatic resident / lock-step choice changes at 8, 2048 and 16384 chains: both sides of
+    each boundary give what the lock-step path gives."""
+    from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    tgt = targets.DiagGaussian(np.linspace(-1, 1, D), np.linspace(0.5, 2.0, D))
+    imm = torch.ones(D, dtype=torch.float64, device="cuda")
+    q0 = torch.as_tensor(np.random.default_rng(C).standard_normal((C, D)), device="cuda")
+    outs = []
+    try:
+        for opt in (2, 0):
+            eng.set_option("resident_nuts", opt)
+            k = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+            info, _ = k(nuts.new_state(q0, tgt), 0.3, imm)
+            outs.append(info)
+    finally:
+        eng.set_option("resident_nuts", 2)
+    np.testing.assert_allclose(outs[0].state.position.cpu().numpy(), outs[1].state.position.cpu().numpy(),
+                               rtol=1e-12, atol=1e-14)
+    assert torch.equal(outs[0].n_leapfrog, outs[1].n_leapfrog)
+    assert torch.equal(outs[0].is_turning, outs[1].is_turning)
