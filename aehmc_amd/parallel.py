@@ -1,6 +1,6 @@
 """Multi-GPU plumbing: one process per GPU, chains sharded contiguously, no data-path
-collective during sampling; the only exchange is the gather of samples/diagnostics
-(RCCL all_gather over xGMI on GPUs, gloo in the CPU tests) -- SURVEY.md 8e.
+collective during sampling; the only exchange is the gather of samples/diagnostics to
+rank 0 (RCCL over xGMI on GPUs, gloo in the CPU tests) -- SURVEY.md 8e.
 
 The reference has no counterpart (single chain, single process)."""
 from __future__ import annotations
@@ -49,26 +49,39 @@ def barrier(device=None):
             dist.barrier()
 
 
-def gather_samples(x: torch.Tensor) -> torch.Tensor:
-    """All-gather the per-rank rows [C_r, ...] into [sum C_r, ...] (rank order)."""
+def gather_samples(x: torch.Tensor, dst: int = 0):
+    """The path's one exchange step: gather the per-rank rows [C_r, ...] into
+    [sum C_r, ...] (rank order) ON RANK ``dst`` -- every other rank returns None.  Each shard
+    crosses xGMI once, straight to the destination (RCCL gather = point-to-point sends), instead
+    of the (w-1) x shard traffic per rank of an all-gather.  ``dst=None`` all-gathers."""
     if not _on():
         return x
     w = dist.get_world_size()
     x = x.contiguous()
     if _cpu_backend() and x.is_cuda:  # gloo dry runs: stage through the host
-        return gather_samples(x.cpu()).to(x.device)
+        out = gather_samples(x.cpu(), dst)
+        return None if out is None else out.to(x.device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(w)]
     dist.all_gather(sizes, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
     sizes = [int(s.item()) for s in sizes]
-    if len(set(sizes)) == 1:
-        out = torch.empty((w * sizes[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x)
-        return out
     mx = max(sizes)
-    pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    pad[: x.shape[0]] = x
-    parts = [torch.empty_like(pad) for _ in range(w)]
-    dist.all_gather(parts, pad)
+    if mx != x.shape[0]:  # ragged shards: pad to the largest
+        pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        pad[: x.shape[0]] = x
+        x = pad
+    if dst is None:
+        out = torch.empty((w * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x)
+        parts = list(out.split(mx, dim=0))
+    elif dist.get_rank() == dst:
+        out = torch.empty((w * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        parts = list(out.split(mx, dim=0))  # views: the shards land in place
+        dist.gather(x, parts, dst=dst)
+    else:
+        dist.gather(x, None, dst=dst)
+        return None
+    if len(set(sizes)) == 1:
+        return out
     return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
 
 

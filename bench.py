@@ -7,16 +7,18 @@ max_tree_depth=10, 4096 chains per GPU, synthetic inputs of SURVEY.md 8d.  A "st
 one NUTS transition of every chain of the rank.  `--config c2` runs the 100-dim HMC
 (L=32, diagonal mass) configuration instead.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N child ranks itself)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Chains shard embarrassingly: each rank owns 4096 chains with its own seeds ("weak"
-scaling); the only collective is the final gather of the last sample (RCCL all_gather),
-which is inside the timed region.  Rank 0 prints ONE JSON line.
+scaling); the only collective is the final gather of the last sample to rank 0 (RCCL over
+xGMI), which is inside the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,6 +52,29 @@ def build_c3(D, device, rho=0.5):
     return Sigma.contiguous(), P.contiguous()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one process per
+    GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches
+    the GPU -- children are new processes, nothing is exec'ed over an initialised HIP runtime."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(rcs):
+        sys.exit(f"bench.py: rank exit codes {rcs}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,17 +87,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        have = torch.cuda.device_count()  # counts devices without initialising the GPU
+        if have < args.gpus and os.environ.get("AEHMC_BENCH_ONE_DEVICE") != "1":
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible")
+        return launch_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # dry-run knobs for a 1-GPU box: AEHMC_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and
     # AEHMC_DIST_BACKEND=gloo swaps RCCL for gloo (the driver's multi-GPU runs use neither)
     if os.environ.get("AEHMC_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    dist_backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("AEHMC_DIST_BACKEND", "nccl")
+        backend = dist_backend = os.environ.get("AEHMC_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -93,6 +126,8 @@ def main():
         return bench_c5(args, rank, world, device)
     C = args.chains
     eng = get_engine(device)
+    if os.environ.get("AEHMC_BENCH_ONE_DEVICE") == "1" and world > 1:
+        eng.set_option("streamk", 0)  # ranks share the device: the persistent stream-K grid is not co-resident
     seeds = [1000 + rank * C + c for c in range(C)]
     q0 = np.random.default_rng(1234 + rank).standard_normal((C, args.dim or (100 if args.config == "c2" else 10_000)))
     D = q0.shape[1]
@@ -138,15 +173,19 @@ def main():
         info, _ = step(state)
         state = info.state._replace(momentum=None)
         n_leap += info.n_leapfrog.sum()
-    gathered = gather_samples(state.position)  # the path's one exchange step
     torch.cuda.synchronize(device)
+    t_g = time.perf_counter()
+    gathered = gather_samples(state.position)  # the path's one exchange step: to rank 0
+    torch.cuda.synchronize(device)
+    t_g = time.perf_counter() - t_g
     barrier(device)
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, device)
     total_leap = sum_over_ranks(int(n_leap.item()), device)
+    ranks_seen = sum_over_ranks(1, device)
     kern_ms, kern_n, kern_flops = eng.profile_read()
     eng.profile_enable(False)
-    assert gathered.shape[0] == C * world
+    assert rank != 0 or gathered.shape[0] == C * world
 
     if rank != 0:
         return
@@ -195,7 +234,9 @@ def main():
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "chains_total": C * world, "dim": D,
-                   "leapfrogs_per_step": total_leap / args.steps},
+                   "leapfrogs_per_step": total_leap / args.steps, "ranks_seen": ranks_seen,
+                   "gather": {"to": "rank 0", "bytes": (world - 1) * C * D * 8, "ms": t_g * 1e3,
+                              "backend": dist_backend}},
         "roofline": roofline, "cpu_baseline": cpu}))
 
 
@@ -251,14 +292,16 @@ def bench_c5(args, rank, world, device):
     barrier(device)
     elapsed = max_over_ranks(time.perf_counter() - t0, device)
     total = sum_over_ranks(int(info.n_leapfrog.sum().item()), device)
+    chains_total = sum_over_ranks(C, device)
     if rank == 0:
+        assert gathered.shape[0] == chains_total
         print(json.dumps({
             "metric": "leapfrog-steps/sec across all chains", "value": total / elapsed, "unit": "leapfrog-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"c5: linear regression, {N} rows, D=2, NUTS after {max(args.warmup, 20)} "
                                    f"window-adaptation steps ({t_w:.2f} s), {C} chains/GPU",
-                       "chains_total": int(gathered.shape[0]), "data_rows_per_s": total / elapsed * N},
+                       "chains_total": chains_total, "data_rows_per_s": total / elapsed * N},
             "roofline": None, "cpu_baseline": None}))
 
 

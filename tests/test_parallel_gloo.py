@@ -29,9 +29,13 @@ def _worker(rank, world, port, total, tmp):
     # stand-in for the per-rank samples: row c holds the chain's global index and seed
     x = torch.tensor([[c, 1000 + c, rank] for c in range(lo, hi)], dtype=torch.float64)
     parallel.barrier()
-    g = parallel.gather_samples(x)
-    assert g.shape == (total, 3)
-    assert torch.equal(g[:, 0], torch.arange(total, dtype=torch.float64))
+    g = parallel.gather_samples(x)  # to rank 0 only (the bench / sampling path)
+    assert (g is None) == (rank != 0)
+    ga = parallel.gather_samples(x, dst=None)  # all-gather variant
+    assert ga.shape == (total, 3)
+    assert torch.equal(ga[:, 0], torch.arange(total, dtype=torch.float64))
+    if rank == 0:
+        assert torch.equal(g, ga)
     assert parallel.max_over_ranks(float(rank)) == world - 1
     assert parallel.sum_over_ranks(hi - lo) == total
     if rank == 0:
@@ -55,3 +59,20 @@ def test_shards_partition():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_bench_refuses_mismatched_world():
+    """`bench.py --gpus N` under a launcher that set a different WORLD_SIZE must not silently run
+    one rank and report n_gpus=1 (round-1 finding); it exits before touching any GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "does not match WORLD_SIZE" in out.stderr
+    env.pop("WORLD_SIZE")
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "GPU(s) visible" in out.stderr
