@@ -7,6 +7,7 @@ import torch
 
 from .engine import _dev_f64, get_engine
 from .integrators import IntegratorState
+from .trajectory import Diagnostics
 
 
 class Layout:
@@ -69,3 +70,25 @@ def new_state(q, logprob_fn, num_chains=None) -> IntegratorState:
     return IntegratorState(position=layout.vec(rows), momentum=None,
                            potential_energy=layout.per_chain(U),
                            potential_energy_grad=layout.vec(g))
+
+
+def diagnostics(layout: Layout, q, U, g, out, tree: bool) -> Diagnostics:
+    """trajectory.py:379-384 record from the engine's [C, ...] outputs (``tree``: NUTS fields;
+    HMC returns None for them as hmc.py:199-204 does)."""
+    return Diagnostics(
+        state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
+                              potential_energy=layout.per_chain(U),
+                              potential_energy_grad=layout.vec(g)),
+        acceptance_probability=layout.per_chain(out["acceptance_probability"]),
+        num_doublings=layout.per_chain(out["num_doublings"]) if tree else None,
+        is_turning=layout.per_chain(out["is_turning"].bool()) if tree else None,
+        is_diverging=layout.per_chain(out["is_diverging"].bool()),
+        n_leapfrog=layout.per_chain(out["n_leapfrog"]))
+
+
+def histories(layout: Layout, out, n: int, keep_samples: bool):
+    """(samples [N, ...], acceptance history, divergence history) of a sample() call."""
+    samples = out["samples"].reshape((n,) + layout.user_shape) if keep_samples else None
+    hist_shape = (n,) + layout.scalar_chain_shape
+    return (samples, out["acceptance_history"].reshape(hist_shape),
+            out["divergence_history"].bool().reshape(hist_shape))

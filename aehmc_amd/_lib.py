@@ -18,7 +18,7 @@ class CTarget(ct.Structure):
 
 class CMetric(ct.Structure):
     _fields_ = [("ndim", ct.c_int32), ("per_chain", ct.c_int32), ("D", ct.c_int64),
-                ("imm", ct.c_void_p), ("sqrt_mass", ct.c_void_p)]
+                ("imm", ct.c_void_p), ("sqrt_mass", ct.c_void_p), ("n_chains", ct.c_int64)]
 
 
 class CAdaptState(ct.Structure):
@@ -41,7 +41,7 @@ SYMBOLS = {
     "aehmc_last_error": (ct.c_char_p, [_P]),
     "aehmc_set_target": (_I, [_P, ct.POINTER(CTarget)]),
     "aehmc_set_metric": (_I, [_P, ct.POINTER(CMetric)]),
-    "aehmc_set_step_sizes": (_I, [_P, _P]),
+    "aehmc_set_step_sizes": (_I, [_P, _P, _I64]),
     "aehmc_metric_sqrt_per_chain": (_I, [_P, _I64, _I64, _P, _P, _P]),
     "aehmc_adapt_init": (_I, [_P, _I64, _I64, _D, ct.POINTER(CAdaptState), _P]),
     "aehmc_adapt_update": (_I, [_P, _I64, _I64, ct.c_int32, ct.c_int32, ct.c_int32, _D, _P, _P,
@@ -64,6 +64,7 @@ SYMBOLS = {
     "aehmc_gemm_nt": (_I, [_P, _I64, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P]),
     "aehmc_profile_enable": (_I, [_P, _I]),
     "aehmc_profile_read": (_I, [_P, ct.POINTER(_D), ct.POINTER(_I64), ct.POINTER(_D)]),
+    "aehmc_synchronize": (_I, [_P, _P]),
 }
 
 

@@ -33,6 +33,7 @@ struct aehmc_ctx {
   double *own_sqrt_mass = nullptr;  // computed by aehmc_set_metric when the caller passes none
   int64_t own_sqrt_mass_n = 0;
   const double *eps_c = nullptr;  // per-chain step sizes (aehmc_set_step_sizes)
+  int64_t eps_n = 0;
   void *ws = nullptr;
   int64_t ws_bytes = 0;
   int *h_active = nullptr;  // pinned, device-visible
@@ -58,7 +59,9 @@ struct aehmc_ctx {
   double *sk_partial = nullptr;
   int *sk_flags = nullptr;
   int sk_epoch = 0;
-  int *h_err = nullptr, *d_err = nullptr;  // pinned: a bounded spin expired
+  // pinned, device-visible error words: [0] a bounded stream-K spin expired, [1] a per-chain
+  // matrix was not positive definite (separate words: one must not erase the other)
+  int *h_err = nullptr, *d_err = nullptr;
   double prof_flops = 0.0;
 };
 
@@ -130,8 +133,8 @@ extern "C" int aehmc_create(aehmc_ctx **out, int device) {
       HIPCHK(hipMalloc((void **)&ctx->sk_flags, ctx->sk_grid * sizeof(int)));
       HIPCHK(hipMemset(ctx->sk_flags, 0, ctx->sk_grid * sizeof(int)));
     }
-    HIPCHK(hipHostMalloc((void **)&ctx->h_err, sizeof(int), hipHostMallocMapped));
-    *ctx->h_err = 0;
+    HIPCHK(hipHostMalloc((void **)&ctx->h_err, 2 * sizeof(int), hipHostMallocMapped));
+    ctx->h_err[0] = ctx->h_err[1] = 0;
     HIPCHK(hipHostGetDevicePointer((void **)&ctx->d_err, ctx->h_err, 0));
   }
   HIPCHK(hipMalloc((void **)&ctx->d_flops, sizeof(unsigned long long)));
@@ -275,6 +278,7 @@ extern "C" int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *m) {
     FAIL("per-chain dense mass matrices are supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
   if (m->per_chain && !m->sqrt_mass)
     FAIL("per-chain metrics need sqrt_mass (dense: aehmc_metric_sqrt_per_chain)");
+  if (m->per_chain && m->n_chains <= 0) FAIL("per-chain metrics need n_chains");
   aehmc_metric met = *m;
   if (!met.sqrt_mass) {  // metrics.py:45,49,56-58 computed here
     const int64_t n = m->ndim == 0 ? 1 : (m->ndim == 1 ? m->D : m->D * m->D);
@@ -306,23 +310,25 @@ extern "C" int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D,
   if (!imm || !sqrt_mass || C <= 0 || D <= 0) FAIL("metric_sqrt_per_chain: bad arguments");
   if (D > AEHMC_PC_DENSE_MAX_D)
     FAIL("per-chain dense mass matrices are supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
-  *ctx->h_err = 0;
+  ctx->h_err[1] = 0;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_inv_pc),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * D * D * sizeof(double))));
   hipLaunchKernelGGL(k_chol_inv_pc, dim3((unsigned)C), dim3(64), (size_t)2 * D * D * sizeof(double),
-                     (hipStream_t)stream, imm, sqrt_mass, (long long)C, (int)D, ctx->d_err);
+                     (hipStream_t)stream, imm, sqrt_mass, (long long)C, (int)D, ctx->d_err + 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  if (*ctx->h_err) {
-    *ctx->h_err = 0;
+  if (ctx->h_err[1]) {
+    ctx->h_err[1] = 0;
     FAIL("inverse mass matrix of some chain is not positive definite");
   }
   return 0;
 }
 
-extern "C" int aehmc_set_step_sizes(aehmc_ctx *ctx, const double *step_sizes) {
+extern "C" int aehmc_set_step_sizes(aehmc_ctx *ctx, const double *step_sizes, int64_t n) {
   if (!ctx) return -2;
+  if (step_sizes && n <= 0) FAIL("set_step_sizes: n must be the number of chains");
   ctx->eps_c = step_sizes;
+  ctx->eps_n = step_sizes ? n : 0;
   return 0;
 }
 
@@ -452,10 +458,21 @@ extern "C" int aehmc_set_workspace(aehmc_ctx *ctx, void *ws, int64_t bytes) {
   return 0;
 }
 
+// per-chain parameters are indexed [c] for c < C: a different length would read out of bounds
+static int check_per_chain(aehmc_ctx *ctx, int64_t C) {
+  if (ctx->eps_c && ctx->eps_n != C)
+    FAIL("per-chain step sizes have " + std::to_string(ctx->eps_n) + " entries, the call has " +
+         std::to_string(C) + " chains");
+  if (ctx->has_met && ctx->met.per_chain && ctx->met.n_chains != C)
+    FAIL("per-chain inverse mass matrix has " + std::to_string(ctx->met.n_chains) + " rows, the call has " +
+         std::to_string(C) + " chains");
+  return 0;
+}
 static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a) {
   if (!ctx->has_tgt || !ctx->has_met) FAIL("set_target and set_metric must be called first");
   if (ctx->tgt.D != ctx->met.D) FAIL("target and metric dimensions differ");
   if (C <= 0) FAIL("C must be positive");
+  if (int rc = check_per_chain(ctx, C)) return rc;
   memset(&a, 0, sizeof(a));
   int64_t need = ws_layout(ctx, C, E, (char *)ctx->ws, &a);
   if (!ctx->ws || need > ctx->ws_bytes)
@@ -478,12 +495,51 @@ static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a) {
 }
 
 // ------------------------------------------------------------------ GEMM + profiling
+// HIP-event pairs around the dominant kernel's launches.  When the pool is used up the finished
+// pairs are folded into the totals and the pool is reused, so long runs are covered completely.
+static int prof_drain(aehmc_ctx *ctx) {
+  for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+    HIPCHK(hipEventSynchronize(ctx->prof_ev[i + 1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+    ctx->prof_ms += ms;
+    ctx->prof_n += 1;
+  }
+  ctx->prof_used = 0;
+  return 0;
+}
+static int prof_begin(aehmc_ctx *ctx, hipStream_t st, bool &on) {
+  on = ctx->prof && !ctx->prof_ev.empty();
+  if (!on) return 0;
+  if (ctx->prof_used + 2 > ctx->prof_ev.size())
+    if (int rc = prof_drain(ctx)) return rc;
+  HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+  return 0;
+}
+static int prof_end(aehmc_ctx *ctx, hipStream_t st, bool on) {
+  if (!on) return 0;
+  HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
+  ctx->prof_used += 2;
+  return 0;
+}
+// A stream-K hand-off that timed out leaves garbage partial sums: every entry point that waits
+// for the device (lagging poll, profile_read, aehmc_synchronize) and every GEMM launch reports it.
+static int check_device_errors(aehmc_ctx *ctx) {
+  if (ctx->h_err && ctx->h_err[0]) FAIL("stream-K GEMM: a workgroup hand-off timed out (results invalid)");
+  return 0;
+}
+extern "C" int aehmc_synchronize(aehmc_ctx *ctx, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return check_device_errors(ctx);
+}
 static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A, int64_t lda,
                 const double *B, int64_t ldb, double *Cm, int64_t ldc, hipStream_t st,
                 const int *row_idx, const int *n_rows, int mode) {
-  const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
-  if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
-  if (*ctx->h_err) FAIL("stream-K GEMM: a workgroup hand-off timed out (results invalid)");
+  bool p = false;
+  if (int rc = prof_begin(ctx, st, p)) return rc;
+  if (int rc = check_device_errors(ctx)) return rc;
   GemmStreamK sk{ctx->sk_partial, ctx->sk_flags, ctx->d_err, ++ctx->sk_epoch};
   const bool use_sk = ctx->opt_streamk && ctx->sk_grid > 0;
   // the kernels read the exact row count on the device; the host only picks the kernel and the
@@ -493,11 +549,7 @@ static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A
   HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st, row_idx, n_rows,
                             p ? ctx->d_flops : nullptr, (use_sk && mode == 0) ? &sk : nullptr, ctx->sk_grid,
                             mode, ctx->opt_streamk == 2 ? ctx->sk_grid_wide : 0));
-  if (p) {
-    HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
-    ctx->prof_used += 2;
-  }
-  return 0;
+  return prof_end(ctx, st, p);
 }
 
 // X [C,D] times the metric matrix `mat` (imm or sqrt_mass): one GEMM over all chains when the
@@ -534,14 +586,7 @@ extern "C" int aehmc_profile_read(aehmc_ctx *ctx, double *ms_total, int64_t *lau
                                   double *flops_total) {
   if (!ctx) return -2;
   HIPCHK(hipSetDevice(ctx->device));
-  for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
-    HIPCHK(hipEventSynchronize(ctx->prof_ev[i + 1]));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
-    ctx->prof_ms += ms;
-    ctx->prof_n += 1;
-  }
-  ctx->prof_used = 0;
+  if (int rc = prof_drain(ctx)) return rc;
   unsigned long long fl = 0;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(&fl, ctx->d_flops, sizeof(fl), hipMemcpyDeviceToHost));
@@ -550,7 +595,7 @@ extern "C" int aehmc_profile_read(aehmc_ctx *ctx, double *ms_total, int64_t *lau
   if (ms_total) *ms_total = ctx->prof_ms;
   if (launches) *launches = ctx->prof_n;
   if (flops_total) *flops_total = ctx->prof_flops;
-  return 0;
+  return check_device_errors(ctx);
 }
 
 extern "C" int aehmc_gemm_nt(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A,
@@ -681,16 +726,17 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   // auto (measured crossovers, tools/nuts_diag_bench.py): the resident kernel wins when the state
   // no longer fits the lock-step kernels' on-chip reuse (D > 256), when there are enough chains
   // to fill the GPU with sub-wavefront teams (C >= 16384), and in the latency regime -- up to
-  // 2048 chains all teams are resident at once and one launch replaces one launch per leapfrog;
+  // 2048 chains (down to the single chain of the README example) all teams are resident at once
+  // and one launch replaces one launch per leapfrog;
   // a few thousand chains of small D run faster in lock step.  The regression target always
   // takes its workgroup-cooperative resident kernel.
   const bool want_resident =
       ctx->opt_resident_nuts == 1 ||
       (ctx->opt_resident_nuts == 2 &&
-       (a.D > 256 || C >= 16384 || (C >= 8 && C <= 2048) || a.tkind == AEHMC_T_LINREG));
+       (a.D > 256 || C >= 16384 || C <= 2048 || a.tkind == AEHMC_T_LINREG));
   if (want_resident && nuts_resident_supported(a.tkind, a.met_ndim, a.D)) {
-    const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
-    if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
     if (a.D > 512) {  // workgroup-per-chain teams: momentum drawn at one wavefront per chain first
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, a.rng, a.nsites, (long long)C,
                          (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf);
@@ -698,21 +744,13 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       a.z_ready = 1;
     }
     HIPCHK(launch_nuts_resident(a, st, ctx->opt_resident_min_team));
-    if (p) {
-      HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
-      ctx->prof_used += 2;
-    }
-    return 0;
+    return prof_end(ctx, st, p);
   }
   if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
-    const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
-    if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
     LAUNCH(k_nuts_fused, C, st, a);
-    if (p) {
-      HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
-      ctx->prof_used += 2;
-    }
-    return 0;
+    return prof_end(ctx, st, p);
   }
   ctx->rows_hint = 0;
   if (int rc = launch_begin(ctx, a, true, st)) return rc;
@@ -731,6 +769,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     if (batch >= 2) {  // lagging poll: never drains the queue
       int slot = (batch - 2) % NRING;
       HIPCHK(hipEventSynchronize(ctx->ev[slot]));
+      if (int rc = check_device_errors(ctx)) return rc;
       if (ctx->h_active[slot] == 0) break;
       if (compact) ctx->rows_hint = ctx->h_active[slot];
     }
@@ -813,6 +852,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   const int64_t D = ctx->tgt.D;
   // fused register-resident path (hmc_fused.cuh): diagonal/scalar metric, coordinate-wise target
   if (ctx->opt_fused_hmc && hmc_fused_supported(ctx->tgt.kind, ctx->met.ndim, D)) {
+    if (int rc = check_per_chain(ctx, C)) return rc;
     HmcFusedArgs f{};
     f.C = C; f.D = D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
     f.met_ndim = ctx->met.ndim; f.imm = ctx->met.imm; f.sqrt_mass = ctx->met.sqrt_mass;
@@ -821,14 +861,10 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
     f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
     f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;
-    const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
-    if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
     HIPCHK(launch_hmc_fused(f, st));
-    if (p) {
-      HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
-      ctx->prof_used += 2;
-    }
-    return 0;
+    return prof_end(ctx, st, p);
   }
   EngineArgs a;
   if (int rc = fill_args(ctx, C, 1, a)) return rc;
@@ -843,8 +879,8 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     // one launch pair per transition: the momentum draw runs at one wavefront per chain
     // (k_draw_momentum), the workgroup-per-chain kernel then integrates and accepts
     f.T = 1;
-    const bool p = ctx->prof && ctx->prof_used + 2 <= ctx->prof_ev.size();
-    if (p) HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used], st));
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
     for (int64_t t = 0; t < T; t++) {
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, rng, 2, (long long)C, (long long)D,
                          f.sqrt_mass, f.imm_cs, f.met_ndim, a.zbuf);
@@ -857,11 +893,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     }
     if (T > 1 && out->n_leapfrog)
       LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
-    if (p) {
-      HIPCHK(hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], st));
-      ctx->prof_used += 2;
-    }
-    return 0;
+    return prof_end(ctx, st, p);
   }
   a.eps = step_size; a.thr = divergence_threshold;
   a.rng = rng; a.nsites = 2;

@@ -3,12 +3,36 @@ buffers handed to it.  PyTorch is used for device memory and streams only."""
 from __future__ import annotations
 
 import ctypes as ct
+import hashlib
 
 import numpy as np
 import torch
 
+try:  # fast content hash for large host-side matrices (offline wheelhouse); hashlib otherwise
+    import xxhash
+except ImportError:  # pragma: no cover
+    xxhash = None
+
 from . import _lib
 from .targets import Target
+
+
+def _content_key(arr: np.ndarray):
+    """Key a host array by CONTENT: numpy inputs may be edited in place between calls (the
+    reference re-reads the matrix on every call), so id() alone must never hit the cache."""
+    buf = memoryview(np.ascontiguousarray(arr)).cast("B")
+    if xxhash is not None:
+        return xxhash.xxh3_128_hexdigest(buf)
+    return hashlib.blake2b(buf, digest_size=16).hexdigest()
+
+
+def _asymmetry(t: torch.Tensor) -> float:
+    """max |t - t^T| in row blocks (no D x D temporary)."""
+    worst, D = 0.0, t.shape[0]
+    for lo in range(0, D, 1024):
+        hi = min(D, lo + 1024)
+        worst = max(worst, float((t[lo:hi] - t[:, lo:hi].T).abs().max()))
+    return worst
 
 
 def _dev_f64(x, device):
@@ -102,16 +126,19 @@ class Engine:
                 f"Expected a mass matrix of dimension 1 (diagonal) or 2, got {ndim}")
         if isinstance(imm, torch.Tensor):
             key = (id(imm), imm._version, D)
-        else:  # numpy / python scalars may be mutated in place: key small ones by content
+        else:  # numpy / python scalars may be mutated in place: keyed by content, whatever the size
             arr = np.asarray(imm, dtype=np.float64)
-            key = (id(imm), hash(arr.tobytes()) if arr.size <= 65536 else None, D)
+            key = (arr.shape, _content_key(arr), D)
         if self._metric_key == key:
             return
         t = _dev_f64(imm, self.device)
         if ndim == 2:
             if t.shape != (D, D):
                 raise ValueError(f"dense inverse mass matrix must be [{D},{D}], got {tuple(t.shape)}")
-            if not torch.allclose(t, t.T, rtol=1e-12, atol=0):
+            # the reference factors one triangle (metrics.py:56) and multiplies by the full matrix
+            # (metrics.py:71); the two agree for a symmetric matrix.  Estimates such as A @ A.T or
+            # a Welford covariance are symmetric only up to rounding: tolerate that much.
+            if _asymmetry(t) > 1e-10 * float(t.diagonal().abs().max()):
                 raise ValueError("dense inverse mass matrix must be symmetric")
         else:
             t = t.reshape(-1)
@@ -150,7 +177,8 @@ class Engine:
                         "aehmc_metric_sqrt_per_chain")
         else:
             sm = torch.sqrt(torch.reciprocal(t))
-        c = _lib.CMetric(ndim=ndim, per_chain=1, D=D, imm=t.data_ptr(), sqrt_mass=sm.data_ptr())
+        c = _lib.CMetric(ndim=ndim, per_chain=1, D=D, imm=t.data_ptr(), sqrt_mass=sm.data_ptr(),
+                         n_chains=t.shape[0])
         self._keep["metric"] = (pc, t, sm)
         self._check(self.lib.aehmc_set_metric(self.ctx, ct.byref(c)), "aehmc_set_metric")
         if self.metric_ndim != ndim:
@@ -162,11 +190,26 @@ class Engine:
         if isinstance(eps, PerChain):
             t = _dev_f64(eps.value, self.device).reshape(-1)
             self._keep["eps"] = t
-            self._check(self.lib.aehmc_set_step_sizes(self.ctx, t.data_ptr()), "aehmc_set_step_sizes")
+            self._check(self.lib.aehmc_set_step_sizes(self.ctx, t.data_ptr(), t.numel()), "aehmc_set_step_sizes")
             return 0.0
-        self._keep.pop("eps", None)
-        self._check(self.lib.aehmc_set_step_sizes(self.ctx, None), "aehmc_set_step_sizes")
+        self._clear_step_sizes()
         return float(eps)
+
+    def _clear_step_sizes(self):
+        """Per-chain step sizes apply to ONE step/sample call: the ctx is shared per device and
+        must not carry them into an unrelated later call."""
+        self._keep.pop("eps", None)
+        self._check(self.lib.aehmc_set_step_sizes(self.ctx, None, 0), "aehmc_set_step_sizes")
+
+    def _step_call(self, fn, what, *args):
+        try:
+            self._check(fn(*args), what)
+        finally:  # kernel arguments were captured at launch: safe to drop the binding now
+            self._clear_step_sizes()
+
+    def synchronize(self):
+        """Wait for the stream and raise on device-side failures that are not data."""
+        self._check(self.lib.aehmc_synchronize(self.ctx, self.stream), "aehmc_synchronize")
 
     def ensure_workspace(self, C: int, max_exp: int):
         need = self.lib.aehmc_workspace_bytes(self.ctx, C, max_exp)
@@ -206,9 +249,8 @@ class Engine:
         C, D = q.shape
         self.ensure_workspace(C, 1)
         out, c = self._diag(C, D, False)
-        self._check(self.lib.aehmc_hmc_step(self.ctx, C, rng.data_ptr(), float(eps), int(L), float(thr),
-                                            q.data_ptr(), U.data_ptr(), g.data_ptr(), ct.byref(c),
-                                            self.stream), "aehmc_hmc_step")
+        self._step_call(self.lib.aehmc_hmc_step, "aehmc_hmc_step", self.ctx, C, rng.data_ptr(), float(eps),
+                        int(L), float(thr), q.data_ptr(), U.data_ptr(), g.data_ptr(), ct.byref(c), self.stream)
         return out
 
     def hmc_sample(self, rng, eps, L, thr, n, q, U, g, keep_samples=True):
@@ -219,10 +261,11 @@ class Engine:
         samples = torch.empty(n, C, D, dtype=torch.float64, device=dev) if keep_samples else None
         acc = torch.empty(n, C, dtype=torch.float64, device=dev)
         div = torch.empty(n, C, dtype=torch.int32, device=dev)
-        self._check(self.lib.aehmc_hmc_sample(
+        self._step_call(
+            self.lib.aehmc_hmc_sample, "aehmc_hmc_sample",
             self.ctx, C, rng.data_ptr(), float(eps), int(L), float(thr), int(n), q.data_ptr(),
             U.data_ptr(), g.data_ptr(), ct.byref(c), samples.data_ptr() if keep_samples else None,
-            acc.data_ptr(), div.data_ptr(), self.stream), "aehmc_hmc_sample")
+            acc.data_ptr(), div.data_ptr(), self.stream)
         out["samples"], out["acceptance_history"], out["divergence_history"] = samples, acc, div
         return out
 
@@ -230,9 +273,9 @@ class Engine:
         C, D = q.shape
         self.ensure_workspace(C, max_exp)
         out, c = self._diag(C, D, True)
-        self._check(self.lib.aehmc_nuts_step(self.ctx, C, rng.data_ptr(), float(eps), int(max_exp),
-                                             float(thr), q.data_ptr(), U.data_ptr(), g.data_ptr(),
-                                             ct.byref(c), self.stream), "aehmc_nuts_step")
+        self._step_call(self.lib.aehmc_nuts_step, "aehmc_nuts_step", self.ctx, C, rng.data_ptr(), float(eps),
+                        int(max_exp), float(thr), q.data_ptr(), U.data_ptr(), g.data_ptr(), ct.byref(c),
+                        self.stream)
         return out
 
     def nuts_sample(self, rng, eps, max_exp, thr, n, q, U, g, keep_samples=True):
@@ -244,10 +287,11 @@ class Engine:
         acc = torch.empty(n, C, dtype=torch.float64, device=dev)
         div = torch.empty(n, C, dtype=torch.int32, device=dev)
         total = torch.zeros(C, dtype=torch.int64, device=dev)
-        self._check(self.lib.aehmc_nuts_sample(
+        self._step_call(
+            self.lib.aehmc_nuts_sample, "aehmc_nuts_sample",
             self.ctx, C, rng.data_ptr(), float(eps), int(max_exp), float(thr), int(n), q.data_ptr(),
             U.data_ptr(), g.data_ptr(), ct.byref(c), samples.data_ptr() if keep_samples else None,
-            acc.data_ptr(), div.data_ptr(), total.data_ptr(), self.stream), "aehmc_nuts_sample")
+            acc.data_ptr(), div.data_ptr(), total.data_ptr(), self.stream)
         out["samples"], out["acceptance_history"], out["divergence_history"] = samples, acc, div
         out["n_leapfrog"] = total
         return out

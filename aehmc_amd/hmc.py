@@ -3,7 +3,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Tuple
 
-from ._common import Layout, new_state as _new_state, state_rows
+from ._common import Layout, diagnostics, histories, new_state as _new_state, state_rows
 from .engine import get_engine, rng_to_device
 from .integrators import IntegratorState
 from .random import RandomStream
@@ -34,14 +34,7 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
         eng.set_metric(inverse_mass_matrix, layout.D)
         out = eng.hmc_step(holder["rng"], eng.set_step_sizes(step_size), int(num_integration_steps),
                            float(divergence_threshold), q, U, g)
-        info = Diagnostics(
-            state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
-                                  potential_energy=layout.per_chain(U),
-                                  potential_energy_grad=layout.vec(g)),
-            acceptance_probability=layout.per_chain(out["acceptance_probability"]),
-            num_doublings=None, is_turning=None,
-            is_diverging=layout.per_chain(out["is_diverging"].bool()),
-            n_leapfrog=layout.per_chain(out["n_leapfrog"]))
+        info = diagnostics(layout, q, U, g, out, False)
         return info, {srng: holder["rng"]}
 
     def sample(state: IntegratorState, step_size, inverse_mass_matrix, num_integration_steps: int,
@@ -59,19 +52,9 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
         eng.set_metric(inverse_mass_matrix, layout.D)
         out = eng.hmc_sample(holder["rng"], eng.set_step_sizes(step_size), int(num_integration_steps),
                              float(divergence_threshold), int(num_samples), q, U, g, keep_samples)
-        info = Diagnostics(
-            state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
-                                  potential_energy=layout.per_chain(U),
-                                  potential_energy_grad=layout.vec(g)),
-            acceptance_probability=layout.per_chain(out["acceptance_probability"]),
-            num_doublings=None, is_turning=None,
-            is_diverging=layout.per_chain(out["is_diverging"].bool()),
-            n_leapfrog=layout.per_chain(out["n_leapfrog"]))
-        n = int(num_samples)
-        samples = out["samples"].reshape((n,) + layout.user_shape) if keep_samples else None
-        hist_shape = (n,) + layout.scalar_chain_shape
-        return (samples, info, out["acceptance_history"].reshape(hist_shape),
-                out["divergence_history"].bool().reshape(hist_shape))
+        info = diagnostics(layout, q, U, g, out, False)
+        samples, acc_hist, div_hist = histories(layout, out, int(num_samples), keep_samples)
+        return samples, info, acc_hist, div_hist
 
     step.sample = sample
     step.num_chains, step.batched = srng.num_chains, srng.batched

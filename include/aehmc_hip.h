@@ -74,6 +74,8 @@ typedef struct {
   const double *sqrt_mass; /* [1] | [D] | [D,D], or NULL: aehmc_set_metric computes it on the
                               device (dense: blocked Cholesky + triangular inverse on the fp64
                               MFMA GEMM) into ctx-owned memory */
+  int64_t n_chains;        /* per_chain: number of rows C of imm / sqrt_mass (the step calls
+                              refuse a different chain count); 0 when shared */
 } aehmc_metric;
 
 /* warm-up state of window_adaptation.run (window_adaptation.py:17-116), one row per chain:
@@ -116,7 +118,7 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   VGPRs for the whole tree) for diagonal/scalar metrics, coordinate-wise
  *                   targets, D <= 10176, and the regression target (four chains per workgroup
  *                   share each pass over the data rows).  2 = auto (used when D > 256,
- *                   C >= 16384 or 8 <= C <= 2048, where it beats the lock-step path, and always
+ *                   C >= 16384 or C <= 2048, where it beats the lock-step path, and always
  *                   for the regression target), 1 = always, 0 = never
  *  "resident_min_team" 0  1: always give a chain the smallest team of lanes that holds it
  *                   (64/T chains per wavefront) instead of widening teams while the GPU would
@@ -168,9 +170,10 @@ int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
                     int64_t max_num_expansions, double divergence_threshold, double *q,
                     double *U, double *g, const aehmc_diagnostics *out, void *stream);
 
-/* per-chain step sizes [C] overriding the scalar step_size argument of the step calls
- * (NULL restores the scalar) -- window adaptation adapts one step size per chain */
-int aehmc_set_step_sizes(aehmc_ctx *ctx, const double *step_sizes);
+/* per-chain step sizes [n] overriding the scalar step_size argument of the step calls
+ * (NULL restores the scalar) -- window adaptation adapts one step size per chain.  A step
+ * call with a chain count other than n fails. */
+int aehmc_set_step_sizes(aehmc_ctx *ctx, const double *step_sizes, int64_t n);
 
 /* window_adaptation.window_adaptation(...).init / .update (window_adaptation.py:119-227,
  * step_size.py:9-100, mass_matrix.py:12-120, algorithms.py:17-204), diagonal mass matrix,
@@ -220,6 +223,12 @@ int aehmc_gemm_nt(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double 
 int aehmc_profile_enable(aehmc_ctx *ctx, int enable);
 int aehmc_profile_read(aehmc_ctx *ctx, double *kernel_ms_total, int64_t *kernel_launches,
                        double *gemm_flops_total);
+
+/* wait for `stream` and report device-side failures that are not data (a stream-K GEMM
+ * hand-off that timed out because the persistent grid was not co-resident): the step calls
+ * are asynchronous, so such a failure in the last launches of a call surfaces here, at the
+ * next GEMM launch or in aehmc_profile_read. */
+int aehmc_synchronize(aehmc_ctx *ctx, void *stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,32 @@ def test_schedule_tables(num_steps, expected):
     assert len(s) == num_steps and s == expected
 
 
+@pytest.mark.parametrize("num_steps, expected", [
+    (19, [(0, False)] * 19),
+    (100, [(0, False)] * 15 + [(1, False)] * 74 + [(1, True)] + [(0, False)] * 10),
+    (200, [(0, False)] * 75 + [(1, False)] * 24 + [(1, True)] + [(1, False)] * 49 + [(1, True)]
+     + [(0, False)] * 50),
+])
+def test_product_schedule_tables(num_steps, expected):
+    """The PRODUCT's build_schedule (aehmc_amd/window_adaptation.py, host logic, importable without
+    a GPU) against the reference's own tables, tests/test_adaptation.py:9-22."""
+    from aehmc_amd.window_adaptation import build_schedule
+    s = build_schedule(num_steps)
+    assert len(s) == num_steps and s == expected
+
+
+def test_product_schedule_equals_restatement():
+    """... and against the literal restatement of window_adaptation.py:230-327 for every length
+    (incl. non-default buffer sizes)."""
+    from aehmc_amd.window_adaptation import build_schedule
+    for n in range(0, 3000):
+        assert build_schedule(n) == na.build_schedule(n), n
+    for n in (150, 500, 1234):
+        for kw in (dict(initial_buffer_size=20, final_buffer_size=30, first_window_size=10),
+                   dict(initial_buffer_size=100, final_buffer_size=10, first_window_size=40)):
+            assert build_schedule(n, **kw) == na.build_schedule(n, **kw), (n, kw)
+
+
 def test_schedule_1000_windows():
     s = na.build_schedule(1000)
     ends = [i for i, (_, e) in enumerate(s) if e]
