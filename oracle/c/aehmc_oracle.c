@@ -363,10 +363,21 @@ void ao_find_storage_indices(int64_t step, int64_t *mn, int64_t *mx) { find_stor
 
 typedef struct { double *ckp, *cks; int64_t mn, mx; } ao_term; /* termination.py:12-16 */
 
+/* EXPERIMENT switches (tests/test_nuts_quirks.py only; both 0 = the reference's semantics,
+ * which is what every parity test pins).  They exist to attribute the stationary bias of the
+ * reference's NUTS to one of its two literal quirks:
+ *   alt_quirk1 = 1: a sub-trajectory of expansion j takes 2**j leapfrogs instead of the
+ *                   reference's 2**j + 1 (trajectory.py:307 scans n_steps = max_num_steps AFTER the
+ *                   first step of trajectory.py:276-284);
+ *   alt_quirk2 = 1: step 0 of a sub-trajectory uses _find_storage_indices(0) instead of the
+ *                   indices inherited from the previous sub-trajectory (termination.py:109-113). */
+static int alt_quirk1 = 0, alt_quirk2 = 0;
+void ao_set_experiment(int32_t q1, int32_t q2) { alt_quirk1 = q1; alt_quirk2 = q2; }
+
 /* termination.py:85-131 */
 static void term_update(ao_term *T, const double *psum, const double *p, int64_t step, int64_t D) {
   int64_t mn, mx;
-  if (step == 0) { mn = T->mn; mx = T->mx; }     /* inherited, possibly stale */
+  if (step == 0 && !alt_quirk2) { mn = T->mn; mx = T->mx; }     /* inherited, possibly stale */
   else find_storage_indices(step, &mn, &mx);
   if (step % 2 == 0) {
     memcpy(T->ckp + mx * D, p, D * sizeof(double));
@@ -461,7 +472,7 @@ static void nuts_step_one(const ao_target *t, const ao_metric *m, ao_pcg64 *rng,
     double d = go_right ? 1.0 : -1.0;
     ao_state *s = go_right ? &right : &left;             /* integrate in place on that end */
     double step_size = d * eps;
-    int64_t max_num_steps = (int64_t)1 << j;
+    int64_t max_num_steps = ((int64_t)1 << j) - (alt_quirk1 ? 1 : 0);
 
     /* ---- dynamic_integration.integrate: first step, trajectory.py:276-305 ---- */
     leapfrog(t, m, s, step_size, v, scratch); nleap++;

@@ -143,6 +143,12 @@ def nuts_step(target, metric, rng, eps, q, U, g, max_exp=10, thr=1000.0, nthread
                 is_turning=turn.astype(bool), is_diverging=div.astype(bool), n_leapfrog=nl)
 
 
+def set_experiment(alt_quirk1=False, alt_quirk2=False):
+    """Experiment switches of the C restatement (see aehmc_oracle.c); (False, False) is the
+    reference's semantics.  Used only by tests/test_nuts_quirks.py."""
+    lib().ao_set_experiment(ct.c_int32(int(alt_quirk1)), ct.c_int32(int(alt_quirk2)))
+
+
 def leapfrog(target, metric, eps, nsteps, q, p, U, g):
     lib().ao_leapfrog(ct.byref(target.c), ct.byref(metric.c), ct.c_int64(q.shape[0]),
                       ct.c_double(eps), ct.c_int64(nsteps), _p(q), _p(p), _p(U), _p(g))

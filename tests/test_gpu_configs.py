@@ -1,0 +1,160 @@
+"""BASELINE configs c3 / c4 AS BENCHMARKED, under parity.
+
+c3: D = 1e4 correlated MVN, dense precision + dense inverse mass matrix, NUTS with the default
+max_tree_depth = 10 and the bench's step size -- trees end by their own U-turns at depth 5-7,
+chains leave the lock-step launches at different times (shrinking live-row lists, the
+few-rows GEMM kernel), none of which the depth-3 test of test_gpu_parity.py reaches.
+c4: one GPU's shard of the 32768-chain configuration split over two GPUs (16384 x 1e4).
+
+Tolerance as everywhere: RTOL 1e-9 on real outputs (north star: 1e-6), every discrete output
+and the RNG consumption identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import c_oracle as co  # noqa: E402
+
+RTOL = 1e-9
+D = 10_000
+EPS = 0.5 * D ** -0.25  # bench.py's step size for c3
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+
+
+@pytest.fixture(scope="module")
+def c3_model():
+    from bench import build_c3
+    Sigma, P = build_c3(D, torch.device("cuda"))
+    return Sigma, P
+
+
+@pytest.fixture(scope="module")
+def c3_oracle(c3_model):
+    Sigma, P = c3_model
+    otgt = co.Target(co.T_DENSE_MVN, D, mu=np.zeros(D), prec=P.cpu().numpy())
+    return otgt, co.Metric(Sigma.cpu().numpy(), D)
+
+
+@pytest.mark.timeout(1200)
+def test_config3_depth10_both_dense_modes_match_oracle(c3_model, c3_oracle):
+    """c3 with max_num_expansions = 10 (the benchmarked setting), 256 chains, two consecutive
+    transitions in both dense-metric modes (`dense_linear` 1: v and w carried by recurrence, 2 GEMMs
+    per leapfrog -- the default and what the bench times; 0: the literal 3 products of
+    metrics.py:71).  Four chains -- first, last, the deepest and the shallowest tree -- against
+    the C oracle: n_leapfrog, num_doublings, both flags and the RNG state after the transition
+    identical, real outputs within 1e-9.  The two modes must agree with each other on every chain
+    in every discrete output (a U-turn test is a `<= 0` on values that differ by rounding)."""
+    from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.engine import get_engine
+    Sigma, P = c3_model
+    otgt, metric = c3_oracle
+    C = 256
+    mu = torch.zeros(D, dtype=torch.float64, device="cuda")
+    tgt = targets.DenseMVN(mu, P)
+    seeds = [1000 + c for c in range(C)]
+    q0 = np.random.default_rng(1234).standard_normal((C, D))
+    eng = get_engine()
+    runs = {}
+    try:
+        for mode in (1, 0):
+            eng.set_option("dense_linear", mode)
+            kernel = nuts.new_kernel(RandomStream(seeds=seeds), tgt, max_num_expansions=10)
+            state = nuts.new_state(dev(q0), tgt)
+            infos = []
+            for _ in range(2):
+                info, upd = kernel(state, EPS, Sigma)
+                state = info.state._replace(momentum=None)
+                infos.append(info)
+            (rng_dev,) = upd.values()
+            runs[mode] = (infos, rng_dev.cpu().numpy().view(np.uint64).copy())
+    finally:
+        eng.set_option("dense_linear", 1)
+    for t in range(2):
+        a, b = runs[1][0][t], runs[0][0][t]
+        for f in ("n_leapfrog", "num_doublings", "is_turning", "is_diverging"):
+            assert torch.equal(getattr(a, f), getattr(b, f)), (t, f)
+        np.testing.assert_allclose(a.state.position.cpu().numpy(), b.state.position.cpu().numpy(),
+                                   rtol=RTOL, atol=1e-10)
+    assert np.array_equal(runs[1][1], runs[0][1])  # same RNG consumption in both modes
+    nl0 = runs[1][0][0].n_leapfrog.cpu().numpy()
+    nd0 = runs[1][0][0].num_doublings.cpu().numpy()
+    assert nd0.max() >= 5 and nl0.max() >= 33, (nd0.max(), nl0.max())  # trees do run deep
+    assert len(np.unique(nd0)) >= 2                                    # ... and end at different depths
+    sel = sorted({0, C - 1, int(nl0.argmax()), int(nl0.argmin())})
+    while len(sel) < 4:
+        sel = sorted(set(sel) | {len(sel) * 37 % C})
+    rng = co.site_states([seeds[i] for i in sel], 4)
+    q, U, g = co.new_state(otgt, q0[sel].copy())
+    for t in range(2):
+        res = co.nuts_step(otgt, metric, rng, EPS, q, U, g, max_exp=10, nthreads=len(sel))
+        for mode in (1, 0):
+            info = runs[mode][0][t]
+            assert info.n_leapfrog[sel].cpu().tolist() == res["n_leapfrog"].tolist(), (t, mode)
+            assert info.num_doublings[sel].cpu().tolist() == res["num_doublings"].tolist(), (t, mode)
+            assert info.is_turning[sel].cpu().tolist() == res["is_turning"].tolist(), (t, mode)
+            assert info.is_diverging[sel].cpu().tolist() == res["is_diverging"].tolist(), (t, mode)
+            np.testing.assert_allclose(info.state.position[sel].cpu().numpy(), q, rtol=RTOL, atol=1e-10)
+            np.testing.assert_allclose(info.state.potential_energy[sel].cpu().numpy(), U, rtol=RTOL)
+            np.testing.assert_allclose(info.state.potential_energy_grad[sel].cpu().numpy(), g,
+                                       rtol=RTOL, atol=1e-9)
+            np.testing.assert_allclose(info.state.momentum[sel].cpu().numpy(), res["momentum"],
+                                       rtol=RTOL, atol=1e-10)
+            np.testing.assert_allclose(info.acceptance_probability[sel].cpu().numpy(),
+                                       res["acceptance_probability"], rtol=RTOL)
+    for mode in (1, 0):  # RNG consumption at all four call sites
+        assert np.array_equal(runs[mode][1][sel], rng), mode
+
+
+@pytest.mark.timeout(900)
+def test_config4_two_gpu_shard(c3_model):
+    """c4's per-GPU shard when 32768 chains are split over two GPUs: 16384 chains x D = 1e4, dense
+    precision + dense mass, default tree depth (73 GB of work vectors).  One transition.
+    Size-independent properties: (i) the first 96 and the last 32 chains of the shard equal, BIT
+    FOR BIT, the same chains (same global seeds) run in a small call of their own -- results do
+    not depend on which chains share a launch, which is what makes a sharded run equal an
+    unsharded one; (ii) returned (U, grad U) equal a fresh evaluation at the returned position;
+    (iii) leapfrog counts are consistent with the number of doublings; (iv) energy is conserved
+    (high acceptance, no divergence)."""
+    from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.parallel import chain_seeds, shard_chains
+    Sigma, P = c3_model
+    total, world, rank = 32768, 2, 1
+    lo, hi = shard_chains(total, rank, world)
+    C = hi - lo
+    assert C == 16384
+    seeds = chain_seeds(1000, total, rank, world)
+    gen = torch.Generator(device="cuda").manual_seed(4321)
+    q0 = torch.randn(C, D, dtype=torch.float64, device="cuda", generator=gen)
+    mu = torch.zeros(D, dtype=torch.float64, device="cuda")
+    tgt = targets.DenseMVN(mu, P)
+    kernel = nuts.new_kernel(RandomStream(seeds=seeds), tgt, max_num_expansions=10)
+    state = nuts.new_state(q0, tgt)
+    info, _ = kernel(state, EPS, Sigma)
+    nd, nl = info.num_doublings.cpu().numpy(), info.n_leapfrog.cpu().numpy()
+    full = np.cumsum([2 ** j + 1 for j in range(10)])
+    assert ((nd >= 1) & (nd <= 10)).all()
+    assert (nl <= full[nd - 1]).all() and (nl > np.concatenate([[0], full])[nd - 1]).all()
+    assert info.acceptance_probability.mean().item() > 0.9 and not info.is_diverging.any().item()
+    assert torch.isfinite(info.state.position).all()
+    fresh = nuts.new_state(info.state.position, tgt)
+    np.testing.assert_allclose(fresh.potential_energy.cpu().numpy(), info.state.potential_energy.cpu().numpy(),
+                               rtol=1e-11)
+    np.testing.assert_allclose(fresh.potential_energy_grad[:64].cpu().numpy(),
+                               info.state.potential_energy_grad[:64].cpu().numpy(), rtol=1e-9, atol=1e-9)
+    pos, acc = info.state.position, info.acceptance_probability
+    del fresh, state
+    for sl in (slice(0, 96), slice(C - 32, C)):
+        k2 = nuts.new_kernel(RandomStream(seeds=seeds[sl]), tgt, max_num_expansions=10)
+        i2, _ = k2(nuts.new_state(q0[sl].clone(), tgt), EPS, Sigma)
+        assert torch.equal(i2.state.position, pos[sl])
+        assert torch.equal(i2.acceptance_probability, acc[sl])
+        assert torch.equal(i2.n_leapfrog, info.n_leapfrog[sl])
