@@ -468,11 +468,12 @@ static int check_per_chain(aehmc_ctx *ctx, int64_t C) {
          std::to_string(C) + " chains");
   return 0;
 }
-static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a) {
+static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a, bool uses_params = true) {
   if (!ctx->has_tgt || !ctx->has_met) FAIL("set_target and set_metric must be called first");
   if (ctx->tgt.D != ctx->met.D) FAIL("target and metric dimensions differ");
   if (C <= 0) FAIL("C must be positive");
-  if (int rc = check_per_chain(ctx, C)) return rc;
+  if (uses_params)  // (new_state evaluates the target only: stale per-chain parameters are not read)
+    if (int rc = check_per_chain(ctx, C)) return rc;
   memset(&a, 0, sizeof(a));
   int64_t need = ws_layout(ctx, C, E, (char *)ctx->ws, &a);
   if (!ctx->ws || need > ctx->ws_bytes)
@@ -700,7 +701,7 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
     LAUNCH(k_new_state_elem, C, st, a);
     return 0;
   }
-  if (int rc = fill_args(ctx, C, 1, a)) return rc;
+  if (int rc = fill_args(ctx, C, 1, a, false)) return rc;
   if (a.tkind == AEHMC_T_DENSE_MVN) {
     LAUNCH(k_residual, C, st, a, q, a.rbuf);
     if (gemm(ctx, C, a.D, a.D, a.rbuf, a.D, ctx->tgt.prec, a.D, g, a.D, st)) return -1;

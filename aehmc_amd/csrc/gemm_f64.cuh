@@ -496,10 +496,13 @@ __global__ __launch_bounds__(256, (PIPE ? 1 : 2)) void gemm_nt_f64_streamk_kerne
   // L2 locality (measured: -11 % at 4.94 rounds) and only pay when part of a round would be wasted.
   const long long rounds = (T + G - 1) / G;
   if (T < G || W < nk || (rounds * G - T) * 100 < 4 * (long long)G) {
-    for (long long t = blockIdx.x; t < T; t += G) {
-      // same tile -> XCD assignment as gemm_tile_of_block within each round
-      const long long base = (t / G) * G, left = (T - base < G) ? T - base : G;
-      const long long chunk = (left + 7) / 8, slot = (t - base) / 8, x = (t - base) % 8;
+    for (long long base = 0; base < T; base += G) {
+      // same tile -> XCD assignment as gemm_tile_of_block within each round: XCD x (= workgroup
+      // index mod 8) takes tiles [x chunk, (x+1) chunk) of the round.  Every workgroup index below
+      // 8 chunk takes part -- NOT only those below `left`: with left % 8 != 0 the last slot of
+      // the higher XCDs would never be visited and their tiles would keep stale output.
+      const long long left = (T - base < G) ? T - base : G;
+      const long long chunk = (left + 7) / 8, slot = blockIdx.x / 8, x = blockIdx.x % 8;
       if (slot < chunk && x * chunk + slot < left) pass((int)(base + x * chunk + slot), 0, nk, 0);
     }
     return;

@@ -114,6 +114,31 @@ def test_gemm_tail_kernel_bitwise_equals_tiled(eng, M, N, K):
                                atol=1e-12 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("M", [129, 200, 256, 257, 300, 384, 385, 500])
+@pytest.mark.parametrize("N,K", [(10000, 512), (1000, 64), (1300, 10000)])
+def test_gemm_few_row_tiles_every_tile_written(eng, M, N, K):
+    """129 .. ~768 rows take the pipelined 128 x 128 kernel on a persistent grid; with fewer tiles than
+    workgroups every workgroup owns at most one tile and the tile count (2 or 3 row tiles x 79 / 8 / 11
+    column tiles) is NOT a multiple of the 8 XCDs -- a round-1 bug left the last slot of the higher
+    XCDs unvisited there (stale output for a few 128 x 128 blocks, c3's live-row counts 129 .. 384).
+    The output buffer is poisoned first; result vs torch and bitwise vs the one-tile-per-workgroup kernel."""
+    r = np.random.default_rng(M + N + K)
+    A, B = dev(r.normal(size=(M, K))), dev(r.normal(size=(N, K)))
+    ref = (A @ B.T)
+    outs = {}
+    for mode in (2, 1, 0):
+        eng.set_option("streamk", mode)
+        poison = torch.full((M, N), float("nan"), dtype=torch.float64, device="cuda")
+        eng.lib.aehmc_gemm_nt(eng.ctx, M, N, K, A.data_ptr(), K, B.data_ptr(), K, poison.data_ptr(), N, eng.stream)
+        torch.cuda.synchronize()
+        outs[mode] = poison
+    eng.set_option("streamk", 2)
+    for mode, out in outs.items():
+        assert torch.isfinite(out).all(), (mode, (~torch.isfinite(out)).sum().item())
+        assert torch.allclose(out, ref, rtol=1e-12, atol=1e-12 * np.sqrt(K)), mode
+    assert torch.equal(outs[2], outs[0]) and torch.equal(outs[1], outs[0])
+
+
 # ------------------------------------------------------------------ G1 on the GPU
 def test_g1_readme_bit_exact_on_gpu():
     """README.md:22-54 through the drop-in API: position after one NUTS transition."""
