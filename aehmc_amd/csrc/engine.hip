@@ -13,6 +13,7 @@
 #include "gemm_f64.cuh"
 #include "hmc_fused.cuh"
 #include "nuts_resident.cuh"
+#include "nuts_wide.cuh"
 
 using namespace aehmc;
 
@@ -669,7 +670,7 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
 // momentum draw (metrics.py:65-68) + per-chain init, for both samplers
 static int launch_begin(aehmc_ctx *ctx, const EngineArgs &a, bool nuts, hipStream_t st) {
   const bool md = a.met_ndim == 2;
-  const int64_t C = a.C, D = a.D;
+  const int64_t C = a.C;
   if (!md) {
     if (nuts) LAUNCH(k_nuts_begin_diag, C, st, a);
     else LAUNCH(k_hmc_begin_diag, C, st, a);
@@ -738,13 +739,14 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   if (want_resident && nuts_resident_supported(a.tkind, a.met_ndim, a.D)) {
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (a.D > 512) {  // workgroup-per-chain teams: momentum drawn at one wavefront per chain first
+    if (a.D > 512) {  // one workgroup per chain (nuts_wide.cuh): momentum drawn at one wavefront per chain first
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, a.rng, a.nsites, (long long)C,
                          (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf);
       HIPCHK(hipGetLastError());
-      a.z_ready = 1;
+      HIPCHK(launch_nuts_wide(a, st));
+    } else {
+      HIPCHK(launch_nuts_resident(a, st, ctx->opt_resident_min_team));
     }
-    HIPCHK(launch_nuts_resident(a, st, ctx->opt_resident_min_team));
     return prof_end(ctx, st, p);
   }
   if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
