@@ -6,7 +6,8 @@ import ctypes as ct
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaehmc_hip.so")
+# AEHMC_AMD_LIB: developer override (e.g. the instrumented `make timing` build); never a CPU path
+LIB_PATH = os.environ.get("AEHMC_AMD_LIB") or os.path.join(_HERE, "libaehmc_hip.so")
 _lib = None
 
 

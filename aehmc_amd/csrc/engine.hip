@@ -417,7 +417,9 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
 static int64_t ws_layout(const aehmc_ctx *ctx, int64_t C, int64_t E, char *base, EngineArgs *a) {
   const bool md = ctx->has_met && ctx->met.ndim == 2;
   const int64_t D = ctx->has_tgt ? ctx->tgt.D : (ctx->has_met ? ctx->met.D : 0);
-  const size_t vec = (((size_t)C * D * sizeof(double)) + 255) & ~(size_t)255;
+  // (rows padded to nuts_wide_ld(D) where the workgroup-per-chain NUTS kernel may run: D > 512)
+  const int64_t ldmax = D > 512 ? nuts_wide_ld(D) : D;
+  const size_t vec = (((size_t)C * ldmax * sizeof(double)) + 255) & ~(size_t)255;
   size_t off = 0;
   auto take = [&](size_t n) -> double * {
     double *p = base ? reinterpret_cast<double *>(base + off) : nullptr;
@@ -481,6 +483,7 @@ static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a, bool u
     FAIL("workspace too small: need " + std::to_string(need) + " bytes");
   a.C = C;
   a.D = ctx->tgt.D;
+  a.ldw = a.D;
   a.max_exp = (int)E;
   a.met_ndim = ctx->met.ndim;
   a.imm = ctx->met.imm;
@@ -740,8 +743,9 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
     if (a.D > 512) {  // one workgroup per chain (nuts_wide.cuh): momentum drawn at one wavefront per chain first
+      a.ldw = nuts_wide_ld(a.D);
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, a.rng, a.nsites, (long long)C,
-                         (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf);
+                         (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf, a.ldw);
       HIPCHK(hipGetLastError());
       HIPCHK(launch_nuts_wide(a, st));
     } else {
@@ -886,7 +890,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     if (int rc = prof_begin(ctx, st, p)) return rc;
     for (int64_t t = 0; t < T; t++) {
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, rng, 2, (long long)C, (long long)D,
-                         f.sqrt_mass, f.imm_cs, f.met_ndim, a.zbuf);
+                         f.sqrt_mass, f.imm_cs, f.met_ndim, a.zbuf, (long long)D);
       HIPCHK(hipGetLastError());
       f.samples = samples ? samples + (size_t)t * C * D : nullptr;
       f.acc_hist = acc_hist ? acc_hist + (size_t)t * C : nullptr;

@@ -21,9 +21,14 @@
 //  * Per-element parameters (imm; mu, sigma, log sigma of a diagonal target) are L2-resident
 //    vectors shared by all chains: kept in VGPRs when they fit (R <= 8), otherwise streamed in
 //    batches with the next batch's loads issued before the current batch's arithmetic.
-// HBM then sees per leapfrog: the checkpoint pair of every other step (8 D bytes on
-// average), ~1/2 checkpoint pair read (8 D), the proposal copy on accept and the
-// trajectory ends at expansion boundaries -- not the 88 D bytes of a streaming step.
+//  * Bytes: the initial state is never copied (the caller's q / dU/dq and the drawn momentum
+//    alias it as proposal and as trajectory ends until something else takes their place); a
+//    trajectory end is stored only when the next expansion turns to the other side; checkpoint
+//    pairs that only the following step reads (every other one) are not stored; with
+//    dU/dq == q (standard / isotropic normal) no gradient array is touched.
+// HBM then sees per leapfrog: a checkpoint pair every fourth step (4 D bytes on average),
+// ~1/2 checkpoint pair read (8 D), the proposal copy on accept and psum / the parked end at
+// expansion boundaries -- ~22 D bytes instead of the 88 D of a streaming step.
 //
 // Arithmetic per element is that of engine.cuh's lock-step path; sums are accumulated per
 // thread in ascending element order, then wave (DPP) and cross-wave in a fixed order, so
@@ -33,55 +38,70 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "engine.cuh"
 
 namespace aehmc {
+
+// Developer instrumentation (make timing): shader-clock cycles per phase of the per-leapfrog
+// loop, accumulated by every thread, written by thread 0 to a.linreg_part[c * 8 + phase]
+// (unused workspace on this path).  Compiled out of the product library.
+#ifdef AEHMC_WIDE_TIMING
+#define AEHMC_TICK(k)                                         \
+  do {                                                        \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime(); \
+    tacc[k] += now_ - tlast;                                  \
+    tlast = now_;                                             \
+  } while (0)
+#else
+#define AEHMC_TICK(k) do { } while (0)
+#endif
 
 template <int T, int R, bool QGL, int TK>
 __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
   constexpr int NW = T / 64;
   constexpr bool DG = TK == AEHMC_T_DIAG_GAUSSIAN;  // otherwise dU/dq == q: no separate copy
-  constexpr bool PAR_REG = R <= 8;                  // per-element parameters live in VGPRs
+  constexpr bool ISO = TK == AEHMC_T_ISO_GAUSSIAN;
+  constexpr bool PAR_REG = R <= 8;          // per-element parameters live in VGPRs
+  constexpr bool IM_LDS = !PAR_REG && !DG;  // imm in the LDS half that dU/dq does not need
+  constexpr bool STREAM = !PAR_REG && DG;   // parameters streamed from L2 every pass
   constexpr int BR = (R % 4 == 0) ? 4 : R;  // elements per streamed batch
   constexpr int NB = R / BR;
   static_assert(R % BR == 0, "R must be a multiple of the batch size");
+  static_assert(QGL || PAR_REG, "more than 8 elements per thread: q lives in LDS");
   __shared__ double red[2][4 * NW];
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
-  double *const sq = dyn_lds, *const sg = dyn_lds + (QGL && DG ? a.D : 0);
+  const unsigned D = (unsigned)a.D;
+  // LDS arrays have D + 1 entries: entry D is the shared dummy of the slots past D (always 0 in q
+  // and dU/dq, 1 in imm)
+  double *const sq = dyn_lds, *const sg = dyn_lds + (QGL && DG ? D + 1 : 0);
+  double *const sim = dyn_lds + (IM_LDS ? D + 1 : 0);
   int flip = 0;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const long long c = blockIdx.x;
-  const size_t row = (size_t)c * a.D;
-  const unsigned last = (unsigned)a.D - 1;
   const bool im_scalar = a.met_ndim == 0;
   const double *const imrow = a.imm + (size_t)c * a.imm_cs;
-  // Thread t owns slots r = 0 .. R-1 = elements t + T r.  Slots r < nfull are valid in every thread
-  // (no predicate in their code), slot nfull is valid for t < D - T nfull, later slots are never
-  // touched -- nfull is wave-uniform, so this costs one scalar branch per slot.
-  const int nfull = (int)(a.D / T), nslots = (int)((a.D + T - 1) / T);
+  // Thread t owns slots r = 0 .. nslots-1 = elements t + T r.  The engine's work arrays have
+  // rows padded to a.ldw (a multiple of T) here, and a slot past D carries q = p = 0 for the whole
+  // transition (0 is a fixed point of the leapfrog for every target below once its parameters
+  // are neutral): its terms in all sums are exactly 0 and its stores land in the padding, so
+  // the per-leapfrog code has no predicates.  Only the caller's unpadded arrays (q, dU/dq, the
+  // momentum output) and the parameter vectors are accessed clamped / masked.
+  const int nslots = (int)((D + T - 1) / T);
+  const size_t rowW = (size_t)c * a.ldw, rowU = (size_t)c * D;
   // `tt` is t behind an opaque barrier that is renewed in every loop iteration: element
   // addresses derived from it cannot be hoisted out of the loops (the compiler would otherwise
   // precompute a 64-bit address per element and array -- hundreds of VGPRs -- and spill them)
   int tt = t;
 #define AEHMC_FRESH_TT() asm volatile("" : "+v"(tt))
-// loads use the clamped index (slots past D re-read element D-1: in bounds, masked out of every
-// sum, never stored)
-#define EI(r) (((unsigned)(tt + T * (r)) < last) ? (unsigned)(tt + T * (r)) : last)
-#define VALID(r) ((unsigned)(tt + T * (r)) <= last)
-#define AT(ptr, r) ((ptr) + row)[EI(r)]
-// body for slot r: unpredicated when the slot is full, predicated by `on` for the ragged slot
-#define AEHMC_SLOT(r, ...)                   \
-  do {                                       \
-    if ((r) < nfull) {                       \
-      constexpr bool on = true;              \
-      (void)on;                              \
-      __VA_ARGS__                            \
-    } else if ((r) < nslots) {               \
-      const bool on = VALID(r);              \
-      __VA_ARGS__                            \
-    }                                        \
-  } while (0)
+#define EW(r) ((unsigned)(tt + T * (r)))                      /* element index, work arrays */
+#define EC(r) (EW(r) < D ? EW(r) : D - 1)                     /* clamped: caller arrays, parameters */
+#define EL(r) (EW(r) < D ? EW(r) : D)                         /* LDS index (dummy entry D) */
+#define ON(r) (EW(r) < D)
+#define WA(ptr, r) ((ptr) + rowW)[EW(r)]
+#define UA(ptr, r) ((ptr) + rowU)[EC(r)]
 
   // team sum of four values; every thread returns the same bits (SGPRs)
   auto sum4 = [&](double &x0, double &x1, double &x2, double &x3) {
@@ -116,31 +136,48 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     x3 = uni(s3);
   };
 
-  // per-element parameters of one element
+  // per-element parameters; a slot past D gets neutral ones (imm 1, mu 0, sigma 1, log sigma 0)
   struct Par {
     double im, mu, sd, ls;
   };
   auto par_load = [&](int r) {
     Par x;
-    const unsigned i = EI(r);
-    x.im = imrow[im_scalar ? 0u : i];
-    x.mu = DG ? a.mu[i] : 0.0;
-    x.sd = DG ? a.sigma[i] : 1.0;
-    x.ls = DG ? a.log_sigma[i] : 0.0;
+    const unsigned i = EC(r);
+    const bool on = ON(r);
+    const double im = imrow[im_scalar ? 0u : i];
+    x.im = on ? im : 1.0;
+    if (DG) {
+      const double mu = a.mu[i], sd = a.sigma[i], ls = a.log_sigma[i];
+      x.mu = on ? mu : 0.0;
+      x.sd = on ? sd : 1.0;
+      x.ls = on ? ls : 0.0;
+    } else {
+      x.mu = 0.0;
+      x.sd = 1.0;
+      x.ls = 0.0;
+    }
     return x;
   };
 
   double q[QGL ? 1 : R], g[(QGL || !DG) ? 1 : R], p[R], pb[R];
   Par preg[PAR_REG ? R : 1];
-// (QGL: a thread only ever touches the LDS slots of its own valid elements -- no barriers)
-#define QGET(r) (QGL ? sq[EI(r)] : q[QGL ? 0 : (r)])
-#define QSET(r, v) do { if (QGL) { if (on) sq[EI(r)] = (v); } else q[QGL ? 0 : (r)] = (v); } while (0)
-#define GGET(r) (!DG ? QGET(r) : (QGL ? sg[EI(r)] : g[(QGL || !DG) ? 0 : (r)]))
-#define GSET(r, v) do { if (DG) { if (QGL) { if (on) sg[EI(r)] = (v); } else g[(QGL || !DG) ? 0 : (r)] = (v); } } while (0)
-#define IMOF(r) (PAR_REG ? preg[PAR_REG ? (r) : 0].im : imrow[im_scalar ? 0u : EI(r)])
+#define QGET(r) (QGL ? sq[EL(r)] : q[QGL ? 0 : (r)])
+#define QSET(r, v) do { if (QGL) sq[EL(r)] = (v); else q[QGL ? 0 : (r)] = (v); } while (0)
+#define GGET(r) (!DG ? QGET(r) : (QGL ? sg[EL(r)] : g[(QGL || !DG) ? 0 : (r)]))
+#define GSET(r, v) do { if (DG) { if (QGL) sg[EL(r)] = (v); else g[(QGL || !DG) ? 0 : (r)] = (v); } } while (0)
+// imm of slot r outside the streamed pass (registers / LDS / L2)
+#define IMOF(r) (PAR_REG ? preg[PAR_REG ? (r) : 0].im : IM_LDS ? sim[EL(r)] : (ON(r) ? imrow[im_scalar ? 0u : EC(r)] : 1.0))
 
-  // ---- load the chain: q, dU/dq, momentum (drawn by k_draw_momentum into zbuf), parameters;
-  //      nuts.py:113-125 --------------------------------------------------------------------
+  // Where the states that are NOT on chip live.  The initial state (q0 = a.q, p0 = a.zbuf,
+  // dU/dq0 = a.g; the caller's arrays stay intact until the transition's outputs are written) is
+  // never copied: "buffer 2" of the proposal slots and an `init` flag per trajectory end alias it.
+  // The end of the side that is being integrated lives in registers / LDS and is stored only when
+  // the next expansion turns to the other side.  With dU/dq == q (!DG) no dU/dq array is touched.
+  int prop_buf = 2;                 // proposal: slot 0 / 1, or 2 = the initial state
+  bool end_init0 = true, end_init1 = true, psum_init = true;
+
+  // ---- load the chain: q, dU/dq, momentum (drawn by k_draw_momentum into zbuf, rows padded
+  //      with zeros), parameters; nuts.py:113-125 ----------------------------------------------
   double kd = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
 #pragma unroll
   for (int r = 0; r < R; r++) {
@@ -148,45 +185,44 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     if (!QGL) q[QGL ? 0 : r] = 0.0;
     if (!QGL && DG) g[(QGL || !DG) ? 0 : r] = 0.0;
     if (PAR_REG) preg[PAR_REG ? r : 0] = Par{1.0, 0.0, 1.0, 0.0};
-    AEHMC_SLOT(r, {
-      const double qv = AT(a.q, r), gv = DG ? AT(a.g, r) : qv, pv = AT(a.zbuf, r);
+    if (r < nslots) {
+      const bool on = ON(r);
+      const double qv = on ? UA(a.q, r) : 0.0, gv = DG ? (on ? UA(a.g, r) : 0.0) : qv, pv = WA(a.zbuf, r);
       if (PAR_REG) preg[PAR_REG ? r : 0] = par_load(r);
-      const double im = IMOF(r);
+      const double im = on ? imrow[im_scalar ? 0u : EC(r)] : 1.0;
+      if (IM_LDS) sim[EL(r)] = im;
       p[r] = pv;
       QSET(r, qv);
       GSET(r, gv);
-      if (on) {
-        kd += (im * pv) * pv;
-        AT(a.end_q[0], r) = qv;
-        AT(a.end_p[0], r) = pv;
-        AT(a.end_g[0], r) = gv;
-        AT(a.end_q[1], r) = qv;
-        AT(a.end_p[1], r) = pv;
-        AT(a.end_g[1], r) = gv;
-        AT(a.slot_q[0], r) = qv;
-        AT(a.slot_p[0], r) = pv;
-        AT(a.slot_g[0], r) = gv;
-        AT(a.psum, r) = pv;
-      }
-    });
+      kd += (im * pv) * pv;
+    }
   }
   ChainRng rng = rng_load(a, c);
   ChainCtl ct = {};
   sum4(kd, z1, z2, z3);
+  const double U0 = a.U[c];
   {
-    const double U = a.U[c];
-    ct.H0 = U + 0.5 * kd;
-    ct.prop_E = ct.H0;
+    ct.H0 = U0 + 0.5 * kd;
     ct.prop_w = 0.0;
     ct.prop_slpa = -INFINITY;
-    ct.U_cur = ct.U_end[0] = ct.U_end[1] = ct.U_slot[0] = ct.U_slot[1] = U;
+    ct.U_cur = ct.U_end[0] = ct.U_end[1] = ct.U_slot[0] = ct.U_slot[1] = U0;
     ct.dir = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
   }
   const double eps = a.eps_c ? a.eps_c[c] : a.eps;
-  int ck_last = -1;  // checkpoint index the previous step stored to (-1: none)
+  int ck_last = -1;  // checkpoint index whose pair the registers held before this step (-1: none)
+  Par cur[BR], nxt[BR];  // streamed parameters: batch 0 of the next pass is fetched ahead
+  if (STREAM) {
+#pragma unroll
+    for (int u = 0; u < BR; u++) cur[u] = par_load(u);
+  }
 
+#ifdef AEHMC_WIDE_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = (long long)__builtin_amdgcn_s_memtime();
+#endif
   while (!ct.done) {
     AEHMC_FRESH_TT();
+    AEHMC_TICK(7);
     const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
     const double b = 0.5 * step_size, aa = 1 * step_size;
     const int step = ct.step;
@@ -205,74 +241,107 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     // level tmax of the check is the pair the previous step stored: p and the momentum sum as
     // they are in registers before this step's update
     const bool fwd = check && ck_last == tmax;
-    const double fwd_m = fwd ? 1.0 : 0.0;
-    double *const ckp = a.ckp + ((size_t)tmax * a.C + c) * a.D;
-    double *const cks = a.cks + ((size_t)tmax * a.C + c) * a.D;
+    // termination.py:115-124 stores a checkpoint pair at every even step.  Only the pairs that
+    // open a sub-tree of 4 or more steps are ever read back from memory (at step + 2^k - 1,
+    // k >= 2, which needs step = 0 mod 4): the pair of a step = 2 mod 4 is consumed by the next
+    // step alone -- from registers, above -- and overwritten before any other read, and the
+    // step-0 pair written to a stale index >= 1 is overwritten by that index's own sub-tree before
+    // it is read (only index 0 is ever read without a store of this sub-trajectory before it).
+    const bool ck_store = (step & 3) == 0 && (step > 0 || tmax == 0);
+    double *const ckp = a.ckp + ((size_t)tmax * a.C + c) * a.ldw;
+    double *const cks = a.cks + ((size_t)tmax * a.C + c) * a.ldw;
 
     // ---- one pass: leapfrog + kinetic energy + momentum sum + checkpoint + first U-turn level ----
     double usum = 0.0, d_l = 0.0, d_r = 0.0;
     kd = 0.0;
-    Par cur[BR], nxt[BR];
-    if (!PAR_REG) {
+    auto pass = [&](auto fwd_tag) {
+      constexpr bool FWD = decltype(fwd_tag)::value;
+#pragma unroll
+      for (int b0 = 0; b0 < NB; b0++) {
+        if (STREAM && b0 + 1 < NB) {
+#pragma unroll
+          for (int u = 0; u < BR; u++) nxt[u] = par_load((b0 + 1) * BR + u);
+        }
+#pragma unroll
+        for (int u = 0; u < BR; u++) {
+          const int r = b0 * BR + u;
+          if (r < nslots) {
+            Par x = PAR_REG ? preg[PAR_REG ? r : 0] : cur[u];
+            if (IM_LDS) x.im = sim[EL(r)];
+            const double p_old = p[r], pb_old = pb[r];
+            double pp = p_old - b * GGET(r);               // integrators.py:59-60
+            const double qq = QGET(r) + aa * (x.im * pp);  // integrators.py:62-64
+            double uu, gg;
+            if (TK == AEHMC_T_STD_NORMAL) {
+              uu = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
+              gg = qq;
+            } else if (ISO) {
+              uu = qq * qq;
+              gg = qq;
+            } else {
+              const double z = (qq - x.mu) / x.sd;
+              uu = 0.5 * (z * z) + x.ls + AEHMC_LOG_SQRT_2PI;
+              gg = z / x.sd;
+            }
+            pp = pp - b * gg;                               // integrators.py:67-69
+            QSET(r, qq);
+            GSET(r, gg);
+            p[r] = pp;
+            const double v = x.im * pp;
+            const double s = (step == 0) ? pp : pb_old + pp;  // trajectory.py:278,243
+            pb[r] = s;
+            usum += (ISO || ON(r)) ? uu : 0.0;  // (a slot past D adds the target's constant only)
+            kd += v * pp;
+            if (FWD) {  // termination.py:160-173 for level idx_max, from registers
+              const double pl = p_old, vl = x.im * pl;
+              const double sub = s - pb_old + pl;
+              const double rho = sub - (pp + pl) / 2;
+              d_l += vl * rho;
+              d_r += v * rho;
+            }
+            if (ck_store) {
+              ckp[EW(r)] = pp;
+              cks[EW(r)] = s;
+            }
+          }
+        }
+        if (STREAM && b0 + 1 < NB) {
+#pragma unroll
+          for (int u = 0; u < BR; u++) cur[u] = nxt[u];
+        }
+        if (R > 8) __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (fwd) pass(std::true_type{});
+    else pass(std::false_type{});
+    if (even) ck_last = tmax;
+    AEHMC_TICK(0);  // pass
+    // fetched ahead, behind the reduction and the per-chain scalar work below: the first
+    // parameter batch of the next pass, and the first checkpoint pair this step's U-turn check
+    // needs from memory (level tmax when it is not in registers, else level tmax - 1)
+    if (STREAM) {
 #pragma unroll
       for (int u = 0; u < BR; u++) cur[u] = par_load(u);
     }
+    const int pre_idx = fwd ? tmax - 1 : tmax;
+    const bool pre_on = check && pre_idx >= tmin;
+    double pre_kp[R], pre_ks[R];
+    if (pre_on) {
+      const double *kp = a.ckp + ((size_t)pre_idx * a.C + c) * a.ldw;
+      const double *ks = a.cks + ((size_t)pre_idx * a.C + c) * a.ldw;
 #pragma unroll
-    for (int b0 = 0; b0 < NB; b0++) {
-      if (!PAR_REG && b0 + 1 < NB) {
-#pragma unroll
-        for (int u = 0; u < BR; u++) nxt[u] = par_load((b0 + 1) * BR + u);
+      for (int r = 0; r < R; r++) {
+        pre_kp[r] = r < nslots ? kp[EW(r)] : 0.0;
+        pre_ks[r] = r < nslots ? ks[EW(r)] : 0.0;
       }
+    } else {
 #pragma unroll
-      for (int u = 0; u < BR; u++) {
-        const int r = b0 * BR + u;
-        const Par x = PAR_REG ? preg[PAR_REG ? r : 0] : cur[u];
-        AEHMC_SLOT(r, {
-          const double p_old = p[r], pb_old = pb[r];
-          double pp = p_old - b * GGET(r);               // integrators.py:59-60
-          const double qq = QGET(r) + aa * (x.im * pp);  // integrators.py:62-64
-          double uu, gg;
-          if (TK == AEHMC_T_STD_NORMAL) {
-            uu = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
-            gg = qq;
-          } else if (TK == AEHMC_T_ISO_GAUSSIAN) {
-            uu = qq * qq;
-            gg = qq;
-          } else {
-            const double z = (qq - x.mu) / x.sd;
-            uu = 0.5 * (z * z) + x.ls + AEHMC_LOG_SQRT_2PI;
-            gg = z / x.sd;
-          }
-          pp = pp - b * gg;                               // integrators.py:67-69
-          QSET(r, qq);
-          GSET(r, gg);
-          p[r] = pp;
-          const double v = x.im * pp;
-          const double s = (step == 0) ? pp : pb_old + pp;  // trajectory.py:278,243
-          pb[r] = s;
-          // termination.py:160-173 for level idx_max, from registers (weight 0 when not due)
-          const double pl = p_old, vl = x.im * pl;
-          const double sub = s - pb_old + pl;
-          const double rho = sub - (pp + pl) / 2;
-          usum += on ? uu : 0.0;
-          kd += on ? v * pp : 0.0;
-          d_l += on ? fwd_m * (vl * rho) : 0.0;
-          d_r += on ? fwd_m * (v * rho) : 0.0;
-          if (even && on) {  // termination.py:115-124
-            ckp[EI(r)] = pp;
-            cks[EI(r)] = s;
-          }
-        });
-      }
-      if (!PAR_REG && b0 + 1 < NB) {
-#pragma unroll
-        for (int u = 0; u < BR; u++) cur[u] = nxt[u];
-      }
-      if (R > 8) __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < R; r++) pre_kp[r] = pre_ks[r] = 0.0;
     }
-    if (even) ck_last = tmax;
+    AEHMC_TICK(1);  // prefetch issue
     sum4(usum, kd, d_l, d_r);
-    ct.U_cur = (TK == AEHMC_T_ISO_GAUSSIAN) ? 0.5 * usum : usum;
+    AEHMC_TICK(2);  // reduction + barrier
+    ct.U_cur = ISO ? 0.5 * usum : usum;
     ct.tmin = tmin;
     ct.tmax = tmax;
 
@@ -284,7 +353,6 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
     bool term = false, take = false;
     if (step == 0) {
-      ct.sub_E = E;
       ct.sub_w = np_w;
       ct.sub_slpa = np_slpa;
       ct.length = 1;
@@ -295,60 +363,37 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
       const int acc = rng_bernoulli(rng.g[2], pa);
       ct.sub_w = np_logaddexp(ct.sub_w, np_w);
       ct.sub_slpa = np_logaddexp(ct.sub_slpa, np_slpa);
-      if (acc) {
-        ct.sub_E = E;
-        take = !ct.phantom;
-      }
+      if (acc) take = !ct.phantom;
       ct.length += 1;
+      AEHMC_TICK(3);  // per-chain scalars
       if (check) {  // termination.py:133-187
         int idx = tmax;
         bool crit = false;
         for (;;) {
-          if (!(fwd && idx == tmax)) {  // a level that is not in registers: read its checkpoint pair
+          if (!(fwd && idx == tmax)) {  // a level that is not in registers: its checkpoint pair from memory
             AEHMC_FRESH_TT();
-            const double *kp = a.ckp + ((size_t)idx * a.C + c) * a.D;
-            const double *ks = a.cks + ((size_t)idx * a.C + c) * a.D;
+            if (idx != pre_idx) {  // not fetched ahead (third and later levels: 1 step in 8)
+              const double *kp = a.ckp + ((size_t)idx * a.C + c) * a.ldw;
+              const double *ks = a.cks + ((size_t)idx * a.C + c) * a.ldw;
+#pragma unroll
+              for (int r = 0; r < R; r++) {
+                pre_kp[r] = r < nslots ? kp[EW(r)] : 0.0;
+                pre_ks[r] = r < nslots ? ks[EW(r)] : 0.0;
+              }
+            }
             d_l = 0.0;
             d_r = 0.0;
-            double kpc[BR], ksc[BR], imc[BR], kpn[BR], ksn[BR], imn[BR];
 #pragma unroll
-            for (int u = 0; u < BR; u++) {
-              kpc[u] = kp[EI(u)];
-              ksc[u] = ks[EI(u)];
-              imc[u] = IMOF(u);
-            }
-#pragma unroll
-            for (int b0 = 0; b0 < NB; b0++) {
-              if (b0 + 1 < NB) {
-#pragma unroll
-                for (int u = 0; u < BR; u++) {
-                  const int r = (b0 + 1) * BR + u;
-                  kpn[u] = kp[EI(r)];
-                  ksn[u] = ks[EI(r)];
-                  imn[u] = IMOF(r);
-                }
+            for (int r = 0; r < R; r++) {
+              if (r < nslots) {
+                const double im = IMOF(r);
+                const double pl = pre_kp[r], pr = p[r];
+                const double vl = im * pl, vr = im * pr;
+                const double sub = pb[r] - pre_ks[r] + pl;
+                const double rho = sub - (pr + pl) / 2;
+                d_l += vl * rho;
+                d_r += vr * rho;
               }
-#pragma unroll
-              for (int u = 0; u < BR; u++) {
-                const int r = b0 * BR + u;
-                AEHMC_SLOT(r, {
-                  const double pl = kpc[u], pr = p[r];
-                  const double vl = imc[u] * pl, vr = imc[u] * pr;
-                  const double sub = pb[r] - ksc[u] + pl;
-                  const double rho = sub - (pr + pl) / 2;
-                  d_l += on ? vl * rho : 0.0;
-                  d_r += on ? vr * rho : 0.0;
-                });
-              }
-              if (b0 + 1 < NB) {
-#pragma unroll
-                for (int u = 0; u < BR; u++) {
-                  kpc[u] = kpn[u];
-                  ksc[u] = ksn[u];
-                  imc[u] = imn[u];
-                }
-              }
-              if (R > 8) __builtin_amdgcn_sched_barrier(0);
             }
             double e0 = 0.0, e1 = 0.0;
             sum4(d_l, d_r, e0, e1);
@@ -361,22 +406,24 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
         term = crit;
       }
     }
+    AEHMC_TICK(4);  // U-turn levels from memory
+    const int sub_buf = prop_buf == 0 ? 1 : 0;  // slot of this sub-trajectory's proposal
     if (take) {  // sub-trajectory proposal <- moving end (copy on accept)
       AEHMC_FRESH_TT();
-      const int s = ct.prop_slot ^ 1;
+      double *const dq = pick2(a.slot_q, sub_buf), *const dp = pick2(a.slot_p, sub_buf),
+                   *const dg = pick2(a.slot_g, sub_buf);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        AEHMC_SLOT(r, {
-          if (on) {
-            AT(pick2(a.slot_q, s), r) = QGET(r);
-            AT(pick2(a.slot_p, s), r) = p[r];
-            AT(pick2(a.slot_g, s), r) = GGET(r);
-          }
-        });
+        if (r < nslots) {
+          WA(dq, r) = QGET(r);
+          WA(dp, r) = p[r];
+          if (DG) WA(dg, r) = GGET(r);
+        }
       }
-      put2(ct.U_slot, s, ct.U_cur);
+      put2(ct.U_slot, sub_buf, ct.U_cur);
     }
 
+    AEHMC_TICK(5);  // proposal copy
     // ---- sub-trajectory / expansion control (trajectory.py:336, 537-608) ----------------------
     bool finalize = false, fin_div = false, fin_term = false;
     if (step == 0 && div && !ct.phantom) {
@@ -395,40 +442,33 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     if (finalize) {
       AEHMC_FRESH_TT();
       const int dir = ct.dir, oth = 1 - dir;
+      const bool oth_init = oth ? end_init1 : end_init0;
+      const double *const po_src = oth_init ? a.zbuf : pick2(a.end_p, oth);
+      const double *const ps_src = psum_init ? a.zbuf : a.psum;
+      double pov[R], psv[R];  // every load of the sweep is issued before the first use
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        pov[r] = r < nslots ? WA(po_src, r) : 0.0;
+        psv[r] = r < nslots ? WA(ps_src, r) : 0.0;
+      }
       d_l = 0.0;
       d_r = 0.0;
 #pragma unroll
-      for (int b0 = 0; b0 < NB; b0++) {
-        double pov[BR], psv[BR], imv[BR];
-#pragma unroll
-        for (int u = 0; u < BR; u++) {
-          const int r = b0 * BR + u;
-          pov[u] = AT(pick2(a.end_p, oth), r);
-          psv[u] = AT(a.psum, r);
-          imv[u] = IMOF(r);
+      for (int r = 0; r < R; r++) {
+        if (r < nslots) {
+          const double im = IMOF(r);
+          const double pc = p[r], po = pov[r];
+          const double vc = im * pc, vo = im * po;
+          const double s = psv[r] + pb[r];
+          const double pl = dir ? po : pc, pr = dir ? pc : po;
+          const double vl = dir ? vo : vc, vr = dir ? vc : vo;
+          const double rho = s - (pr + pl) / 2;
+          d_l += vl * rho;
+          d_r += vr * rho;
+          WA(a.psum, r) = s;
         }
-#pragma unroll
-        for (int u = 0; u < BR; u++) {
-          const int r = b0 * BR + u;
-          AEHMC_SLOT(r, {
-            const double pc = p[r], po = pov[u];
-            const double vc = imv[u] * pc, vo = imv[u] * po;
-            const double s = psv[u] + pb[r];
-            const double pl = dir ? po : pc, pr = dir ? pc : po;
-            const double vl = dir ? vo : vc, vr = dir ? vc : vo;
-            const double rho = s - (pr + pl) / 2;
-            d_l += on ? vl * rho : 0.0;
-            d_r += on ? vr * rho : 0.0;
-            if (on) {
-              AT(a.psum, r) = s;
-              AT(pick2(a.end_q, dir), r) = QGET(r);
-              AT(pick2(a.end_p, dir), r) = pc;
-              AT(pick2(a.end_g, dir), r) = GGET(r);
-            }
-          });
-        }
-        if (R > 8) __builtin_amdgcn_sched_barrier(0);
       }
+      psum_init = false;
       double e0 = 0.0, e1 = 0.0;
       sum4(d_l, d_r, e0, e1);
       const bool turning = (d_l <= 0) | (d_r <= 0);
@@ -443,29 +483,33 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
       } else {
         ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);
         ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
-        if (acc_b) {
-          ct.prop_slot ^= 1;
-          ct.prop_E = ct.sub_E;
-        }
+        if (acc_b) prop_buf = sub_buf;
       }
       ct.ndoubl = ct.j + 1;
       ct.out_div = fin_div;
       ct.out_turn = turning;
       const bool end_transition = fin_div || turning || fin_term || (ct.j + 1 == a.max_exp);
       if (end_transition) {
-        const int s = ct.prop_slot;  // outputs (the phantom scan below cannot change them)
+        // outputs (the phantom scan below cannot change them); a proposal that is still the initial
+        // state leaves q, dU/dq and U as they are
+        const double *const oq = pick2(a.slot_q, prop_buf & 1), *const og = pick2(a.slot_g, prop_buf & 1);
+        const double *const op = prop_buf == 2 ? a.zbuf : pick2(a.slot_p, prop_buf);
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          AEHMC_SLOT(r, {
-            if (on) {
-              AT(a.q, r) = AT(pick2(a.slot_q, s), r);
-              AT(a.g, r) = AT(pick2(a.slot_g, s), r);
-              if (a.out.momentum) AT(a.out.momentum, r) = AT(pick2(a.slot_p, s), r);
+          if (r < nslots) {
+            const double pv = WA(op, r);
+            if (ON(r)) {
+              if (prop_buf != 2) {
+                const double qv = WA(oq, r);
+                UA(a.q, r) = qv;
+                UA(a.g, r) = DG ? WA(og, r) : qv;
+              }
+              if (a.out.momentum) UA(a.out.momentum, r) = pv;
             }
-          });
+          }
         }
         if (t == 0) {
-          a.U[c] = pick2(ct.U_slot, s);
+          if (prop_buf != 2) a.U[c] = pick2(ct.U_slot, prop_buf);
           a.out.acceptance_probability[c] = ct.acc_prob;
           if (a.out.num_doublings) a.out.num_doublings[c] = ct.ndoubl;
           if (a.out.is_turning) a.out.is_turning[c] = ct.out_turn;
@@ -482,22 +526,48 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
         const int go_right = rng_bernoulli(rng.g[1], 0.5);
         ct.dir = go_right;
         ct.step = 0;
-        if (go_right != dir) {  // continue from the other end
+        if (go_right != dir) {  // continue from the other end: park this end, fetch that one
+          const bool src_init = go_right ? end_init1 : end_init0;
+          double nq[R], np_[R], ng[DG ? R : 1];
+          if (src_init) {  // the caller's (unpadded) arrays
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              const bool on = r < nslots && ON(r);
+              nq[r] = on ? UA(a.q, r) : 0.0;
+              if (DG) ng[DG ? r : 0] = on ? UA(a.g, r) : 0.0;
+              np_[r] = r < nslots ? WA(a.zbuf, r) : 0.0;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              nq[r] = r < nslots ? WA(pick2(a.end_q, go_right), r) : 0.0;
+              if (DG) ng[DG ? r : 0] = r < nslots ? WA(pick2(a.end_g, go_right), r) : 0.0;
+              np_[r] = r < nslots ? WA(pick2(a.end_p, go_right), r) : 0.0;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < R; r++) {
-            AEHMC_SLOT(r, {
-              const double qv = AT(pick2(a.end_q, go_right), r);
-              const double gv = DG ? AT(pick2(a.end_g, go_right), r) : qv;
-              p[r] = AT(pick2(a.end_p, go_right), r);
-              QSET(r, qv);
-              GSET(r, gv);
-            });
+            if (r < nslots) {
+              WA(pick2(a.end_q, dir), r) = QGET(r);
+              WA(pick2(a.end_p, dir), r) = p[r];
+              if (DG) WA(pick2(a.end_g, dir), r) = GGET(r);
+              p[r] = np_[r];
+              QSET(r, nq[r]);
+              GSET(r, DG ? ng[DG ? r : 0] : nq[r]);
+            }
           }
+          if (dir) end_init1 = false;
+          else end_init0 = false;
           ct.U_cur = pick2(ct.U_end, go_right);
         }
       }
+      AEHMC_TICK(6);  // expansion boundary
     }
   }
+#ifdef AEHMC_WIDE_TIMING
+  if (t == 0)
+    for (int k = 0; k < 8; k++) a.linreg_part[c * 8 + k] = (double)tacc[k];
+#endif
   if (t == 0) {
     if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
     pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, rng.g[1]);
@@ -505,10 +575,12 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     pcg_store(a.rng + ((size_t)c * a.nsites + 3) * 4, rng.g[3]);
   }
 #undef AEHMC_FRESH_TT
-#undef AEHMC_SLOT
-#undef EI
-#undef VALID
-#undef AT
+#undef EW
+#undef EC
+#undef EL
+#undef ON
+#undef WA
+#undef UA
 #undef QGET
 #undef QSET
 #undef GGET
@@ -525,8 +597,8 @@ inline bool nuts_wide_supported(int tkind, int met_ndim, long long D) {
 
 template <int T, int R, bool QGL>
 inline hipError_t launch_nuts_wide_tr(const EngineArgs &a, hipStream_t st) {
-  const bool dg = a.tkind == AEHMC_T_DIAG_GAUSSIAN;
-  const size_t dyn = QGL ? (size_t)(dg ? 2 : 1) * a.D * sizeof(double) : 0;
+  // q and (diagonal target) dU/dq or (otherwise, R > 8) imm: two arrays of D + 1 doubles
+  const size_t dyn = QGL ? (size_t)2 * (a.D + 1) * sizeof(double) : 0;
   const dim3 grid((unsigned)a.C), block(T);
 #define AEHMC_WIDE_LAUNCH(TKV)                                                                          \
   do {                                                                                                  \
@@ -545,7 +617,9 @@ inline hipError_t launch_nuts_wide_tr(const EngineArgs &a, hipStream_t st) {
 #undef AEHMC_WIDE_LAUNCH
   return hipGetLastError();
 }
-// the momentum of site #1 must already be in a.zbuf (k_draw_momentum)
+// row stride of the engine's work arrays on this path (a multiple of every team size)
+inline long long nuts_wide_ld(long long D) { return (D + 511) / 512 * 512; }
+// the momentum of site #1 must already be in a.zbuf (k_draw_momentum, rows of a.ldw, zero padded)
 inline hipError_t launch_nuts_wide(const EngineArgs &a, hipStream_t st) {
   const long long D = a.D;
   if (D <= 1024) return launch_nuts_wide_tr<256, 4, false>(a, st);
