@@ -59,7 +59,6 @@ struct EngineArgs {
   // per-chain RNG [C, nsites, 4]
   uint64_t *rng;
   int nsites;
-  int z_ready;  // zbuf already holds this transition's momentum (k_draw_momentum ran first)
   // work vectors [C,D]
   double *cur_q, *cur_p, *cur_g, *cur_v, *cur_w;
   double *end_q[2], *end_p[2], *end_g[2], *end_v[2], *end_w[2];

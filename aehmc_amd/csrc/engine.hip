@@ -739,7 +739,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       ctx->opt_resident_nuts == 1 ||
       (ctx->opt_resident_nuts == 2 &&
        (a.D > 256 || C >= 16384 || C <= 2048 || a.tkind == AEHMC_T_LINREG));
-  if (want_resident && nuts_resident_supported(a.tkind, a.met_ndim, a.D)) {
+  if (want_resident && (nuts_resident_supported(a.tkind, a.met_ndim, a.D) || nuts_wide_supported(a.tkind, a.met_ndim, a.D))) {
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
     if (a.D > 512) {  // one workgroup per chain (nuts_wide.cuh): momentum drawn at one wavefront per chain first

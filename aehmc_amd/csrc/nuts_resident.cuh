@@ -1,9 +1,8 @@
 // Register-resident NUTS transition (gfx950): the whole nuts.new_kernel(...)(state, eps, imm)
 // call in ONE launch, the chain's moving state living on chip for the entire tree.
 //
-// A *team* of T threads owns one chain:
+// A *team* of T threads owns one chain (D <= 512; larger chains: nuts_wide.cuh):
 //   T = 64            one wavefront per chain (the north star's layout), 128 < D <= 512;
-//   T = 256 / 1024    one workgroup per chain for larger D (cross-wave sums through LDS);
 //   T = 1 ... 32      sub-wavefront teams for small D: 64/T chains share a wavefront, so the
 //                     per-chain scalar work (RNG, exp/log of the proposal weights, tree
 //                     indices) -- ~3000 fp64 instructions per leapfrog that a full wave
@@ -11,8 +10,7 @@
 //                     chains of a wave diverge like ordinary SIMT threads.
 // Thread t keeps elements t, t+T, ... of
 // q, p, dU/dq and of the sub-trajectory momentum sum in VGPRs; energies and U-turn dot
-// products are __shfl_xor wavefront reductions (plus one LDS hop across the waves of a
-// workgroup team).  HBM/L2 sees only the U-turn checkpoints (written every other step,
+// products are DPP wavefront reductions.  HBM/L2 sees only the U-turn checkpoints (written every other step,
 // ~1 pair read per step), the trajectory ends at expansion boundaries and the proposal on
 // accept -- instead of the 88*D bytes per leapfrog of a streaming implementation.
 //
@@ -29,11 +27,10 @@ namespace aehmc {
 
 template <int T>
 struct Team {
+  static_assert(T <= 64, "teams are at most one wavefront");
   static constexpr bool SUB = (T < 64);    // several chains per wavefront
   static constexpr bool WAVE = (T == 64);  // one wavefront per chain
-  static constexpr bool MULTI = (T > 64);  // one workgroup per chain
-  static constexpr int BLOCK = MULTI ? T : 256;
-  static constexpr int NW = MULTI ? T / 64 : 1;  // waves per team
+  static constexpr int BLOCK = 256;
 };
 
 // butterfly sum over the T (< 64) consecutive lanes of a sub-wavefront team
@@ -49,7 +46,7 @@ __device__ __forceinline__ double subwave_sum(double x) {
 
 // sum of two values over the team; every thread of the team returns the same bits
 template <int T>
-__device__ __forceinline__ void team_sum2(double &x, double &y, double (*red)[2 * Team<T>::NW], int &flip) {
+__device__ __forceinline__ void team_sum2(double &x, double &y) {
   if (Team<T>::SUB) {
     x = subwave_sum<T>(x);
     y = subwave_sum<T>(y);
@@ -57,32 +54,8 @@ __device__ __forceinline__ void team_sum2(double &x, double &y, double (*red)[2 
   }
   x = wave_sum(x);
   y = wave_sum(y);
-  if (Team<T>::MULTI) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    double *buf = red[flip];
-    flip ^= 1;  // double-buffered: the next reduction writes the other buffer
-    if (lane == 0) {
-      buf[2 * wave] = x;
-      buf[2 * wave + 1] = y;
-    }
-    __syncthreads();
-    double sx = buf[0], sy = buf[1];
-#pragma unroll
-    for (int w = 1; w < Team<T>::NW; w++) {
-      sx += buf[2 * w];
-      sy += buf[2 * w + 1];
-    }
-    // identical in every thread of the workgroup: tell the compiler (SGPRs, scalar branches)
-    x = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sx)),
-                         __builtin_amdgcn_readfirstlane(__double2loint(sx)));
-    y = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sy)),
-                         __builtin_amdgcn_readfirstlane(__double2loint(sy)));
-  }
 }
 
-// QGL: q and dU/dq of the moving end live in LDS instead of VGPRs (one workgroup per CU
-// owns up to 160 KB: a whole D = 1e4 chain), p and the momentum sum stay in registers.
-//
 // LR: the linear-regression target (examples/LinearRegression.ipynb:126-166, D = 2).  Its
 // gradient is a reduction over the N data rows, so the four wavefront-teams of a workgroup
 // evaluate it together: every thread streams its rows of (X, y) once per leapfrog (from L2)
@@ -90,29 +63,25 @@ __device__ __forceinline__ void team_sum2(double &x, double &y, double (*red)[2 
 // has finished keeps serving rows until the whole workgroup is done.
 constexpr int LR_BLOCK = 512, LR_WAVES = LR_BLOCK / 64;  // 4 chain waves + 4 waves that only serve rows
 constexpr int LR_CHUNK = 256, LR_RING = 4;               // rows per chunk, chunks in flight per wave (128 KB of LDS)
-template <int T, int R, bool QGL = false, bool LR = false>
+template <int T, int R, bool LR = false>
 __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
   using TM = Team<T>;
-  static_assert(!LR || (T == 64 && R == 1 && !QGL), "LR: one wavefront per chain, D = 2");
-  __shared__ double red[2][2 * TM::NW];
+  static_assert(!LR || (T == 64 && R == 1), "LR: one wavefront per chain, D = 2");
   __shared__ double lr_w[4], lr_part[LR_WAVES][8];
   __shared__ int lr_done[4];
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
-  double *const sq = dyn_lds, *const sg = dyn_lds + (QGL ? a.D : 0);
-  int flip = 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long c = LR && wave >= 4 ? a.C  // row-serving wave: no chain
                       : TM::SUB       ? ((long long)blockIdx.x * 256 + threadIdx.x) / T
-                      : TM::WAVE      ? (long long)blockIdx.x * 4 + wave
-                                      : (long long)blockIdx.x;
-  const int t = TM::SUB ? (int)(threadIdx.x % T) : TM::WAVE ? lane : (int)threadIdx.x;
-  const bool ghost = c >= a.C;  // a whole team leaves together (only workgroup teams use the barrier) ...
+                                      : (long long)blockIdx.x * 4 + wave;
+  const int t = TM::SUB ? (int)(threadIdx.x % T) : lane;
+  const bool ghost = c >= a.C;  // a whole team leaves together ...
   if (ghost && !LR) return;     // ... except with LR, where it stays to serve data rows
   const size_t row = (size_t)c * a.D;
   const bool lead = t == 0;
 
-  double q[QGL ? 1 : R], g[QGL ? 1 : R], p[R], pb[R];  // moving end + sub-trajectory momentum sum
+  double q[R], g[R], p[R], pb[R];  // moving end + sub-trajectory momentum sum
   bool ok[R];
 // large R: keep the scheduler from interleaving all R unrolled iterations (their
 // temporaries would not fit the register file and spill)
@@ -121,10 +90,10 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 #define EI(r) ((unsigned)(t + T * (r)))
 #define AT(ptr, r) ((ptr) + row)[EI(r)]
 #define R_FENCE() do { if (R > 4) __builtin_amdgcn_sched_barrier(0); } while (0)
-#define QGET(r) (QGL ? sq[t + T * (r)] : q[QGL ? 0 : (r)])
-#define GGET(r) (QGL ? sg[t + T * (r)] : g[QGL ? 0 : (r)])
-#define QSET(r, v) do { if (QGL) sq[t + T * (r)] = (v); else q[QGL ? 0 : (r)] = (v); } while (0)
-#define GSET(r, v) do { if (QGL) sg[t + T * (r)] = (v); else g[QGL ? 0 : (r)] = (v); } while (0)
+#define QGET(r) (q[r])
+#define GGET(r) (g[r])
+#define QSET(r, v) do { q[r] = (v); } while (0)
+#define GSET(r, v) do { g[r] = (v); } while (0)
   // imm is re-read from L1/L2 when many elements per thread would cost registers
   constexpr bool IM_REG = R <= 4;
   constexpr int BR = R > 4 ? 4 : R;  // elements whose global operands are in flight together
@@ -149,10 +118,8 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
     const long long i = (long long)t + (long long)T * r;
     ok[r] = i < a.D;
     if (IM_REG) imr[r] = ok[r] ? a.imm[imo + (a.met_ndim == 0 ? 0 : i)] : 1.0;
-    if (ok[r] || !QGL) {
-      QSET(r, ok[r] ? AT(a.q, r) : 0.0);
-      GSET(r, ok[r] ? AT(a.g, r) : 0.0);
-    }
+    QSET(r, ok[r] ? AT(a.q, r) : 0.0);
+    GSET(r, ok[r] ? AT(a.g, r) : 0.0);
   }
 
   // ---- momentum, site #1 (nuts.py:113 -> metrics.py:65-68) ------------------------
@@ -173,7 +140,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
     }
     if (lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
   } else {
-    if ((TM::WAVE || wave == 0) && !(TM::MULTI && a.z_ready)) {
+    {
       const double *sm = a.sqrt_mass + imo;
       const bool scalar = a.met_ndim == 0;
       double *dst = a.zbuf;
@@ -181,7 +148,6 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
       if (lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
     }
     __threadfence_block();
-    if (TM::MULTI) __syncthreads();
   }
 
   // ---- nuts.py:113-125 ----------------------------------------------------------------
@@ -204,7 +170,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
       AT(a.psum, r) = p[r];
     }
   }
-  team_sum2<T>(kd, zero, red, flip);
+  team_sum2<T>(kd, zero);
   {
     const double U = a.U[c];
     ct.H0 = U + 0.5 * kd;
@@ -344,7 +310,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
         p[0] = pp;
         kd = (IMM(0) * pp) * pp;
       }
-      team_sum2<T>(usum, kd, red, flip);
+      team_sum2<T>(usum, kd);
     } else {
       // (global operands -- imm when it is not in registers -- are fetched BR elements at a
       // time: one round trip per batch instead of one per element)
@@ -372,7 +338,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
         }
         R_FENCE();
       }
-      team_sum2<T>(usum, kd, red, flip);
+      team_sum2<T>(usum, kd);
       ct.U_cur = target_finish(a, usum);
     }
 
@@ -461,7 +427,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
             }
             R_FENCE();
           }
-          team_sum2<T>(d_l, d_r, red, flip);
+          team_sum2<T>(d_l, d_r);
           crit = (d_l <= 0) | (d_r <= 0);
           bool reached = (idx - 1) < tmin;
           idx -= 1;
@@ -533,7 +499,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
         }
         R_FENCE();
       }
-      team_sum2<T>(d_l, d_r, red, flip);
+      team_sum2<T>(d_l, d_r);
       const bool turning = (d_l <= 0) | (d_r <= 0);
       put2(ct.U_end, dir, ct.U_cur);
       ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;
@@ -615,25 +581,21 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 
 inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
   if (tkind == AEHMC_T_LINREG) return met_ndim < 2 && D == 2;
-  // (D = 1e4 needs 160 000 of the CU's 163 840 bytes of LDS for q and dU/dq; the kernel's small
-  //  static arrays leave room for D up to 10176)
+  // teams of 1 .. 64 lanes up to D = 512; larger chains take one workgroup each (nuts_wide.cuh)
   return (tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN) &&
-         met_ndim < 2 && D <= 10176;
+         met_ndim < 2 && D <= 512;
 }
 
-template <int T, int R, bool QGL = false, bool LR = false>
+template <int T, int R, bool LR = false>
 inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
-  const unsigned grid = Team<T>::SUB    ? (unsigned)((a.C * T + 255) / 256)
-                        : Team<T>::WAVE ? (unsigned)((a.C + 3) / 4)
-                                        : (unsigned)a.C;
-  const size_t dyn = QGL ? (size_t)2 * a.D * sizeof(double)
-                     : LR ? (size_t)LR_WAVES * LR_RING * LR_CHUNK * 2 * sizeof(double) : 0;
-  if (QGL || LR) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<T, R, QGL, LR>),
+  const unsigned grid = Team<T>::SUB ? (unsigned)((a.C * T + 255) / 256) : (unsigned)((a.C + 3) / 4);
+  const size_t dyn = LR ? (size_t)LR_WAVES * LR_RING * LR_CHUNK * 2 * sizeof(double) : 0;
+  if (LR) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<T, R, LR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((k_nuts_resident<T, R, QGL, LR>), dim3(grid), dim3(LR ? LR_BLOCK : Team<T>::BLOCK), dyn, st, a);
+  hipLaunchKernelGGL((k_nuts_resident<T, R, LR>), dim3(grid), dim3(LR ? LR_BLOCK : Team<T>::BLOCK), dyn, st, a);
   return hipGetLastError();
 }
 // Team size: the smallest team that holds the chain (<= 4 elements per lane below a wave,
@@ -642,14 +604,8 @@ inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
 // control state wave-uniform (SGPRs, scalar branches).
 inline hipError_t launch_nuts_resident(const EngineArgs &a, hipStream_t st, int force_min_team = 0) {
   const long long D = a.D, C = a.C;
-  if (a.tkind == AEHMC_T_LINREG) return launch_nuts_resident_tr<64, 1, false, true>(a, st);
-  if (D > 512) {
-    if (D <= 1024) return launch_nuts_resident_tr<256, 4>(a, st);
-    if (D <= 2048) return launch_nuts_resident_tr<256, 8>(a, st);
-    if (D <= 4096) return launch_nuts_resident_tr<512, 8, true>(a, st);
-    if (D <= 8192) return launch_nuts_resident_tr<512, 16, true>(a, st);
-    return launch_nuts_resident_tr<512, 20, true>(a, st);
-  }
+  if (a.tkind == AEHMC_T_LINREG) return launch_nuts_resident_tr<64, 1, true>(a, st);
+  if (D > 512) return hipErrorInvalidValue;  // one workgroup per chain: nuts_wide.cuh
   const int tmin = D <= 4 ? 1 : D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64;
   int twant = 64;
   while (twant > 1 && C * (twant / 2) >= 64LL * 4096) twant /= 2;

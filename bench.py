@@ -52,6 +52,69 @@ def build_c3(D, device, rho=0.5):
     return Sigma.contiguous(), P.contiguous()
 
 
+def diag_case(kind, D, C, device):
+    """Secondary workloads (diagonal / scalar mass: HBM-bound): D-dim isotropic Gaussian,
+    diagonal inverse mass matrix of ones, eps = 0.5 D^-1/4, C chains; `kind` nuts (default depth) or
+    hmc (L = 32).  Shared with tools/diag_run.py, whose rocprofv3 --pmc passes count the bytes."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    eps = 0.5 * D ** -0.25
+    q0 = torch.as_tensor(np.random.default_rng(0).standard_normal((C, D)), device=device)
+    imm = torch.ones(D, dtype=torch.float64, device=device)
+    tgt = targets.IsoGaussian()
+    mod = nuts if kind == "nuts" else hmc
+    kernel = mod.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+    state = mod.new_state(q0, tgt)
+    if kind == "nuts":
+        return state, (lambda st: kernel(st, eps, imm))
+    # HMC: 10 transitions per engine call (kernel.sample, the user-level scan); n_leapfrog is the call's total
+    return state, (lambda st: (kernel.sample(st, eps, imm, 32, 10, keep_samples=False)[1], None))
+
+
+def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
+    """Diagonal-mass NUTS and HMC at the headline shape.  `achieved` = HBM bytes per transition as
+    COUNTED by rocprofv3 (FETCH_SIZE x 2 + WRITE_SIZE of the kernels of one transition, separate
+    --pmc passes of the same workload: profiles/r2/diag_pmc_summary.json) / the transition's kernel
+    time measured here with HIP events on the launch stream."""
+    pmc_path = os.path.join(ROOT, "profiles", "r2", "diag_pmc_summary.json")
+    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) and (D, C) == (10_000, 4096) else None
+    out = []
+    for kind, main_kernel in (("nuts", "k_nuts_wide"), ("hmc", "k_hmc_wide")):
+        state, step = diag_case(kind, D, C, device)
+        for _ in range(warmup):
+            info, _ = step(state)
+            state = info.state._replace(momentum=None)
+        eng.profile_enable(True)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        nl = torch.zeros((), dtype=torch.int64, device=device)
+        for _ in range(steps):
+            info, _ = step(state)
+            state = info.state._replace(momentum=None)
+            nl += info.n_leapfrog.sum()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        kern_ms, kern_n, _ = eng.profile_read()
+        eng.profile_enable(False)
+        nl = int(nl.item())
+        per_call = 10 if kind == "hmc" else 1  # transitions per engine call (= per HIP-event pair)
+        traffic = None
+        if pmc and kind in pmc:
+            traffic = pmc[kind]["hbm_bytes_per_transition"]
+        avg_ms = kern_ms / max(kern_n, 1) / per_call
+        alg = (48.0 if kind == "hmc" else 88.0) * D * nl / (steps * per_call)  # SURVEY 8d streaming figure, for reference only
+        roof = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "kernel": main_kernel + " (+ k_draw_momentum)",
+                "avg_launch_ms": avg_ms, "launches": kern_n * per_call, "traffic": traffic,
+                "achieved": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                "streaming_bytes_per_transition": alg,
+                "note": "achieved = counted HBM bytes per transition / kernel time; the chain state is on chip, so the "
+                        "counted bytes are far below the streaming figure (48 D / 88 D per leapfrog)"}
+        roof["frac"] = roof["achieved"] / PEAK_HBM_GBS if traffic else None
+        out.append({"workload": f"{D}-dim isotropic Gaussian, diagonal mass, {'NUTS depth 10' if kind == 'nuts' else 'HMC L=32'}, "
+                                f"{C} chains", "value": nl / dt, "unit": "leapfrog-steps/s", "ms_per_transition": dt / (steps * per_call) * 1e3,
+                    "leapfrogs_per_transition": nl / (steps * per_call), "roofline": roof})
+    return out
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one process per
     GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches
@@ -85,6 +148,7 @@ def main():
     ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the diagonal-mass secondary lines")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -226,6 +290,11 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(args.config, D, q0, target, imm, eps)
+    secondary = None
+    if args.config == "c3" and world == 1 and not args.no_secondary and D == 10_000:
+        del state, info, kernel, target, imm, gathered
+        torch.cuda.empty_cache()
+        secondary = bench_secondary(eng, device, max(args.steps, 3), 1)
 
     print(json.dumps({
         "metric": "leapfrog-steps/sec across all chains", "value": value, "unit": "leapfrog-steps/s",
@@ -237,7 +306,7 @@ def main():
                    "leapfrogs_per_step": total_leap / args.steps, "ranks_seen": ranks_seen,
                    "gather": {"to": "rank 0", "bytes": (world - 1) * C * D * 8, "ms": t_g * 1e3,
                               "backend": dist_backend}},
-        "roofline": roofline, "cpu_baseline": cpu}))
+        "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))
 
 
 def bench_c1(args):

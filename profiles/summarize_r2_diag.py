@@ -27,3 +27,20 @@ for k, d in out.items():
 json.dump(out, open(os.path.join(src, "summary.json"), "w"), indent=1)
 for k, d in sorted(out.items(), key=lambda kv: -kv[1].get("total_ns", 0))[:12]:
     print(k[:90], {a: (round(b, 1) if isinstance(b, float) else b) for a, b in d.items()})
+
+# per-transition HBM bytes of the two secondary workloads of bench.py -> profiles/r2/diag_pmc_summary.json
+def find(sub):
+    ks = [k for k in out if sub in k]
+    return out[ks[0]] if ks else None
+
+dm, nw, hw = find("k_draw_momentum"), find("k_nuts_wide"), find("k_hmc_wide")
+summ = {"note": "rocprofv3 --pmc, separate passes (FETCH_SIZE; WRITE_SIZE; SQ groups) of tools/diag_run.py = bench.py's "
+                "secondary workloads; FETCH_SIZE doubled (gfx950: 128-byte requests tallied at 64 B); averages per launch; "
+                "one transition = one k_draw_momentum + one main-kernel launch"}
+for name, main in (("nuts", nw), ("hmc", hw)):
+    if main and dm and "hbm_bytes_per_launch" in main and "hbm_bytes_per_launch" in dm:
+        summ[name] = {"hbm_bytes_per_transition": main["hbm_bytes_per_launch"] + dm["hbm_bytes_per_launch"],
+                      "main_kernel": main, "k_draw_momentum": dm}
+dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r2")
+os.makedirs(dst, exist_ok=True)
+json.dump(summ, open(os.path.join(src, "diag_pmc_summary.json"), "w"), indent=1)
