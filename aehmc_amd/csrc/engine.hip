@@ -12,6 +12,7 @@
 #include "engine.cuh"
 #include "gemm_f64.cuh"
 #include "hmc_fused.cuh"
+#include "hmc_linreg.cuh"
 #include "nuts_resident.cuh"
 #include "nuts_wide.cuh"
 
@@ -871,6 +872,22 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
     HIPCHK(launch_hmc_fused(f, st));
+    return prof_end(ctx, st, p);
+  }
+  // regression target: the whole call in one launch, four chains per workgroup (hmc_linreg.cuh)
+  if (ctx->opt_fused_hmc && hmc_linreg_supported(ctx->tgt.kind, ctx->met.ndim, D)) {
+    if (int rc = check_per_chain(ctx, C)) return rc;
+    HmcFusedArgs f{};
+    f.C = C; f.D = D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
+    f.met_ndim = ctx->met.ndim; f.imm = ctx->met.imm; f.sqrt_mass = ctx->met.sqrt_mass;
+    f.imm_cs = ctx->met.per_chain ? (ctx->met.ndim == 0 ? 1 : D) : 0;
+    f.eps_c = ctx->eps_c;
+    f.tkind = ctx->tgt.kind; f.X = ctx->tgt.X; f.y = ctx->tgt.y; f.N = ctx->tgt.N;
+    f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
+    f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    HIPCHK(launch_hmc_linreg(f, st));
     return prof_end(ctx, st, p);
   }
   EngineArgs a;

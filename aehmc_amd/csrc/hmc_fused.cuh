@@ -28,6 +28,8 @@ struct HmcFusedArgs {
   const double *imm, *sqrt_mass;
   int tkind;
   const double *mu, *sigma, *log_sigma;
+  const double *X, *y;  // regression target: data rows [N]
+  long long N;
   uint64_t *rng;  // [C,2,4]
   double *q, *U, *g;
   aehmc_diagnostics out;
@@ -95,15 +97,33 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
     kd = wave_sum(kd);
     const double H0 = U + 0.5 * kd;  // hmc.py:187
 
-    for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
+    if (TK == AEHMC_T_DIAG_GAUSSIAN) {
+      for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        p[r] = p[r] - b * g[r];
-        q[r] = q[r] + aa * (im[r] * p[r]);
-        if (TK == AEHMC_T_DIAG_GAUSSIAN) g[r] = ((q[r] - mu[r]) / sg[r]) / sg[r];
-        else g[r] = q[r];
-        p[r] = p[r] - b * g[r];
+        for (int r = 0; r < R; r++) {
+          p[r] = p[r] - b * g[r];
+          q[r] = q[r] + aa * (im[r] * p[r]);
+          g[r] = ((q[r] - mu[r]) / sg[r]) / sg[r];
+          p[r] = p[r] - b * g[r];
+        }
       }
+    } else {
+      // dU/dq == q: no separate gradient registers in the loop, and the product b * q' that ends one
+      // leapfrog is the same number that starts the next: 6 fp64 operations per element and step
+      double bq[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) bq[r] = b * q[r];
+      for (long long l = 0; l < a.L; l++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          p[r] = p[r] - bq[r];
+          q[r] = q[r] + aa * (im[r] * p[r]);
+          bq[r] = b * q[r];
+          p[r] = p[r] - bq[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) g[r] = q[r];
     }
     // potential energy at the end point, kinetic energy of the flipped momentum
     double usum = 0.0;
@@ -238,18 +258,31 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
   }
   sum2(kd, zero);
   const double H0 = U + 0.5 * kd;  // hmc.py:187
-  for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
+  if (DG) {
+    for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      double pp = p[r] - b * GR(r);
-      const double qq = q[r] + aa * (im[r] * pp);
-      double gg;
-      if (DG) gg = ((qq - a.mu[EI(r)]) / a.sigma[EI(r)]) / a.sigma[EI(r)];
-      else gg = qq;
-      pp = pp - b * gg;
-      q[r] = qq;
-      if (DG) g[DG ? r : 0] = gg;
-      p[r] = pp;
+      for (int r = 0; r < R; r++) {
+        double pp = p[r] - b * GR(r);
+        const double qq = q[r] + aa * (im[r] * pp);
+        const double gg = ((qq - a.mu[EI(r)]) / a.sigma[EI(r)]) / a.sigma[EI(r)];
+        pp = pp - b * gg;
+        q[r] = qq;
+        g[DG ? r : 0] = gg;
+        p[r] = pp;
+      }
+    }
+  } else {  // dU/dq == q; b * q' ends one leapfrog and starts the next (same product, computed once)
+    double bq[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) bq[r] = b * q[r];
+    for (long long l = 0; l < a.L; l++) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        p[r] = p[r] - bq[r];
+        q[r] = q[r] + aa * (im[r] * p[r]);
+        bq[r] = b * q[r];
+        p[r] = p[r] - bq[r];
+      }
     }
   }
   double usum = 0.0;

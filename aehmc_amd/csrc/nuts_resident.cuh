@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "engine.cuh"
+#include "linreg_rows.cuh"
 
 namespace aehmc {
 
@@ -61,8 +62,6 @@ __device__ __forceinline__ void team_sum2(double &x, double &y) {
 // evaluate it together: every thread streams its rows of (X, y) once per leapfrog (from L2)
 // for all four chains, and each wave keeps the tree of its own chain.  A wave whose chain
 // has finished keeps serving rows until the whole workgroup is done.
-constexpr int LR_BLOCK = 512, LR_WAVES = LR_BLOCK / 64;  // 4 chain waves + 4 waves that only serve rows
-constexpr int LR_CHUNK = 256, LR_RING = 4;               // rows per chunk, chunks in flight per wave (128 KB of LDS)
 template <int T, int R, bool LR = false>
 __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
   using TM = Team<T>;
@@ -219,66 +218,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
         w4[k] = lr_w[k];
         sxr[k] = srr[k] = 0.0;
       }
-      // The rows stream through a wave-private LDS ring filled by LDS-DMA (global_load_lds, 16 B per
-      // lane: one instruction lands 128 consecutive doubles): a chunk is 256 rows of X and of y
-      // (4 x 1 KB), LR_RING chunks per wave are in flight, so a chunk has ~3 chunk-times (> 1 us) to
-      // arrive and no VGPR holds data in flight.  Lane l adds rows r0+l, r0+64+l, r0+128+l, r0+192+l of
-      // its wave's chunks in ascending order.
-      {
-        double *const ring = dyn_lds + (size_t)wave * (LR_RING * LR_CHUNK * 2);
-        const int nchunks = (int)(a.N / LR_CHUNK);                      // full chunks
-        const int nm = wave < nchunks ? (nchunks - wave + LR_WAVES - 1) / LR_WAVES : 0;  // this wave's
-        auto issue = [&](int m) {
-          const long long r0 = (long long)(wave + LR_WAVES * m) * LR_CHUNK;
-          double *slot = ring + (size_t)(m % LR_RING) * (LR_CHUNK * 2);
-#pragma unroll
-          for (int h = 0; h < LR_CHUNK / 128; h++) {
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(a.X + r0 + 128 * h + 2 * lane),
-                (__attribute__((address_space(3))) void *)(slot + 128 * h), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(a.y + r0 + 128 * h + 2 * lane),
-                (__attribute__((address_space(3))) void *)(slot + LR_CHUNK + 128 * h), 16, 0, 0);
-          }
-        };
-        constexpr int PER = 2 * (LR_CHUNK / 128);  // DMA instructions per chunk
-        for (int m = 0; m < LR_RING - 1 && m < nm; m++) issue(m);
-        for (int m = 0; m < nm; m++) {
-          if (m + LR_RING - 1 < nm) {
-            issue(m + LR_RING - 1);  // into the slot read in the previous step (its values are in registers)
-            __builtin_amdgcn_s_waitcnt(0x0F70 | (((LR_RING - 1) * PER) & 0xF) | ((((LR_RING - 1) * PER) >> 4) << 14));
-          } else {
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the tail of the stream
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          const double *slot = ring + (size_t)(m % LR_RING) * (LR_CHUNK * 2);
-          double xs[LR_CHUNK / 64], ys[LR_CHUNK / 64];
-#pragma unroll
-          for (int u = 0; u < LR_CHUNK / 64; u++) {
-            xs[u] = slot[64 * u + lane];
-            ys[u] = slot[LR_CHUNK + 64 * u + lane];
-          }
-          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the slot may be refilled from here on
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < LR_CHUNK / 64; u++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const double rr = ys[u] - xs[u] * w4[k];
-              sxr[k] += xs[u] * rr;
-              srr[k] += rr * rr;
-            }
-        }
-        for (long long i = (long long)nchunks * LR_CHUNK + threadIdx.x; i < a.N; i += LR_BLOCK) {  // last < 256 rows
-          const double x = a.X[i], yy = a.y[i];
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const double rr = yy - x * w4[k];
-            sxr[k] += x * rr;
-            srr[k] += rr * rr;
-          }
-        }
-      }
+      lr_rows_stream(a.X, a.y, a.N, dyn_lds, wave, lane, w4, sxr, srr);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         sxr[k] = wave_sum(sxr[k]);
@@ -589,7 +529,7 @@ inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
 template <int T, int R, bool LR = false>
 inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
   const unsigned grid = Team<T>::SUB ? (unsigned)((a.C * T + 255) / 256) : (unsigned)((a.C + 3) / 4);
-  const size_t dyn = LR ? (size_t)LR_WAVES * LR_RING * LR_CHUNK * 2 * sizeof(double) : 0;
+  const size_t dyn = LR ? LR_RING_BYTES : 0;
   if (LR) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<T, R, LR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);

@@ -375,38 +375,44 @@ def bench_c5(args, rank, world, device):
 
 
 def cpu_baseline(config, D, q0, target, imm, eps):
-    """The C restatement (oracle, "port") timed on this host's cores on a bounded sample."""
+    """The C restatement (oracle, "port") timed on this host's cores on a bounded sample, twice:
+    one thread, and all cores (OpenMP over chains, one chain per thread) -- SURVEY.md 8d."""
     from oracle import c_oracle as co
-    threads = min(os.cpu_count() or 1, 16)
-    n = threads
-    seeds = [1000 + c for c in range(n)]
-    if config == "c3":
-        mu = np.zeros(D)
-        otgt = co.Target(co.T_DENSE_MVN, D, mu=mu, prec=target.precision.cpu().numpy())
-        metric = co.Metric(imm.cpu().numpy(), D)
-        rng = co.site_states(seeds, 4)
+    cores = os.cpu_count() or 1
+
+    def run(n, threads):
+        seeds = [1000 + c for c in range(n)]
+        if config == "c3":
+            rng = co.site_states(seeds, 4)
+            q, U, g = co.new_state(otgt, q0[:n].copy())
+            t0 = time.perf_counter()
+            res = co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=max_exp, nthreads=threads)
+            return int(res["n_leapfrog"].sum()), time.perf_counter() - t0
+        rng = co.site_states(seeds, 2)
         q, U, g = co.new_state(otgt, q0[:n].copy())
-        max_exp = 3
-        t0 = time.perf_counter()
-        res = co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=max_exp, nthreads=threads)
-        dt = time.perf_counter() - t0
-        nl = int(res["n_leapfrog"].sum())
-        sample = (f"{n} chains x 1 NUTS transition truncated at max_num_expansions={max_exp} "
-                  f"({nl} leapfrogs), same D/target/metric, {threads} OpenMP threads over chains")
-    else:
-        n = 256
-        otgt, metric = co.Target(co.T_ISO_GAUSSIAN, D), co.Metric(np.ones(D), D)
-        rng = co.site_states([1000 + c for c in range(n)], 2)
-        q, U, g = co.new_state(otgt, q0[:n].copy())
-        reps = 200
         t0 = time.perf_counter()
         for _ in range(reps):
             co.hmc_step(otgt, metric, rng, eps, 32, q, U, g, nthreads=threads)
-        dt = time.perf_counter() - t0
-        nl = n * 32 * reps
-        sample = f"{n} chains x {reps} HMC transitions (L=32), {threads} OpenMP threads over chains"
-    return {"value": nl / dt, "unit": "leapfrog-steps/s", "cores": threads, "kind": "port",
-            "sample": sample, "host_cpu_count": os.cpu_count(),
+        return n * 32 * reps, time.perf_counter() - t0
+
+    if config == "c3":
+        otgt = co.Target(co.T_DENSE_MVN, D, mu=np.zeros(D), prec=target.precision.cpu().numpy())
+        metric = co.Metric(imm.cpu().numpy(), D)
+        max_exp = 3  # bounded: 2 + 3 + 5 = 10 leapfrogs per chain (a full-depth tree is ~57: minutes on a CPU)
+        n_all = min(cores, q0.shape[0])
+        what = (f"NUTS transition truncated at max_num_expansions={max_exp} (10 leapfrogs/chain), same D / target / "
+                f"dense metric as the GPU run")
+    else:
+        otgt, metric = co.Target(co.T_ISO_GAUSSIAN, D), co.Metric(np.ones(D), D)
+        reps, n_all = 100, min(4 * cores, q0.shape[0])
+        what = f"{reps} HMC transitions (L=32) per chain"
+    nl1, dt1 = run(1 if config == "c3" else 8, 1)
+    nla, dta = run(n_all, cores)
+    return {"value": nla / dta, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_all} chains x {what}, {cores} OpenMP threads over chains ({nla} leapfrogs, {dta:.1f} s)",
+            "single_thread": {"value": nl1 / dt1, "unit": "leapfrog-steps/s", "cores": 1,
+                              "sample": f"{1 if config == 'c3' else 8} chain(s) x {what} ({nl1} leapfrogs, {dt1:.1f} s)"},
+            "host_cpu_count": cores,
             "note": "C restatement of aehmc semantics (oracle/c), not Aesara; reported, not optimised"}
 
 

@@ -173,6 +173,47 @@ def test_g2_g3_regression_on_gpu(regression_data):
     assert info.acceptance_probability.item() == 1.0 and not info.is_diverging.item()
 
 
+@pytest.mark.parametrize("N,C,L", [(10_000, 1, 64), (10_000, 6, 33), (10_176, 9, 20), (10_177, 5, 20), (25_001, 7, 12), (700, 4, 50)])
+def test_regression_hmc_fused_matches_oracle(eng, N, C, L):
+    """HMC on the regression target in one launch (hmc_linreg.cuh): rows resident in LDS (N <= 10176)
+    or streamed through the LDS-DMA ring (N above), workgroups with 1..4 live chains, three consecutive
+    transitions through kernel.sample -- against the oracle, and against the lock-step path
+    (`fused_hmc` = 0), which differs in the order of the row sums only."""
+    from aehmc_amd import PerChain, RandomStream, hmc, targets
+    r = np.random.default_rng(N + C)
+    X = r.normal(0, 1, size=N)
+    y = 3 * X + 0.5 * r.normal(0, 1, size=N)  # (row-wise noise: a well-conditioned posterior for any N)
+    tgt, otgt = targets.LinearRegression(X, y), co.Target(co.T_LINREG, 2, X=X, y=y)
+    imm = np.array([0.25 / N, 0.5 / N])  # ~ posterior variances of w and log n
+    eps = 0.3
+    seeds = [500 + c for c in range(C)]
+    q0 = np.array([3.0, np.log(0.5)]) + (0.5 / np.sqrt(N)) * r.normal(size=(C, 2))
+    metric = co.Metric(imm, 2)
+    outs = {}
+    for fused in (1, 0):
+        eng.set_option("fused_hmc", fused)
+        kernel = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
+        state = hmc.new_state(dev(q0), tgt)
+        samples, info, acc, div = kernel.sample(state, eps, imm, L, 3)
+        outs[fused] = (samples.cpu().numpy(), info, acc.cpu().numpy())
+    eng.set_option("fused_hmc", 1)
+    rng = co.site_states(seeds, 2)
+    q, U, g = co.new_state(otgt, q0.copy())
+    for t in range(3):
+        res = co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
+        for fused in (1, 0):
+            np.testing.assert_allclose(outs[fused][0][t], q, rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(outs[fused][2][t], res["acceptance_probability"], rtol=1e-7, atol=1e-12)
+    for fused in (1, 0):
+        info = outs[fused][1]
+        np.testing.assert_allclose(info.state.potential_energy.cpu().numpy(), U, rtol=RTOL)
+        np.testing.assert_allclose(info.state.potential_energy_grad.cpu().numpy(), g, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(info.state.momentum.cpu().numpy(), res["momentum"], rtol=1e-7, atol=1e-10)
+        assert np.array_equal(info.is_diverging.cpu().numpy(), res["is_diverging"])
+        assert (info.n_leapfrog == 3 * L).all()
+    assert 0.2 < outs[1][2].mean() <= 1.0  # a real trajectory, not a frozen chain
+
+
 @pytest.mark.parametrize("metric_kind,C,resident", [("diag", 12, 2), ("diag", 6, 2), ("diag", 5, 0), ("dense", 12, 2)])
 def test_regression_nuts_matches_oracle(eng, regression_data, metric_kind, C, resident):
     """NUTS on the notebook's regression posterior (notebook cell 36 settings).  Diagonal metric:
