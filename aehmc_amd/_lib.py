@@ -25,7 +25,8 @@ class CMetric(ct.Structure):
 class CAdaptState(ct.Structure):
     _fields_ = [(n, ct.c_void_p) for n in ("da_step", "da_x", "da_x_avg", "da_g_avg", "da_mu",
                                            "wc_mean", "wc_m2", "wc_n", "step_size", "imm",
-                                           "sqrt_mass")] + [("full", ct.c_int32)]
+                                           "sqrt_mass")] + [("full", ct.c_int32), ("reserved", ct.c_int32),
+                                                            ("work", ct.c_void_p)]
 
 
 class CDiagnostics(ct.Structure):

@@ -1092,9 +1092,12 @@ __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long 
   if ((threadIdx.x & 63) == 0) pcg_store(rng + c * 4, g);
 }
 // ---- per-chain dense metric (what is_mass_matrix_full window adaptation produces) --------
-// Small models only (D <= AEHMC_PC_DENSE_MAX_D): every chain owns a D x D inverse mass matrix,
-// so the metric products are per-chain mat-vecs instead of one GEMM over all chains.
-constexpr int AEHMC_PC_DENSE_MAX_D = 64;
+// Every chain owns a D x D inverse mass matrix (C D^2 doubles -- the reference's per-chain
+// semantics, mass_matrix.py:12-120, which memory bounds long before AEHMC_PC_DENSE_MAX_D), so the
+// metric products are per-chain mat-vecs instead of one GEMM over all chains.  Up to
+// AEHMC_PC_LDS_MAX_D the factorisation of a chain's matrix runs in LDS, above it in global memory.
+constexpr int AEHMC_PC_LDS_MAX_D = 64;
+constexpr int AEHMC_PC_DENSE_MAX_D = 2048;
 // out[c, i] = sum_j mats[c, i, j] x[c, j]  (j ascending); one wavefront per (live) chain
 __global__ __launch_bounds__(256) void k_matvec_pc(const double *mats, const double *x, double *out, long long C,
                                                    long long D, const int *row_idx, const int *n_rows) {
@@ -1114,8 +1117,32 @@ __global__ __launch_bounds__(256) void k_matvec_pc(const double *mats, const dou
     out[(size_t)c * D + i] = s;
   }
 }
-// L = chol(A) (lower) and S = L^-T for one D x D matrix held in LDS by one wavefront
-// (metrics.py:56-58).  `A` is overwritten by L; returns false if A is not positive definite.
+// The same product for D > 64: workgroup (x, w) forms 64 rows of chain w's product, one row per
+// wave at a time with the 64 lanes striding over the columns (coalesced reads of the matrix row)
+// and a wave sum per row.
+__global__ __launch_bounds__(256) void k_matvec_pc_rows(const double *mats, const double *x, double *out,
+                                                        long long C, long long D, const int *row_idx,
+                                                        const int *n_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long w = blockIdx.y;
+  long long c = w;
+  if (row_idx) {
+    if (w >= *n_rows) return;
+    c = row_idx[w];
+  }
+  const double *m = mats + (size_t)c * D * D, *xr = x + (size_t)c * D;
+  for (int k = 0; k < 16; k++) {
+    const long long i = (long long)blockIdx.x * 64 + wave * 16 + k;
+    if (i >= D) break;
+    double s = 0.0;
+    for (long long j = lane; j < D; j += 64) s += m[i * D + j] * xr[j];
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)c * D + i] = s;
+  }
+}
+// L = chol(A) (lower) and S = L^-T for one D x D matrix worked on by one wavefront (metrics.py:56-58);
+// A and S in LDS or in global memory.  `A` is overwritten by L; returns false if A is not positive
+// definite.
 __device__ inline bool wave_chol_inv_t(double *A, double *S, int D, int lane) {
   bool ok = true;
   for (int k = 0; k < D; k++) {  // right-looking Cholesky, column k
@@ -1123,12 +1150,12 @@ __device__ inline bool wave_chol_inv_t(double *A, double *S, int D, int lane) {
     if (!(akk > 0.0)) ok = false;
     const double lkk = sqrt(akk);
     for (int i = k + lane; i < D; i += 64) A[i * D + k] = (i == k) ? lkk : A[i * D + k] / lkk;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __threadfence_block();  // (one wavefront; LDS or global)
     for (int idx = lane; idx < (D - k - 1) * (D - k - 1); idx += 64) {
       const int i = k + 1 + idx / (D - k - 1), j = k + 1 + idx % (D - k - 1);
       if (j <= i) A[i * D + j] = A[i * D + j] - A[i * D + k] * A[j * D + k];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __threadfence_block();  // (one wavefront; LDS or global)
   }
   // X = L^-1 by forward substitution, one column per lane; S = X^T
   for (int col = lane; col < D; col += 64) {
@@ -1138,21 +1165,24 @@ __device__ inline bool wave_chol_inv_t(double *A, double *S, int D, int lane) {
       S[col * D + i] = (i < col) ? 0.0 : v / A[i * D + i];
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __threadfence_block();  // (one wavefront; LDS or global)
   return ok;
 }
 // sqrt_mass[c] = chol(imm[c])^-T for every chain; *err = 1 if a matrix is not positive definite
 __global__ __launch_bounds__(64) void k_chol_inv_pc(const double *imm, double *sqrt_mass, long long C, int D,
-                                                     int *err) {
-  extern __shared__ __attribute__((aligned(16))) double pc_lds[];  // A [D*D], S [D*D]
+                                                     int *err, double *work) {
+  extern __shared__ __attribute__((aligned(16))) double pc_lds[];  // D <= 64: A [D*D], S [D*D]
   const int lane = threadIdx.x;
   const long long c = blockIdx.x;
-  double *A = pc_lds, *S = pc_lds + D * D;
+  const bool in_lds = D <= AEHMC_PC_LDS_MAX_D;
+  double *A = in_lds ? pc_lds : work + (size_t)c * D * D;
+  double *S = in_lds ? pc_lds + D * D : sqrt_mass + (size_t)c * D * D;
   for (int i = lane; i < D * D; i += 64) A[i] = imm[(size_t)c * D * D + i];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __threadfence_block();
   const bool ok = wave_chol_inv_t(A, S, D, lane);
   // S holds X^T laid out as S[col][i] = X[i][col] = (L^-1)[i][col] = (L^-T)[col][i]: row-major L^-T
-  for (int i = lane; i < D * D; i += 64) sqrt_mass[(size_t)c * D * D + i] = S[i];
+  if (in_lds)
+    for (int i = lane; i < D * D; i += 64) sqrt_mass[(size_t)c * D * D + i] = S[i];
   if (!ok && lane == 0) *err = 1;
 }
 
@@ -1211,11 +1241,11 @@ __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
   double step_size = exp(x);
   long long n = a.s.wc_n[c];
   if (a.s.full) {
-    // full covariance (algorithms.py:187-197 with np.outer, mass_matrix.py:83-118); D <= 64:
-    // delta / updated delta of the whole position sit in LDS, the D x D arrays in HBM
-    __shared__ double fl_delta[4][AEHMC_PC_DENSE_MAX_D], fl_ud[4][AEHMC_PC_DENSE_MAX_D];
-    extern __shared__ __attribute__((aligned(16))) double ad_lds[];  // [4 waves][2 D*D] at a window end
-    const int wv = threadIdx.x >> 6;
+    // full covariance (algorithms.py:187-197 with np.outer, mass_matrix.py:83-118), one wavefront per
+    // workgroup: delta / updated delta of the whole position sit in LDS, the D x D arrays in HBM; the
+    // window-end factorisation runs in LDS (D <= 64) or in a.s.work / sqrt_mass
+    extern __shared__ __attribute__((aligned(16))) double ad_lds[];  // delta [D], ud [D], then A, S [D*D] (D <= 64)
+    double *const fl_delta = ad_lds, *const fl_ud = ad_lds + a.D;
     const long long DD = a.D * a.D;
     if (a.stage != 0) {
       n += 1;
@@ -1225,16 +1255,26 @@ __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
         const double delta = v - mean;
         mean = mean + delta / (double)n;
         a.s.wc_mean[c * a.D + i] = mean;
-        fl_delta[wv][i] = delta;
-        fl_ud[wv][i] = v - mean;
+        fl_delta[i] = delta;
+        fl_ud[i] = v - mean;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      for (long long idx = lane; idx < DD; idx += 64)
-        a.s.wc_m2[c * DD + idx] = a.s.wc_m2[c * DD + idx] + fl_ud[wv][idx / a.D] * fl_delta[wv][idx % a.D];
+      __threadfence_block();
+      if (a.D <= AEHMC_PC_LDS_MAX_D) {
+        for (long long idx = lane; idx < DD; idx += 64)
+          a.s.wc_m2[c * DD + idx] = a.s.wc_m2[c * DD + idx] + fl_ud[idx / a.D] * fl_delta[idx % a.D];
+      } else {  // row by row: coalesced, no index divisions
+        for (long long i = 0; i < a.D; i++) {
+          const double ud = fl_ud[i];
+          double *m2 = a.s.wc_m2 + c * DD + i * a.D;
+          for (long long j = lane; j < a.D; j += 64) m2[j] = m2[j] + ud * fl_delta[j];
+        }
+      }
     }
     if (a.window_end) {
       const double nn = (double)n;
-      double *A = ad_lds + (size_t)wv * 2 * DD, *S = A + DD;
+      const bool in_lds = a.D <= AEHMC_PC_LDS_MAX_D;
+      double *A = in_lds ? ad_lds + 2 * a.D : a.s.work + c * DD;
+      double *S = in_lds ? A + DD : a.s.sqrt_mass + c * DD;
       for (long long idx = lane; idx < DD; idx += 64) {
         const double cov = a.s.wc_m2[c * DD + idx] / (double)(n - 1);
         double imm = (nn / (nn + 5)) * cov;
@@ -1244,9 +1284,10 @@ __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
         a.s.wc_m2[c * DD + idx] = 0.0;
       }
       for (long long i = lane; i < a.D; i += 64) a.s.wc_mean[c * a.D + i] = 0.0;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __threadfence_block();
       wave_chol_inv_t(A, S, (int)a.D, lane);  // a non-PD estimate leaves NaNs, as the reference's cholesky would
-      for (long long idx = lane; idx < DD; idx += 64) a.s.sqrt_mass[c * DD + idx] = S[idx];
+      if (in_lds)
+        for (long long idx = lane; idx < DD; idx += 64) a.s.sqrt_mass[c * DD + idx] = S[idx];
       n = 0;
       mu = step_size;
       step = 1;

@@ -313,12 +313,19 @@ extern "C" int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D,
   if (D > AEHMC_PC_DENSE_MAX_D)
     FAIL("per-chain dense mass matrices are supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
   ctx->h_err[1] = 0;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_inv_pc),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * D * D * sizeof(double))));
-  hipLaunchKernelGGL(k_chol_inv_pc, dim3((unsigned)C), dim3(64), (size_t)2 * D * D * sizeof(double),
-                     (hipStream_t)stream, imm, sqrt_mass, (long long)C, (int)D, ctx->d_err + 1);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  const bool in_lds = D <= AEHMC_PC_LDS_MAX_D;
+  const size_t dyn = in_lds ? (size_t)2 * D * D * sizeof(double) : 0;
+  double *work = nullptr;
+  if (!in_lds) HIPCHK(hipMalloc((void **)&work, (size_t)C * D * D * sizeof(double)));
+  if (dyn)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_inv_pc),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+  hipLaunchKernelGGL(k_chol_inv_pc, dim3((unsigned)C), dim3(64), dyn, (hipStream_t)stream, imm, sqrt_mass,
+                     (long long)C, (int)D, ctx->d_err + 1, work);
+  const hipError_t le = hipGetLastError(), se = hipStreamSynchronize((hipStream_t)stream);
+  if (work) (void)hipFree(work);
+  HIPCHK(le);
+  HIPCHK(se);
   if (ctx->h_err[1]) {
     ctx->h_err[1] = 0;
     FAIL("inverse mass matrix of some chain is not positive definite");
@@ -367,10 +374,11 @@ extern "C" int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t 
   if (!p_accept || !position) FAIL("adaptation: acceptance_probability / position missing");
   a.stage = stage; a.window_end = is_window_end; a.last = is_last; a.target = target;
   a.p_accept = p_accept; a.position = position;
-  if (state->full) {  // one wavefront per workgroup: the window-end factorisation holds two D x D matrices in LDS
+  if (state->full) {  // one wavefront per workgroup: delta vectors (and, D <= 64, the window-end factorisation) in LDS
     if (D > AEHMC_PC_DENSE_MAX_D)
       FAIL("full mass-matrix adaptation is supported up to D = " + std::to_string(AEHMC_PC_DENSE_MAX_D));
-    const size_t dyn = (size_t)2 * D * D * sizeof(double);  // up to 64 KB next to 4 KB of static LDS
+    if (D > AEHMC_PC_LDS_MAX_D && !state->work) FAIL("full mass-matrix adaptation with D > 64 needs state->work [C,D,D]");
+    const size_t dyn = (size_t)(2 * D + (D <= AEHMC_PC_LDS_MAX_D ? 2 * D * D : 0)) * sizeof(double);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_adapt_update),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     hipLaunchKernelGGL(k_adapt_update, dim3((unsigned)C), dim3(64), dyn, (hipStream_t)stream, a);
@@ -564,8 +572,12 @@ static int metric_mul(aehmc_ctx *ctx, int64_t C, const double *X, const double *
                       hipStream_t st, const int *row_idx = nullptr, const int *n_rows = nullptr) {
   const int64_t D = ctx->met.D;
   if (ctx->met.per_chain) {
-    hipLaunchKernelGGL(k_matvec_pc, chain_grid(C), dim3(256), 0, st, mat, X, out, (long long)C, (long long)D,
-                       row_idx, n_rows);
+    if (D <= AEHMC_PC_LDS_MAX_D)
+      hipLaunchKernelGGL(k_matvec_pc, chain_grid(C), dim3(256), 0, st, mat, X, out, (long long)C, (long long)D,
+                         row_idx, n_rows);
+    else
+      hipLaunchKernelGGL(k_matvec_pc_rows, dim3((unsigned)((D + 63) / 64), (unsigned)C), dim3(256), 0, st, mat, X,
+                         out, (long long)C, (long long)D, row_idx, n_rows);
     HIPCHK(hipGetLastError());
     return 0;
   }

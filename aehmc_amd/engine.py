@@ -352,6 +352,8 @@ class Engine:
                   wc_m2=torch.empty(mat, dtype=f64, device=dev), wc_n=torch.empty(C, dtype=i64, device=dev),
                   step_size=torch.empty(C, dtype=f64, device=dev), imm=torch.empty(mat, dtype=f64, device=dev),
                   sqrt_mass=torch.empty(mat, dtype=f64, device=dev))
+        if full and D > 64:  # scratch of the window-end factorisation (LDS holds it up to D = 64)
+            st["work"] = torch.empty(mat, dtype=f64, device=dev)
         return st, _lib.CAdaptState(full=int(bool(full)), **{k: v.data_ptr() for k, v in st.items()})
 
     def adapt_init(self, C, D, initial_step_size, cstate):

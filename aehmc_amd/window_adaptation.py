@@ -1,5 +1,5 @@
 """Stan-style window adaptation of the step size and the inverse mass matrix (diagonal, or
-dense per chain with ``is_mass_matrix_full`` for D <= 64), one adaptation per chain (reference: aehmc/window_adaptation.py, step_size.py,
+dense per chain with ``is_mass_matrix_full``), one adaptation per chain (reference: aehmc/window_adaptation.py, step_size.py,
 mass_matrix.py, algorithms.py).  The schedule is host logic; the per-chain dual-averaging /
 Welford updates run in one HIP kernel per warm-up step (`aehmc_adapt_update`)."""
 from __future__ import annotations
@@ -51,9 +51,9 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     C, D = layout.C, layout.D
     scalar_position = (len(layout.user_shape) - (1 if batched else 0)) == 0
     full = bool(is_mass_matrix_full) and not scalar_position  # mass_matrix.py:54-57: a scalar stays a scalar
-    if full and D > 64:
-        raise NotImplementedError("is_mass_matrix_full keeps one dense matrix per chain and is supported "
-                                  "up to D = 64; use the diagonal adaptation for larger models")
+    if full and D > 2048:  # C x D x D doubles per array: memory is the real bound
+        raise ValueError("is_mass_matrix_full keeps one dense D x D matrix per chain (as the reference does) and "
+                         "is supported up to D = 2048")
     st, cst = eng.adapt_alloc(C, D, full)
     eng.adapt_init(C, D, float(initial_step_size), cst)
     schedule = build_schedule(int(num_steps))

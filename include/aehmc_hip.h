@@ -66,7 +66,7 @@ typedef struct {
 typedef struct {
   int32_t ndim;
   int32_t per_chain;       /* 1: imm / sqrt_mass are [C,1] (ndim 0), [C,D] (ndim 1) or [C,D,D]
-                              (ndim 2, D <= 64), one per chain -- what per-chain window
+                              (ndim 2, D <= 2048), one per chain -- what per-chain window
                               adaptation produces; sqrt_mass must be given
                               (aehmc_metric_sqrt_per_chain computes the dense one); 0: shared */
   int64_t D;
@@ -89,7 +89,10 @@ typedef struct {
   double *step_size;                     /* [C] */
   double *imm, *sqrt_mass;               /* [C,D] */
   int32_t full;                          /* 1: is_mass_matrix_full -- wc_m2, imm and sqrt_mass are
-                                            [C,D,D] (full covariance per chain, D <= 64) */
+                                            [C,D,D] (full covariance per chain, D <= 2048) */
+  int32_t reserved;
+  double *work;                          /* full && D > 64: [C,D,D] scratch of the window-end
+                                            factorisation (smaller D: LDS; may be NULL) */
 } aehmc_adapt_state;
 
 /* per-transition outputs == trajectory.py:379-384 Diagnostics (+ n_leapfrog) */
@@ -195,7 +198,8 @@ int aehmc_nuts_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size
                       double *acceptance_history, int32_t *divergence_history,
                       int64_t *n_leapfrog_total, void *stream);
 
-/* sqrt_mass[c] = chol(imm[c])^-T (metrics.py:56-58) for C dense D x D matrices, D <= 64 */
+/* sqrt_mass[c] = chol(imm[c])^-T (metrics.py:56-58) for C dense D x D matrices, D <= 2048 (one
+ * wavefront per matrix: in LDS up to D = 64, in a temporary device buffer above) */
 int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D, const double *imm, double *sqrt_mass,
                                 void *stream);
 
