@@ -271,21 +271,29 @@ def main():
                     "kernel": "gemm_nt_f64_streamk_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
                     "avg_rows_per_launch": flops / (2.0 * D * D), "gemm_share_of_step_time": kern_ms / 1e3 / elapsed}
     else:
-        # fused HMC kernel: algorithmic bytes = SURVEY.md 8d streaming figure 48*D B per leapfrog per chain
-        bytes_per_launch = 48.0 * D * C * 32 * 100
+        # fused HMC kernel (100 transitions per launch, state in registers): the HBM traffic is the I/O of a
+        # launch, counted by rocprofv3; the kernel is bound by fp64 VALU issue (profiles/r2/c2_pmc_summary.json)
         avg_s = kern_ms / 1e3 / max(kern_n, 1)
-        achieved = bytes_per_launch / avg_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1", "c2_pmc_summary.json")
+        traffic, valu = None, None
+        pmc = os.path.join(ROOT, "profiles", "r2", "c2_pmc_summary.json")
         if os.path.exists(pmc) and D == 100 and C == 4096:  # measured offline (separate rocprofv3 --pmc passes)
-            traffic = json.load(open(pmc))["hmc_fused_summary"]["traffic_bytes_per_launch_avg"]
+            pj = json.load(open(pmc))
+            traffic = pj["derived"]["hbm_bytes_per_launch"]
+            ipt = pj["derived"]["valu_instructions_per_wave_per_transition"]
+            ceil = pj["derived"]["valu_issue_ceiling_leapfrogs_per_s_at_this_instruction_count"]
+            valu = {"instructions_per_wave_per_transition": ipt,
+                    "leapfrog_fp64_instructions_per_transition": pj["derived"]["leapfrog_fp64_instructions_per_transition"],
+                    "issue_ceiling_leapfrogs_per_s": ceil, "frac_of_issue_ceiling": value / ceil,
+                    "busy_fraction_rocprof": pj["derived"]["valu_busy_fraction_of_kernel_time_at_2.4GHz"],
+                    "note": "one wavefront per chain, 4 per SIMD; a 64-lane fp64 VALU instruction occupies its 16-lane SIMD "
+                            "for 4 cycles; ceiling = 1024 SIMDs x 2.4 GHz / (4 waves x 4 cycles x instructions per transition)"}
+        achieved = (traffic / avg_s / 1e9) if traffic else 40.0 * D * C * 100 / avg_s / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "kernel": "k_hmc_fused",
-                    "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
-                    "achieved_io_only_GBs": 40.0 * D * C * 100 / avg_s / 1e9,
-                    "note": "achieved uses SURVEY 8d's streaming figure (48*D B per leapfrog); the state is "
-                            "register-resident for all L steps, so frac > 1 means on-chip reuse; "
-                            "achieved_io_only_GBs counts what the kernel really moves (40*D B per transition)"}
+                    "avg_launch_ms": avg_s * 1e3, "launches": kern_n, "valu": valu,
+                    "note": "achieved = counted HBM bytes per launch (q, dU/dq in and out once, momentum out, histories) / "
+                            "launch time: the chain state stays in VGPRs for 100 transitions x 32 leapfrogs, so HBM is idle "
+                            "and the bound that matters is fp64 VALU issue -- see `valu`"}
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -398,18 +406,21 @@ def cpu_baseline(config, D, q0, target, imm, eps):
     if config == "c3":
         otgt = co.Target(co.T_DENSE_MVN, D, mu=np.zeros(D), prec=target.precision.cpu().numpy())
         metric = co.Metric(imm.cpu().numpy(), D)
-        max_exp = 3  # bounded: 2 + 3 + 5 = 10 leapfrogs per chain (a full-depth tree is ~57: minutes on a CPU)
-        n_all = min(cores, q0.shape[0])
-        what = (f"NUTS transition truncated at max_num_expansions={max_exp} (10 leapfrogs/chain), same D / target / "
+        max_exp = 2  # bounded: 2 + 3 = 5 leapfrogs per chain (a full-depth tree is ~57: minutes on a CPU)
+        # every mat-vec streams an 800 MB matrix: the all-cores leg is DRAM-bound well below the core count,
+        # so 64 chains (= threads that get work) saturate it within the time budget
+        n_all = min(cores, 64, q0.shape[0])
+        what = (f"NUTS transition truncated at max_num_expansions={max_exp} (5 leapfrogs/chain), same D / target / "
                 f"dense metric as the GPU run")
     else:
         otgt, metric = co.Target(co.T_ISO_GAUSSIAN, D), co.Metric(np.ones(D), D)
         reps, n_all = 100, min(4 * cores, q0.shape[0])
         what = f"{reps} HMC transitions (L=32) per chain"
     nl1, dt1 = run(1 if config == "c3" else 8, 1)
-    nla, dta = run(n_all, cores)
-    return {"value": nla / dta, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_all} chains x {what}, {cores} OpenMP threads over chains ({nla} leapfrogs, {dta:.1f} s)",
+    used = min(cores, n_all)  # threads that get a chain
+    nla, dta = run(n_all, used)
+    return {"value": nla / dta, "unit": "leapfrog-steps/s", "cores": used, "kind": "port",
+            "sample": f"{n_all} chains x {what}, {used} OpenMP threads over chains ({nla} leapfrogs, {dta:.1f} s)",
             "single_thread": {"value": nl1 / dt1, "unit": "leapfrog-steps/s", "cores": 1,
                               "sample": f"{1 if config == 'c3' else 8} chain(s) x {what} ({nl1} leapfrogs, {dt1:.1f} s)"},
             "host_cpu_count": cores,
