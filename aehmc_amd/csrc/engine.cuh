@@ -121,6 +121,34 @@ __device__ __forceinline__ double np_logaddexp(double x, double y) {  // numpy n
   return tmp;
 }
 
+// The per-leapfrog scalars of dynamic_integration (proposals.py:96-99, 141-144): the acceptance
+// probability expit(w_new - w_sub) and the two running logaddexp's.  All inputs are wave-uniform
+// and the three results are independent given the new weight, so they are evaluated in three
+// LANES of the wave at once -- one vector exp and one vector log1p instead of three and two
+// scalar ones (the 64-wide redundant evaluation of the same scalar costs exactly as much as a
+// lane-varying one).  Each lane runs the very instruction sequence of np_logaddexp / the scalar
+// expression, so the results are the same bits.  Valid when one wavefront (or more) owns the chain.
+struct StepScalars {
+  double pa, sub_w, sub_slpa;
+};
+__device__ __forceinline__ StepScalars nuts_step_scalars(double sub_w, double np_w, double sub_slpa,
+                                                         double np_slpa, int lane) {
+  const double x = lane == 1 ? sub_w : sub_slpa, y = lane == 1 ? np_w : np_slpa;  // lanes 1, 2: logaddexp(x, y)
+  const double tmp = x - y;
+  const double earg = lane == 0 ? -(np_w - sub_w) : (tmp > 0 ? -tmp : tmp);
+  const double e = exp(earg);
+  const double l = log1p(e);
+  double la = (x == y) ? x + 0.693147180559945309417232121458176568 : (tmp > 0 ? x + l : (tmp <= 0 ? y + l : tmp));
+  double pa = 1.0 / (1.0 + e);
+  if (isnan(pa)) pa = 0.0;
+  const double r = lane == 0 ? pa : la;
+  StepScalars o;
+  o.pa = read_lane_f64(r, 0);
+  o.sub_w = read_lane_f64(r, 1);
+  o.sub_slpa = read_lane_f64(r, 2);
+  return o;
+}
+
 // coordinate-wise targets: contribution to U and dU/dq_i
 __device__ __forceinline__ void target_elem(const EngineArgs &a, long long i, double q,
                                             double &u, double &g) {
@@ -559,12 +587,11 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
     copy_cur_to_slot<MET_DENSE>(a, row, lane, ct.prop_slot ^ 1);
     put2(ct.U_slot, ct.prop_slot ^ 1, ct.U_cur);
   } else {
-    // progressive_uniform_sampling proposals.py:72-102
-    double pa = 1.0 / (1.0 + exp(-(np_w - ct.sub_w)));
-    if (isnan(pa)) pa = 0.0;
-    int acc = rng_bernoulli(rng.g[2], pa);
-    ct.sub_w = np_logaddexp(ct.sub_w, np_w);
-    ct.sub_slpa = np_logaddexp(ct.sub_slpa, np_slpa);
+    // progressive_uniform_sampling proposals.py:72-102 (+ proposals.py:141-144), three lanes at once
+    const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
+    int acc = rng_bernoulli(rng.g[2], sc.pa);
+    ct.sub_w = sc.sub_w;
+    ct.sub_slpa = sc.sub_slpa;
     if (acc) {
       ct.sub_E = E;
       if (!ct.phantom) {

@@ -325,11 +325,19 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
       ct.length = 1;
       take = true;
     } else {
-      double pa = 1.0 / (1.0 + exp(-(np_w - ct.sub_w)));  // proposals.py:96-99
-      if (isnan(pa)) pa = 0.0;
-      int acc = rng_bernoulli(rng.g[2], pa);
-      ct.sub_w = np_logaddexp(ct.sub_w, np_w);
-      ct.sub_slpa = np_logaddexp(ct.sub_slpa, np_slpa);
+      int acc;
+      if (TM::WAVE) {  // the wave owns one chain: three lanes evaluate the three transcendental chains at once
+        const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
+        acc = rng_bernoulli(rng.g[2], sc.pa);
+        ct.sub_w = sc.sub_w;
+        ct.sub_slpa = sc.sub_slpa;
+      } else {
+        double pa = 1.0 / (1.0 + exp(-(np_w - ct.sub_w)));  // proposals.py:96-99
+        if (isnan(pa)) pa = 0.0;
+        acc = rng_bernoulli(rng.g[2], pa);
+        ct.sub_w = np_logaddexp(ct.sub_w, np_w);
+        ct.sub_slpa = np_logaddexp(ct.sub_slpa, np_slpa);
+      }
       if (acc) {
         ct.sub_E = E;
         take = !ct.phantom;

@@ -358,11 +358,10 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
       ct.length = 1;
       take = true;
     } else {
-      double pa = 1.0 / (1.0 + exp(-(np_w - ct.sub_w)));  // proposals.py:96-99
-      if (isnan(pa)) pa = 0.0;
-      const int acc = rng_bernoulli(rng.g[2], pa);
-      ct.sub_w = np_logaddexp(ct.sub_w, np_w);
-      ct.sub_slpa = np_logaddexp(ct.sub_slpa, np_slpa);
+      const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);  // proposals.py:96-99, 141-144
+      const int acc = rng_bernoulli(rng.g[2], sc.pa);
+      ct.sub_w = sc.sub_w;
+      ct.sub_slpa = sc.sub_slpa;
       if (acc) take = !ct.phantom;
       ct.length += 1;
       AEHMC_TICK(3);  // per-chain scalars
