@@ -76,7 +76,7 @@ def gather_samples(x: torch.Tensor, dst: int = 0):
     elif dist.get_rank() == dst:
         out = torch.empty((w * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         parts = list(out.split(mx, dim=0))  # views: the shards land in place
-        dist.gather(x, parts, dst=dst)
+        dist.gather(x, parts, dst=dst)      # (RCCL: grouped point-to-point sends / receives)
     else:
         dist.gather(x, None, dst=dst)
         return None

@@ -24,13 +24,26 @@ def case(name, sampler, D, C, metric_kind, target_kind, eps, n_transitions, seed
     import zlib
     r = np.random.default_rng(zlib.crc32(name.encode()))
     mu, sigma = r.normal(size=D).round(6), (0.5 + r.random(D)).round(6)
+    prec = None
     if target_kind == "std_normal":
         otgt = co.Target(co.T_STD_NORMAL, D)
     elif target_kind == "iso":
         otgt = co.Target(co.T_ISO_GAUSSIAN, D)
+    elif target_kind == "dense":  # dense MVN: precision = symmetrised inverse of A A^T / D + I, rounded so that
+        A = r.normal(size=(D, D))  # the JSON holds exactly the matrix that was used
+        prec = np.linalg.inv(A @ A.T / D + np.eye(D))
+        prec = (0.5 * (prec + prec.T)).round(9)
+        otgt = co.Target(co.T_DENSE_MVN, D, mu=mu, prec=prec)
     else:
         otgt = co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
-    imm = np.float64(0.7) if metric_kind == "scalar" else (0.5 + r.random(D)).round(6)
+    if metric_kind == "scalar":
+        imm = np.float64(0.7)
+    elif metric_kind == "dense":
+        B = r.normal(size=(D, D))
+        imm = B @ B.T / D + np.eye(D)
+        imm = (0.5 * (imm + imm.T)).round(9)
+    else:
+        imm = (0.5 + r.random(D)).round(6)
     metric = co.Metric(imm, D)
     seeds = [seed0 + c for c in range(C)]
     q0 = r.normal(size=(C, D)).round(6)
@@ -50,6 +63,7 @@ def case(name, sampler, D, C, metric_kind, target_kind, eps, n_transitions, seed
                           is_turning=res.get("is_turning", np.zeros(C, bool)).astype(int).tolist()))
     return dict(name=name, sampler=sampler, D=D, C=C, metric_kind=metric_kind, target_kind=target_kind,
                 mu=mu.tolist(), sigma=sigma.tolist(), imm=np.atleast_1d(imm).tolist(), eps=eps, L=L,
+                prec=None if prec is None else prec.tolist(),
                 max_exp=max_exp, seeds=seeds, q0=q0.tolist(), steps=steps)
 
 
@@ -79,3 +93,17 @@ json.dump({"published": published, "derived": derived,
            "note": "derived vectors come from oracle/c (this repo), not from the reference"},
           open(out, "w"))
 print("wrote", out, os.path.getsize(out), "bytes")
+# v2 (round 2): the dense branch (dense inverse mass matrix and / or dense precision: no reference value
+# exists for it anywhere) and a chain wide enough for the workgroup-per-chain kernels
+derived2 = [
+    case("nuts_dense_metric_d40", "nuts", 40, 3, "dense", "diag", 0.2, 2, 60, max_exp=7),
+    case("nuts_dense_both_d40", "nuts", 40, 2, "dense", "dense", 0.2, 2, 70, max_exp=7),
+    case("hmc_dense_both_d40", "hmc", 40, 2, "dense", "dense", 0.15, 2, 80, L=11),
+    case("nuts_diag_d700", "nuts", 700, 2, "diag", "diag", 0.1, 2, 90, max_exp=8),
+    case("hmc_diag_d1300", "hmc", 1300, 2, "diag", "diag", 0.08, 1, 95, L=16),
+]
+out2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vectors_v2.json")
+json.dump({"derived": derived2,
+           "note": "derived vectors come from oracle/c (this repo), not from the reference; the dense branch is unpinned "
+                   "by the reference (no published value exists)"}, open(out2, "w"))
+print("wrote", out2, os.path.getsize(out2), "bytes")

@@ -8,13 +8,18 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = json.load(open(os.path.join(HERE, "golden", "vectors_v1.json")))
+FIX["derived"] = FIX["derived"] + json.load(open(os.path.join(HERE, "golden", "vectors_v2.json")))["derived"]
 
 
 def _oracle_run(case):
     from oracle import c_oracle as co
     D, C = case["D"], case["C"]
-    kind = {"std_normal": co.T_STD_NORMAL, "iso": co.T_ISO_GAUSSIAN, "diag": co.T_DIAG_GAUSSIAN}[case["target_kind"]]
-    otgt = co.Target(kind, D, mu=np.array(case["mu"]), sigma=np.array(case["sigma"]))
+    kind = {"std_normal": co.T_STD_NORMAL, "iso": co.T_ISO_GAUSSIAN, "diag": co.T_DIAG_GAUSSIAN,
+            "dense": co.T_DENSE_MVN}[case["target_kind"]]
+    if case["target_kind"] == "dense":
+        otgt = co.Target(kind, D, mu=np.array(case["mu"]), prec=np.array(case["prec"]))
+    else:
+        otgt = co.Target(kind, D, mu=np.array(case["mu"]), sigma=np.array(case["sigma"]))
     imm = np.float64(case["imm"][0]) if case["metric_kind"] == "scalar" else np.array(case["imm"])
     metric = co.Metric(imm, D)
     q, U, g = co.new_state(otgt, np.array(case["q0"]))
@@ -41,7 +46,10 @@ def test_hip_reproduces_fixtures(case):
     from aehmc_amd import RandomStream, hmc, nuts, targets
     D = case["D"]
     tgt = {"std_normal": targets.StdNormal, "iso": targets.IsoGaussian}.get(case["target_kind"])
-    tgt = tgt() if tgt else targets.DiagGaussian(np.array(case["mu"]), np.array(case["sigma"]))
+    if case["target_kind"] == "dense":
+        tgt = targets.DenseMVN(np.array(case["mu"]), np.array(case["prec"]))
+    else:
+        tgt = tgt() if tgt else targets.DiagGaussian(np.array(case["mu"]), np.array(case["sigma"]))
     imm = np.float64(case["imm"][0]) if case["metric_kind"] == "scalar" else np.array(case["imm"])
     mod = nuts if case["sampler"] == "nuts" else hmc
     srng = RandomStream(seeds=case["seeds"])
@@ -52,7 +60,7 @@ def test_hip_reproduces_fixtures(case):
         info, _ = kernel(state, case["eps"], imm) if mod is nuts else kernel(state, case["eps"], imm, case["L"])
         state = info.state._replace(momentum=None)
         np.testing.assert_allclose(info.state.position.cpu().numpy(), np.array(st["position"]),
-                                   rtol=1e-9, atol=1e-12)
+                                   rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(info.acceptance_probability.cpu().numpy(),
                                    st["acceptance_probability"], rtol=1e-9)
         assert info.n_leapfrog.cpu().tolist() == st["n_leapfrog"]
