@@ -302,7 +302,7 @@ def main():
     if args.config == "c3" and world == 1 and not args.no_secondary and D == 10_000:
         del state, info, kernel, target, imm, gathered
         torch.cuda.empty_cache()
-        secondary = bench_secondary(eng, device, max(args.steps, 3), 1)
+        secondary = bench_secondary(eng, device, max(args.steps, 3), 2)
 
     print(json.dumps({
         "metric": "leapfrog-steps/sec across all chains", "value": value, "unit": "leapfrog-steps/s",

@@ -405,14 +405,23 @@ def test_hmc_resident_large_d_matches_oracle(eng, D, C, tk):
         res = co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
         check_state(info, q, U, g, res, nuts=False)
         state = info.state._replace(momentum=None)
+    # multi-transition calls, two back to back, then a single step: the RNG streams continue
     samples, info2, acc, div = kernel.sample(state, eps, imm, L, 3)
     for t_ in range(3):
         res = co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
         np.testing.assert_allclose(samples[t_].cpu().numpy(), q, rtol=RTOL, atol=1e-12)
+    samples, info2, acc, div = kernel.sample(info2.state._replace(momentum=None), eps, imm, L, 4)
+    for t_ in range(4):
+        res = co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
+        np.testing.assert_allclose(samples[t_].cpu().numpy(), q, rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(acc[t_].cpu().numpy(), res["acceptance_probability"], rtol=RTOL)
+    info2, _ = kernel(info2.state._replace(momentum=None), eps, imm, L)
+    res = co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
+    check_state(info2, q, U, g, res, nuts=False)
     eng.set_option("fused_hmc", 0)  # lock-step path on the same seeds
     k2 = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
     s2 = hmc.new_state(dev(q0), tgt)
-    for _ in range(5):
+    for _ in range(10):
         i2, _ = k2(s2, eps, imm, L)
         s2 = i2.state._replace(momentum=None)
     eng.set_option("fused_hmc", 1)
