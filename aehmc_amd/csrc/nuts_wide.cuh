@@ -41,6 +41,7 @@
 #include <type_traits>
 
 #include "engine.cuh"
+#include "linreg_rows.cuh"  // dpp_xor1 / dpp_xor2
 
 namespace aehmc {
 
@@ -103,20 +104,22 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
 #define WA(ptr, r) ((ptr) + rowW)[EW(r)]
 #define UA(ptr, r) ((ptr) + rowU)[EC(r)]
 
-  // team sum of four values; every thread returns the same bits (SGPRs)
+  // team sum of four values; every thread returns the same bits (SGPRs).  Inside a wave the four
+  // values are reduced together: two "transpose" stages (lane bit b keeps one half of the values and
+  // receives the partner's other half) leave one register per lane, four butterfly stages finish it
+  // -- 7 cross-lane additions instead of 24; lane l then holds the wave total of value l & 3.
   auto sum4 = [&](double &x0, double &x1, double &x2, double &x3) {
-    x0 = wave_sum(x0);
-    x1 = wave_sum(x1);
-    x2 = wave_sum(x2);
-    x3 = wave_sum(x3);
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const double r0 = (b0 ? x1 : x0) + dpp_xor1(b0 ? x0 : x1);
+    const double r1 = (b0 ? x3 : x2) + dpp_xor1(b0 ? x2 : x3);
+    double x = (b1 ? r1 : r0) + dpp_xor2(b1 ? r0 : r1);
+    x += __shfl_xor(x, 4);
+    x += __shfl_xor(x, 8);
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
     double *buf = red[flip];
     flip ^= 1;  // double-buffered: the next reduction writes the other buffer
-    if (lane == 0) {
-      buf[4 * wave] = x0;
-      buf[4 * wave + 1] = x1;
-      buf[4 * wave + 2] = x2;
-      buf[4 * wave + 3] = x3;
-    }
+    if (lane < 4) buf[4 * wave + lane] = x;
     __syncthreads();
     double s0 = buf[0], s1 = buf[1], s2 = buf[2], s3 = buf[3];
 #pragma unroll
