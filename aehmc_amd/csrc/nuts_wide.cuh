@@ -257,6 +257,10 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     // ---- one pass: leapfrog + kinetic energy + momentum sum + checkpoint + first U-turn level ----
     double usum = 0.0, d_l = 0.0, d_r = 0.0;
     kd = 0.0;
+    if (step == 0) {  // the momentum sum of the sub-trajectory restarts: 0 + p' == p'
+#pragma unroll
+      for (int r = 0; r < R; r++) pb[r] = 0.0;
+    }
     auto pass = [&](auto fwd_tag) {
       constexpr bool FWD = decltype(fwd_tag)::value;
 #pragma unroll
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
             GSET(r, gg);
             p[r] = pp;
             const double v = x.im * pp;
-            const double s = (step == 0) ? pp : pb_old + pp;  // trajectory.py:278,243
+            const double s = pb_old + pp;  // trajectory.py:243 (the sum restarts from 0 at step 0, :278)
             pb[r] = s;
             usum += (ISO || ON(r)) ? uu : 0.0;  // (a slot past D adds the target's constant only)
             kd += v * pp;
@@ -301,10 +305,6 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
               const double rho = sub - (pp + pl) / 2;
               d_l += vl * rho;
               d_r += v * rho;
-            }
-            if (ck_store) {
-              ckp[EW(r)] = pp;
-              cks[EW(r)] = s;
             }
           }
         }
@@ -317,6 +317,15 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     };
     if (fwd) pass(std::true_type{});
     else pass(std::false_type{});
+    if (ck_store) {  // every fourth step: the checkpoint pair, straight from the registers
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (r < nslots) {
+          ckp[EW(r)] = p[r];
+          cks[EW(r)] = pb[r];
+        }
+      }
+    }
     if (even) ck_last = tmax;
     AEHMC_TICK(0);  // pass
     // fetched ahead, behind the reduction and the per-chain scalar work below: the first
