@@ -510,6 +510,39 @@ def test_nuts_resident_teams_match_oracle(eng, D, C):
     eng.set_option("resident_min_team", 0)
 
 
+@pytest.mark.parametrize("D,tk", [(600, "diag"), (2500, "iso"), (5000, "iso"), (9000, "std"), (8200, "diag")])
+def test_nuts_wide_deep_trees_match_oracle(D, tk):
+    """The workgroup-per-chain kernel on DEEP trees (step size 20x too small: 8-9 doublings, sub-trajectories
+    of up to 257 steps, U-turn checks over up to 8 checkpoint levels): everything the kernel does
+    differently from the literal algorithm is exercised at depth -- the first check level taken from
+    registers (incl. the stale step-0 indices of every later expansion), deeper levels prefetched or
+    fetched on demand, checkpoint pairs that are never read back not stored, trajectory ends parked
+    only on a change of direction, the initial state aliased instead of copied.  Every variant:
+    registers only (D = 600, 2500), q in LDS with imm beside it (5000, 9000), q and dU/dq in LDS
+    with streamed parameters (8200, diagonal-Gaussian target)."""
+    from aehmc_amd import RandomStream, nuts
+    r = np.random.default_rng(D)
+    tgt, otgt, imm = make_case("diag", tk, D, r)
+    C = 3
+    seeds = [40 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    eps = 0.012 / D ** 0.25
+    srng = RandomStream(seeds=seeds)
+    kernel = nuts.new_kernel(srng, tgt, max_num_expansions=9)
+    state = nuts.new_state(dev(q0), tgt)
+    rng, metric = co.site_states(seeds, 4), co.Metric(imm, D)
+    q, U, g = co.new_state(otgt, q0.copy())
+    deepest = 0
+    for _ in range(3):
+        info, updates = kernel(state, eps, imm)
+        res = co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=9)
+        check_state(info, q, U, g, res)
+        assert np.array_equal(updates[srng].cpu().numpy().view(np.uint64)[:, :, :2], rng[:, :, :2])
+        state = info.state._replace(momentum=None)
+        deepest = max(deepest, int(res["num_doublings"].max()))
+    assert deepest >= 8, deepest
+
+
 def test_nuts_fused_equals_lockstep_bitwise(eng):
     """The single-launch NUTS kernel (one wavefront loops a chain's whole tree) and the
     one-launch-per-leapfrog lock-step path share their device functions: same bits."""
