@@ -261,15 +261,17 @@ def main():
         avg_s = kern_ms / 1e3 / max(kern_n, 1)
         achieved = flops / avg_s / 1e12
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1", "c3_pmc_summary.json")
+        pmc = os.path.join(ROOT, "profiles", "r2", "c3_pmc_summary.json")
         if os.path.exists(pmc) and D == 10_000 and C == 4096:  # measured offline: rocprofv3 --pmc cannot run inside the bench
             traffic = json.load(open(pmc))["gemm_summary"]["traffic_bytes_per_launch_avg"]
-            traffic_src = "profiles/r1/c3_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
+            traffic_src = "profiles/r2/c3_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": (2.0 * flops / (2.0 * D * D) * D + D * D) * 8,
                     "kernel": "gemm_nt_f64_streamk_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
-                    "avg_rows_per_launch": flops / (2.0 * D * D), "gemm_share_of_step_time": kern_ms / 1e3 / elapsed}
+                    "avg_rows_per_launch": flops / (2.0 * D * D), "gemm_share_of_step_time": kern_ms / 1e3 / elapsed,
+                    "parity_note": "c3's arithmetic is the dense branch, which no reference value pins (SURVEY.md 8c): parity "
+                                   "is HIP == C restatement, checked at this depth in tests/test_gpu_configs.py"}
     else:
         # fused HMC kernel (100 transitions per launch, state in registers): the HBM traffic is the I/O of a
         # launch, counted by rocprofv3; the kernel is bound by fp64 VALU issue (profiles/r2/c2_pmc_summary.json)
