@@ -58,6 +58,8 @@ SYMBOLS = {
     "aehmc_nuts_step": (_I, [_P, _I64, _P, _D, _I64, _D, _P, _P, _P, ct.POINTER(CDiagnostics), _P]),
     "aehmc_nuts_sample": (_I, [_P, _I64, _P, _D, _I64, _D, _I64, _P, _P, _P, ct.POINTER(CDiagnostics),
                                _P, _P, _P, _P, _P]),
+    "aehmc_nuts_warmup": (_I, [_P, _I64, _P, _I64, _P, _P, _D, _I64, _D, _P, _P, _P, ct.POINTER(CDiagnostics),
+                               ct.POINTER(CAdaptState), _P]),
     "aehmc_leapfrog": (_I, [_P, _I64, _D, _I64, _P, _P, _P, _P, _P]),
     "aehmc_kinetic_energy": (_I, [_P, _I64, _P, _P, _P]),
     "aehmc_is_turning": (_I, [_P, _I64, _P, _P, _P, _P, _P]),

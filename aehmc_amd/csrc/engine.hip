@@ -824,6 +824,31 @@ extern "C" int aehmc_nuts_step(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double 
                   (hipStream_t)stream);
 }
 
+// window_adaptation.run (window_adaptation.py:17-116): the whole warm-up loop -- one NUTS transition
+// with the current per-chain parameters, then the adaptation update -- enqueued without returning
+// to the host language between steps.  The caller has bound the per-chain metric (state->imm /
+// state->sqrt_mass) and step sizes (state->step_size), which the update kernel rewrites in place.
+extern "C" int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t num_steps,
+                                 const int32_t *stage, const int32_t *is_window_end,
+                                 double target_acceptance_rate, int64_t max_num_expansions,
+                                 double divergence_threshold, double *q, double *U, double *g,
+                                 const aehmc_diagnostics *out, const aehmc_adapt_state *state, void *stream) {
+  if (!ctx || !out || !state || !stage || !is_window_end) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->has_tgt) FAIL("set_target and set_metric must be called first");
+  if (!ctx->eps_c || !ctx->met.per_chain) FAIL("warm-up needs per-chain step sizes and a per-chain metric bound to the adaptation state");
+  const int64_t D = ctx->tgt.D;
+  for (int64_t i = 0; i < num_steps; i++) {
+    if (int rc = nuts_run(ctx, C, rng, 0.0, max_num_expansions, divergence_threshold, q, U, g, out,
+                          (hipStream_t)stream))
+      return rc;
+    if (int rc = aehmc_adapt_update(ctx, C, D, stage[i], is_window_end[i], i == num_steps - 1,
+                                    target_acceptance_rate, out->acceptance_probability, q, state, stream))
+      return rc;
+  }
+  return 0;
+}
+
 extern "C" int aehmc_nuts_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
                                  int64_t max_num_expansions, double divergence_threshold,
                                  int64_t num_samples, double *q, double *U, double *g,

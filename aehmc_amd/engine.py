@@ -296,6 +296,23 @@ class Engine:
         out["n_leapfrog"] = total
         return out
 
+    def nuts_warmup(self, rng, schedule, target_accept, max_exp, thr, q, U, g, st, cstate, imm_param):
+        """The whole window-adaptation loop in one C-ABI call (no Python between warm-up steps)."""
+        C, D = q.shape
+        out, c = self._diag(C, D, True)
+        n = len(schedule)
+        stage = (ct.c_int32 * n)(*[int(s) for s, _ in schedule])
+        wend = (ct.c_int32 * n)(*[int(bool(e)) for _, e in schedule])
+        # bind the adaptation state's own arrays: the update kernel rewrites them in place
+        self.set_metric(imm_param, D)
+        self.ensure_workspace(C, max_exp)  # (after the metric: a dense one needs more work vectors)
+        self._keep["eps"] = st["step_size"]
+        self._check(self.lib.aehmc_set_step_sizes(self.ctx, st["step_size"].data_ptr(), C), "aehmc_set_step_sizes")
+        self._step_call(self.lib.aehmc_nuts_warmup, "aehmc_nuts_warmup", self.ctx, C, rng.data_ptr(), n, stage, wend,
+                        float(target_accept), int(max_exp), float(thr), q.data_ptr(), U.data_ptr(), g.data_ptr(),
+                        ct.byref(c), ct.byref(cstate), self.stream)
+        return out
+
     def leapfrog(self, eps, nsteps, q, p, U, g):
         C, D = q.shape
         self.ensure_workspace(C, 1)

@@ -58,4 +58,7 @@ def new_kernel(srng: RandomStream, logprob_fn, max_num_expansions: int = 10,
 
     step.sample = sample
     step.num_chains, step.batched = srng.num_chains, srng.batched
+    # what window_adaptation.run needs to drive the warm-up loop inside the engine
+    step._nuts = dict(srng=srng, rng_host=rng_host, holder=holder, logprob_fn=logprob_fn,
+                      max_num_expansions=int(max_num_expansions), divergence_threshold=float(divergence_threshold))
     return step

@@ -36,13 +36,18 @@ def build_schedule(num_steps: int, initial_buffer_size: int = 75, final_buffer_s
 
 
 def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matrix_full=False,
-        initial_step_size=1.0, target_acceptance_rate=0.80
+        initial_step_size=1.0, target_acceptance_rate=0.80, fused=True
         ) -> Tuple[IntegratorState, Tuple, Dict]:
     """Warm a (NUTS) kernel up for ``num_steps`` transitions (reference:
     aehmc/window_adaptation.py:17-116).  Returns ``(last_chain_state, (step_size,
     inverse_mass_matrix), updates)`` where the parameters are ``PerChain`` values -- one
     step size and one (diagonal or dense) inverse mass matrix per chain, exactly as running the
-    reference once per chain would produce -- to be passed back to ``kernel``."""
+    reference once per chain would produce -- to be passed back to ``kernel``.
+
+    With a NUTS kernel of this package the whole loop runs inside one C-ABI call
+    (``aehmc_nuts_warmup``: transition, adaptation update, transition, ... enqueued back to back);
+    ``fused=False`` -- and any other kernel -- takes the step-by-step loop below, which issues the
+    same kernels in the same order (identical results)."""
     eng = get_engine()
     pos = initial_state.position
     srng_chains = getattr(kernel, "num_chains", None)
@@ -61,7 +66,21 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     def imm_param():
         return PerChain(st["imm"].reshape(C) if scalar_position else st["imm"], st["sqrt_mass"])
 
-    state, updates = initial_state, {}
+    nk = getattr(kernel, "_nuts", None)
+    if fused and nk is not None and len(schedule) > 0:
+        from ._common import diagnostics, state_rows
+        from .engine import rng_to_device
+        if "rng" not in nk["holder"]:
+            nk["holder"]["rng"] = rng_to_device(nk["rng_host"], eng.device)
+        q, U, g = state_rows(initial_state, layout, eng.device)
+        eng.set_target(nk["logprob_fn"], D)
+        out = eng.nuts_warmup(nk["holder"]["rng"], schedule, float(target_acceptance_rate),
+                              nk["max_num_expansions"], nk["divergence_threshold"], q, U, g, st, cst, imm_param())
+        info = diagnostics(layout, q, U, g, out, True)
+        state, updates = info.state._replace(momentum=None), {nk["srng"]: nk["holder"]["rng"]}
+        schedule = []
+    else:
+        state, updates = initial_state, {}
     for i, (stage, window_end) in enumerate(schedule):
         info, updates = kernel(state, PerChain(st["step_size"]), imm_param())
         state = info.state._replace(momentum=None)

@@ -189,6 +189,17 @@ int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t stage, int3
                        const double *acceptance_probability, const double *position,
                        const aehmc_adapt_state *state, void *stream);
 
+/* window_adaptation.run (window_adaptation.py:17-116) for a NUTS kernel: num_steps x (one transition
+ * with the current per-chain parameters, then aehmc_adapt_update), enqueued in one call.  `stage` /
+ * `is_window_end` [num_steps] are HOST arrays from build_schedule.  Before the call the caller binds
+ * the per-chain metric to state->imm / state->sqrt_mass (aehmc_set_metric, per_chain = 1) and the step
+ * sizes to state->step_size (aehmc_set_step_sizes); the update kernel rewrites them in place.
+ * `out` receives the diagnostics of the last warm-up transition. */
+int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t num_steps, const int32_t *stage,
+                      const int32_t *is_window_end, double target_acceptance_rate,
+                      int64_t max_num_expansions, double divergence_threshold, double *q, double *U,
+                      double *g, const aehmc_diagnostics *out, const aehmc_adapt_state *state, void *stream);
+
 /* num_samples consecutive NUTS transitions per chain (the user-level scan of
  * tests/test_hmc.py:296-324); same optional outputs as aehmc_hmc_sample plus the per-chain
  * leapfrog total [C].  `out` describes the last transition. */

@@ -324,3 +324,25 @@ def test_window_adaptation_full_recovers_covariance():
     assert not div.any().item() and acc.mean().item() > 0.6
     emp = np.cov(samples.cpu().numpy().reshape(-1, D).T)
     assert (np.abs(emp - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))).max() < 0.25
+
+
+@pytest.mark.parametrize("full,D,C", [(False, 30, 7), (True, 6, 5), (False, 1, 9), (True, 80, 3)])
+def test_fused_warmup_equals_step_by_step(full, D, C):
+    """window_adaptation.run through aehmc_nuts_warmup (the whole loop in one C-ABI call) issues the same
+    kernels in the same order as the step-by-step Python loop: identical state, parameters and RNG."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    r = np.random.default_rng(D + C)
+    mu, sigma = r.normal(size=D), 0.5 + r.random(D)
+    tgt = targets.DiagGaussian(mu, sigma)
+    q0 = mu + sigma * r.normal(size=(C, D))
+    outs = []
+    for fused in (True, False):
+        srng = RandomStream(seeds=[300 + c for c in range(C)])
+        kernel = nuts.new_kernel(srng, tgt)
+        state = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+        state, (eps, imm), upd = window_adaptation.run(kernel, state, 130, is_mass_matrix_full=full, fused=fused)
+        info, upd = kernel(state, eps, imm)
+        outs.append((state.position.clone(), eps.value.clone(), imm.value.clone(), imm.sqrt_mass.clone(),
+                     info.state.position.clone(), upd[srng].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
