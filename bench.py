@@ -416,7 +416,10 @@ def cpu_baseline(config, D, q0, target, imm, eps):
                 f"dense metric as the GPU run")
     else:
         otgt, metric = co.Target(co.T_ISO_GAUSSIAN, D), co.Metric(np.ones(D), D)
-        reps, n_all = 100, min(4 * cores, q0.shape[0])
+        # (one oracle call = one transition of all chains: ~1e8 flop, so the fork / join of a 256-thread
+        #  team would dominate -- all chains of the config, at most 32 threads)
+        reps, n_all = 20, q0.shape[0]
+        cores = min(cores, 32)
         what = f"{reps} HMC transitions (L=32) per chain"
     nl1, dt1 = run(1 if config == "c3" else 8, 1)
     used = min(cores, n_all)  # threads that get a chain
