@@ -429,6 +429,35 @@ def test_hmc_resident_large_d_matches_oracle(eng, D, C, tk):
                                rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("D,tk", [(5000, "iso"), (10000, "std"), (8190, "iso")])
+def test_hmc_wide_many_chains_equal_small_call(eng, D, tk):
+    """More chains than CUs on the workgroup-per-chain HMC kernel (several rounds of workgroups per CU):
+    chains of a 700-chain call equal, bit for bit, the same chains (same seeds) run in a small call,
+    over two transitions of sample() -- results do not depend on what shares the launch."""
+    from aehmc_amd import RandomStream, hmc
+    r = np.random.default_rng(D)
+    tgt, otgt, imm = make_case("diag", tk, D, r)
+    C, L = 700, 6
+    seeds = [3000 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    eps = 0.2 / D ** 0.25
+    kernel = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
+    samples, info, acc, div = kernel.sample(hmc.new_state(dev(q0), tgt), eps, imm, L, 2)
+    sel = [0, 1, 255, 256, 257, 511, 512, 699]
+    k2 = hmc.new_kernel(RandomStream(seeds=[seeds[i] for i in sel]), tgt)
+    s2, i2, a2, d2 = k2.sample(hmc.new_state(dev(q0[sel]), tgt), eps, imm, L, 2)
+    assert torch.equal(samples[:, sel], s2) and torch.equal(acc[:, sel], a2)
+    assert torch.equal(info.state.momentum[sel], i2.state.momentum)
+    assert torch.equal(info.state.potential_energy[sel], i2.state.potential_energy)
+    # ... and the oracle for the first of them
+    metric, rng = co.Metric(imm, D), co.site_states(seeds[:2], 2)
+    q, U, g = co.new_state(otgt, q0[:2].copy())
+    for t_ in range(2):
+        co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
+        np.testing.assert_allclose(samples[t_, :2].cpu().numpy(), q, rtol=RTOL, atol=1e-12)
+    assert 0.3 < acc.mean().item() <= 1.0
+
+
 def test_hmc_fused_equals_lockstep_bitwise(eng):
     """The register-resident single-launch HMC kernel and the generic lock-step path run
     the same arithmetic in the same order."""
