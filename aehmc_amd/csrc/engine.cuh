@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "../../include/aehmc_hip.h"
+#include "linreg_rows.cuh"
 #include "rng.cuh"
 
 namespace aehmc {
@@ -146,6 +147,31 @@ __device__ __forceinline__ StepScalars nuts_step_scalars(double sub_w, double np
   o.pa = read_lane_f64(r, 0);
   o.sub_w = read_lane_f64(r, 1);
   o.sub_slpa = read_lane_f64(r, 2);
+  return o;
+}
+
+// The scalars at the end of a sub-trajectory (trajectory.py:537-608, proposals.py:105-174): the
+// acceptance statistic exp(slpa_sub), the biased-sampling ratio exp(w_sub - w_prop) and the two
+// logaddexp's that merge the sub-trajectory into the proposal, in four lanes at once.  `swap`
+// (a diverged or U-turned sub-trajectory) only changes the argument order of the slpa merge.
+struct ExpansionScalars {
+  double e_slpa, e_ratio, la_w, la_slpa;
+};
+__device__ __forceinline__ ExpansionScalars nuts_expansion_scalars(double sub_w, double prop_w, double sub_slpa,
+                                                                   double prop_slpa, bool swap, int lane) {
+  const double x = lane == 2 ? prop_w : (swap ? sub_slpa : prop_slpa);   // lanes 2, 3: logaddexp(x, y)
+  const double y = lane == 2 ? sub_w : (swap ? prop_slpa : sub_slpa);
+  const double tmp = x - y;
+  const double earg = lane == 0 ? sub_slpa : lane == 1 ? sub_w - prop_w : (tmp > 0 ? -tmp : tmp);
+  const double e = exp(earg);
+  const double l = log1p(e);
+  const double la = (x == y) ? x + 0.693147180559945309417232121458176568 : (tmp > 0 ? x + l : (tmp <= 0 ? y + l : tmp));
+  const double r = lane < 2 ? e : la;
+  ExpansionScalars o;
+  o.e_slpa = read_lane_f64(r, 0);
+  o.e_ratio = read_lane_f64(r, 1);
+  o.la_w = read_lane_f64(r, 2);
+  o.la_slpa = read_lane_f64(r, 3);
   return o;
 }
 
@@ -1009,20 +1035,12 @@ __global__ __launch_bounds__(256) void k_target_linreg(EngineArgs a, const doubl
 #pragma unroll
     for (int u = 0; u < 4; u++)
 #pragma unroll
-      for (int k = 0; k < LINREG_CPB; k++) {
-        const double r = ys[u] - xs[u] * w[k];
-        sxr[k] += xs[u] * r;
-        srr[k] += r * r;
-      }
+      for (int k = 0; k < LINREG_CPB; k++) lr_term(xs[u], ys[u], w[k], sxr[k], srr[k]);
   }
   for (; i < hi; i += 256) {
     const double x = a.X[i], yy = a.y[i];
 #pragma unroll
-    for (int k = 0; k < LINREG_CPB; k++) {
-      const double r = yy - x * w[k];
-      sxr[k] += x * r;
-      srr[k] += r * r;
-    }
+    for (int k = 0; k < LINREG_CPB; k++) lr_term(x, yy, w[k], sxr[k], srr[k]);
   }
 #pragma unroll
   for (int k = 0; k < LINREG_CPB; k++) {

@@ -13,6 +13,7 @@
 #include "gemm_f64.cuh"
 #include "hmc_fused.cuh"
 #include "hmc_linreg.cuh"
+#include "nuts_linreg.cuh"
 #include "nuts_resident.cuh"
 #include "nuts_wide.cuh"
 
@@ -179,6 +180,7 @@ extern "C" int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *t) {
       break;
     case AEHMC_T_LINREG:
       if (!t->X || !t->y || t->N <= 0 || t->D != 2) FAIL("linreg target needs X, y, N and D == 2");
+      if ((((uintptr_t)t->X) | ((uintptr_t)t->y)) & 15) FAIL("linreg target: X and y must be 16-byte aligned");
       break;
     default:
       FAIL("unknown target kind");
@@ -731,9 +733,13 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
   FAIL("new_state: target kind not implemented");
 }
 
+// One NUTS transition of every chain.  `multi` (optional): the caller wants multi->T transitions with
+// per-transition outputs; a kernel that runs them all in one launch does so and sets *multi_done,
+// otherwise ONE transition is run and the caller loops.
 static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
                     int64_t max_num_expansions, double divergence_threshold, double *q, double *U,
-                    double *g, const aehmc_diagnostics *out, hipStream_t st) {
+                    double *g, const aehmc_diagnostics *out, hipStream_t st,
+                    const NutsSampleArgs *multi = nullptr, bool *multi_done = nullptr) {
   if (max_num_expansions < 1 || max_num_expansions > 20) FAIL("max_num_expansions must be in [1, 20]");
   if (!out->acceptance_probability || !out->is_diverging) FAIL("diagnostics arrays missing");
   EngineArgs a;
@@ -747,11 +753,24 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   // 2048 chains (down to the single chain of the README example) all teams are resident at once
   // and one launch replaces one launch per leapfrog;
   // a few thousand chains of small D run faster in lock step.  The regression target always
-  // takes its workgroup-cooperative resident kernel.
+  // takes its workgroup-cooperative resident kernel (nuts_linreg.cuh), which also runs any number
+  // of consecutive transitions in one launch.
+  if (ctx->opt_resident_nuts && nuts_linreg_supported(a.tkind, a.met_ndim, a.D, max_num_expansions)) {
+    NutsSampleArgs m{};
+    m.T = 1;
+    if (multi) {
+      m = *multi;
+      *multi_done = true;
+    }
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    HIPCHK(launch_nuts_linreg(a, m, st));
+    return prof_end(ctx, st, p);
+  }
   const bool want_resident =
       ctx->opt_resident_nuts == 1 ||
       (ctx->opt_resident_nuts == 2 &&
-       (a.D > 256 || C >= 16384 || C <= 2048 || a.tkind == AEHMC_T_LINREG));
+       (a.D > 256 || C >= 16384 || C <= 2048));
   if (want_resident && (nuts_resident_supported(a.tkind, a.met_ndim, a.D) || nuts_wide_supported(a.tkind, a.met_ndim, a.D))) {
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
@@ -865,10 +884,18 @@ extern "C" int aehmc_nuts_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, doubl
     if (!out->n_leapfrog) FAIL("n_leapfrog_total needs out->n_leapfrog");
     HIPCHK(hipMemsetAsync(n_leapfrog_total, 0, C * sizeof(int64_t), st));
   }
+  NutsSampleArgs multi{};
+  multi.T = num_samples;
+  multi.samples = samples;
+  multi.acc_hist = acceptance_history;
+  multi.div_hist = divergence_history;
+  multi.nleap_total = (long long *)n_leapfrog_total;
   for (int64_t t = 0; t < num_samples; t++) {
+    bool all_done = false;
     if (int rc = nuts_run(ctx, C, rng, step_size, max_num_expansions, divergence_threshold, q, U, g,
-                          out, st))
+                          out, st, t == 0 ? &multi : nullptr, &all_done))
       return rc;
+    if (all_done) return 0;  // every transition ran inside that one launch
     if (samples)
       HIPCHK(hipMemcpyAsync(samples + (size_t)t * C * D, q, (size_t)C * D * sizeof(double),
                             hipMemcpyDeviceToDevice, st));

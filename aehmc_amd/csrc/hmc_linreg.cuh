@@ -99,7 +99,7 @@ __global__ __launch_bounds__(LR_BLOCK) void k_hmc_linreg(HmcFusedArgs a) {
       } else if (RES) {
         lr_rows_lds<K, LR_BLOCK>(dyn_lds, dyn_lds + a.N, a.N, tid, w4, sxr, srr);
       } else {
-        lr_rows_stream(a.X, a.y, a.N, dyn_lds, wave, lane, w4, sxr, srr);
+        lr_rows_direct(a.X, a.y, a.N, wave, lane, w4, sxr, srr);
       }
       if (K == 1) {
         const double s0 = wave_sum(sxr[0]), s1 = wave_sum(srr[0]);
@@ -175,7 +175,7 @@ inline bool hmc_linreg_supported(int tkind, int met_ndim, long long D) {
 template <bool RES, int K>
 inline hipError_t launch_hmc_linreg_k(const HmcFusedArgs &a, hipStream_t st) {
   const dim3 grid((unsigned)((a.C + 3) / 4)), block(LR_BLOCK);
-  const size_t dyn = RES ? (size_t)2 * a.N * sizeof(double) : LR_RING_BYTES;
+  const size_t dyn = RES ? (size_t)2 * a.N * sizeof(double) : 0;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_linreg<RES, K>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
   if (e != hipSuccess) return e;

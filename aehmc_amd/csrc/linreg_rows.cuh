@@ -8,73 +8,71 @@
 namespace aehmc {
 
 constexpr int LR_BLOCK = 512, LR_WAVES = LR_BLOCK / 64;  // 4 chain waves + 4 waves that only serve rows
-constexpr int LR_CHUNK = 256, LR_RING = 4;               // rows per chunk, chunks in flight per wave (128 KB of LDS)
-constexpr size_t LR_RING_BYTES = (size_t)LR_WAVES * LR_RING * LR_CHUNK * 2 * sizeof(double);
 
-// Rows streamed from L2 (any N): `dyn_lds` holds LR_RING_BYTES.
-__device__ __forceinline__ void lr_rows_stream(const double *X, const double *y, long long N, double *dyn_lds,
-                                         int wave, int lane, const double (&w4)[4], double (&sxr)[4],
-                                         double (&srr)[4]) {
-  // The rows stream through a wave-private LDS ring filled by LDS-DMA (global_load_lds, 16 B per
-  // lane: one instruction lands 128 consecutive doubles): a chunk is 256 rows of X and of y
-  // (4 x 1 KB), LR_RING chunks per wave are in flight, so a chunk has ~3 chunk-times (> 1 us) to
-  // arrive and no VGPR holds data in flight.  Lane l adds rows r0+l, r0+64+l, r0+128+l, r0+192+l of
-  // its wave's chunks in ascending order.
-  {
-    double *const ring = dyn_lds + (size_t)wave * (LR_RING * LR_CHUNK * 2);
-    const int nchunks = (int)(N / LR_CHUNK);                      // full chunks
-    const int nm = wave < nchunks ? (nchunks - wave + LR_WAVES - 1) / LR_WAVES : 0;  // this wave's
-    auto issue = [&](int m) {
-      const long long r0 = (long long)(wave + LR_WAVES * m) * LR_CHUNK;
-      double *slot = ring + (size_t)(m % LR_RING) * (LR_CHUNK * 2);
-  #pragma unroll
-      for (int h = 0; h < LR_CHUNK / 128; h++) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(X + r0 + 128 * h + 2 * lane),
-            (__attribute__((address_space(3))) void *)(slot + 128 * h), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void *)(y + r0 + 128 * h + 2 * lane),
-            (__attribute__((address_space(3))) void *)(slot + LR_CHUNK + 128 * h), 16, 0, 0);
-      }
-    };
-    constexpr int PER = 2 * (LR_CHUNK / 128);  // DMA instructions per chunk
-    for (int m = 0; m < LR_RING - 1 && m < nm; m++) issue(m);
-    for (int m = 0; m < nm; m++) {
-      if (m + LR_RING - 1 < nm) {
-        issue(m + LR_RING - 1);  // into the slot read in the previous step (its values are in registers)
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (((LR_RING - 1) * PER) & 0xF) | ((((LR_RING - 1) * PER) >> 4) << 14));
-      } else {
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the tail of the stream
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const double *slot = ring + (size_t)(m % LR_RING) * (LR_CHUNK * 2);
-      double xs[LR_CHUNK / 64], ys[LR_CHUNK / 64];
-  #pragma unroll
-      for (int u = 0; u < LR_CHUNK / 64; u++) {
-        xs[u] = slot[64 * u + lane];
-        ys[u] = slot[LR_CHUNK + 64 * u + lane];
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the slot may be refilled from here on
-      __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
-      for (int u = 0; u < LR_CHUNK / 64; u++)
-  #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const double rr = ys[u] - xs[u] * w4[k];
-          sxr[k] += xs[u] * rr;
-          srr[k] += rr * rr;
-        }
+// One row's terms for one chain: r = y - x w, sxr += x r, srr += r r as three fused multiply-adds
+// (one rounding per term where separate multiplies and adds have two; every regression kernel
+// uses this same form, so their sums differ only by the order of the rows).
+__device__ __forceinline__ void lr_term(double x, double yy, double w, double &sxr, double &srr) {
+  const double rr = __builtin_fma(-x, w, yy);
+  sxr = __builtin_fma(x, rr, sxr);
+  srr = __builtin_fma(rr, rr, srr);
+}
+
+// Rows streamed from L2 straight into registers (any N; X and y 16-byte aligned): a wavefront
+// takes blocks of 64 x LR_UN 16-byte pieces (two rows each) of X and of y, blocks w, w + 8, ... in
+// ascending order, the next block's loads in flight while the current one is used (two register
+// buffers).  Measured on MI355X (tools/debug/lr_stream_bench.hip, 256 workgroups x 1e5 rows x 4
+// chains): 16 us per sweep against 32 us for round 1's LDS-DMA ring with unfused arithmetic (23 us for these loads unfused); the
+// loads alone take 12 us (every CU pulls all rows through its 64 B/clk vector-memory path).
+// Adds this thread's rows to sxr[k] (sum(x r) of chain k) and srr[k] (sum(r^2)).
+constexpr int LR_UN = 4;
+// `between()` runs after the first block's loads have been issued (work that hides their latency).
+template <class Between>
+__device__ __forceinline__ void lr_rows_direct(const double *X, const double *y, long long N, int wave, int lane,
+                                               const double (&w4)[4], double (&sxr)[4], double (&srr)[4],
+                                               Between between) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2 *X2 = reinterpret_cast<const d2 *>(X), *y2 = reinterpret_cast<const d2 *>(y);
+  constexpr int BLK = 64 * LR_UN;  // pieces per block
+  const int nblk = (int)((N / 2) / BLK);
+  d2 xa[LR_UN], ya[LR_UN], xb[LR_UN], yb[LR_UN];
+  auto load = [&](int b, d2(&xx)[LR_UN], d2(&yy)[LR_UN]) {
+    const long long p0 = (long long)b * BLK + lane;
+#pragma unroll
+    for (int u = 0; u < LR_UN; u++) {
+      xx[u] = X2[p0 + 64 * u];
+      yy[u] = y2[p0 + 64 * u];
     }
-    for (long long i = (long long)nchunks * LR_CHUNK + threadIdx.x; i < N; i += LR_BLOCK) {  // last < 256 rows
-      const double x = X[i], yy = y[i];
-  #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const double rr = yy - x * w4[k];
-        sxr[k] += x * rr;
-        srr[k] += rr * rr;
-      }
+  };
+  auto use = [&](const d2(&xx)[LR_UN], const d2(&yy)[LR_UN]) {
+#pragma unroll
+    for (int u = 0; u < LR_UN; u++)
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) lr_term(xx[u][h], yy[u][h], w4[k], sxr[k], srr[k]);
+  };
+  int b = wave;
+  if (b < nblk) load(b, xa, ya);
+  between();
+  for (; b < nblk; b += 2 * LR_WAVES) {
+    const bool more = b + LR_WAVES < nblk;
+    if (more) load(b + LR_WAVES, xb, yb);
+    use(xa, ya);
+    if (more) {
+      if (b + 2 * LR_WAVES < nblk) load(b + 2 * LR_WAVES, xa, ya);
+      use(xb, yb);
     }
   }
+  for (long long i = (long long)nblk * BLK * 2 + wave * 64 + lane; i < N; i += LR_BLOCK) {  // last rows
+    const double x = X[i], yy = y[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) lr_term(x, yy, w4[k], sxr[k], srr[k]);
+  }
+}
+__device__ __forceinline__ void lr_rows_direct(const double *X, const double *y, long long N, int wave, int lane,
+                                               const double (&w4)[4], double (&sxr)[4], double (&srr)[4]) {
+  lr_rows_direct(X, y, N, wave, lane, w4, sxr, srr, [] {});
 }
 
 // Rows resident in LDS for the whole kernel (N * 16 bytes fit): lx = dyn_lds, ly = dyn_lds + N.
@@ -89,11 +87,7 @@ __device__ __forceinline__ void lr_rows_lds(const double *lx, const double *ly, 
   const long long nblk = N / (UN * LR_BLOCK);
   auto add = [&](double x, double yy) {
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-      const double rr = yy - x * w4[k];
-      sxr[k] += x * rr;
-      srr[k] += rr * rr;
-    }
+    for (int k = 0; k < K; k++) lr_term(x, yy, w4[k], sxr[k], srr[k]);
   };
   for (long long blk = 0; blk < nblk; blk++) {  // whole blocks: no bounds checks
     const long long i0 = blk * (UN * LR_BLOCK) + tid;

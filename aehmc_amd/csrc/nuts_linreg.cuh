@@ -1,0 +1,433 @@
+// NUTS on the linear-regression target (examples/LinearRegression.ipynb:126-166, q = [w, log n],
+// D = 2): any number of consecutive nuts.new_kernel(...)(state, eps, imm) transitions of every
+// chain in ONE launch.
+//
+// The target's gradient is a reduction over the N data rows, so a 512-thread workgroup owns FOUR
+// chains: per leapfrog all eight wavefronts sweep (X, y) once from L2 for the four chains together
+// (linreg_rows.cuh: direct 16-byte loads, double-buffered in registers, three fused multiply-adds
+// per row and chain; the first 10176 rows stay in the CU's LDS for the whole launch and never
+// touch the vector-memory path again), and wavefronts 0-3 each keep the tree of one chain.  D = 2, so the whole
+// transition state of a chain lives in registers of its wavefront -- element e of every vector in
+// lane e, the U-turn checkpoints (termination.py:12-16) of level i in lanes 2i, 2i+1 of two more
+// registers; the tree touches no memory at all.
+//
+// Chains are independent, so nothing is synchronised at transition boundaries: a chain whose tree
+// has ended draws its next momentum and goes on in the very next sweep while its neighbours are
+// still inside their trees (the sweep serves four chains whatever transition each is in).  With
+// the short, unequal trees of a warmed-up sampler (2 or 5 leapfrogs, rarely more) a launch of T
+// transitions costs about T x the MEAN tree length instead of T x the longest tree on the GPU.
+//
+// Diagonal / scalar metric (shared or per chain).  Arithmetic and its order are those of nuts_book
+// (engine.cuh) / k_nuts_resident; reference: nuts.py:56-153, trajectory.py:154-374,428-714,
+// termination.py:85-235, proposals.py:19-174, integrators.py:54-73, metrics.py:44-104.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "engine.cuh"
+#include "linreg_rows.cuh"
+
+namespace aehmc {
+
+// optional per-transition outputs of a launch that runs T transitions
+struct NutsSampleArgs {
+  long long T;
+  double *samples;         // [T][C][D] positions after each transition
+  double *acc_hist;        // [T][C]
+  int *div_hist;           // [T][C]
+  long long *nleap_total;  // [C] leapfrogs of all T transitions
+};
+
+#ifdef AEHMC_WIDE_TIMING  // developer build (make timing): cycles per phase of every chain wave -> a.ckp[c][8]
+#define LRN_TICK(k)                                                  \
+  do {                                                               \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime();  \
+    tacc[k] += now_ - tlast;                                         \
+    tlast = now_;                                                    \
+  } while (0)
+#else
+#define LRN_TICK(k) do { } while (0)
+#endif
+
+constexpr int NUTS_LINREG_MAX_EXP = 32;  // checkpoint levels that fit the lanes of a wavefront
+constexpr long long NUTS_LINREG_LDS_ROWS = 10176;  // rows kept in LDS (2 x 8 B each, next to ~1 KB static)
+
+__global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSampleArgs m) {
+  __shared__ double lr_w[4], lr_part[LR_WAVES][8];
+  __shared__ int lr_fin[4];
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+  const long long NL = a.N <= NUTS_LINREG_LDS_ROWS ? a.N : NUTS_LINREG_LDS_ROWS;  // rows [0, NL) live in LDS
+  for (long long i = threadIdx.x; i < NL; i += LR_BLOCK) {
+    dyn_lds[i] = a.X[i];
+    dyn_lds[NL + i] = a.y[i];
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long c = wave < 4 ? (long long)blockIdx.x * 4 + wave : a.C;
+  bool fin = c >= a.C;  // no chain (row-serving wavefront), or all T transitions done
+  const int e = lane & 1;
+  const bool el = lane < 2;  // this lane holds element `lane` of the chain's vectors
+  // sum over the two elements (other lanes hold nothing): wave-uniform, lane order 0, 1
+  auto sum2 = [](double x) { return read_lane_f64(x, 0) + read_lane_f64(x, 1); };
+
+  double q = 0.0, g = 0.0, p = 0.0, pb = 0.0;  // moving end + sub-trajectory momentum sum
+  double sq = 0.0, sg = 0.0, U_state = 0.0;    // the chain's state between transitions
+  double end_q[2], end_p[2], end_g[2], slot_q[2], slot_p[2], slot_g[2], psum = 0.0;
+  double ckp = 0.0, cks = 0.0;                 // checkpoints: level i, element e in lane 2 i + e
+  double imr = 1.0, smr = 0.0, eps = 0.0;
+  ChainRng rng = {};
+  ChainCtl ct = {};
+  long long t_idx = 0, nleap_sum = 0;
+#pragma unroll
+  for (int s = 0; s < 2; s++) end_q[s] = end_p[s] = end_g[s] = slot_q[s] = slot_p[s] = slot_g[s] = 0.0;
+
+  // ---- nuts.py:113-125: momentum (site #1, metrics.py:65-68), initial energy, fresh tree --------
+  auto begin_transition = [&]() {
+    const double z0 = rng_standard_normal(rng.g[0]), z1 = rng_standard_normal(rng.g[0]);
+    p = el ? smr * (lane == 0 ? z0 : z1) : 0.0;
+    q = sq;
+    g = sg;
+    pb = 0.0;
+    const double kd = sum2(el ? (imr * p) * p : 0.0);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      end_q[s] = q;
+      end_p[s] = p;
+      end_g[s] = g;
+    }
+    slot_q[0] = q;
+    slot_p[0] = p;
+    slot_g[0] = g;
+    psum = p;
+    const double U = U_state;
+    ct.H0 = U + 0.5 * kd;
+    ct.prop_E = ct.H0;
+    ct.prop_w = 0.0;
+    ct.prop_slpa = -INFINITY;
+    ct.sub_E = ct.sub_w = ct.sub_slpa = 0.0;
+    ct.U_cur = ct.U_end[0] = ct.U_end[1] = ct.U_slot[0] = ct.U_slot[1] = U;
+    ct.acc_prob = 0.0;
+    ct.nleap = 0;
+    ct.j = 0;
+    ct.length = 0;
+    ct.tmin = ct.tmax = 0;
+    ct.done = ct.phantom = 0;
+    ct.prop_slot = 0;
+    ct.ndoubl = ct.out_div = ct.out_turn = 0;
+    ct.dir = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
+    ct.step = 0;
+  };
+  if (!fin) {
+    const size_t imo = (size_t)c * a.imm_cs;
+    if (el) {
+      sq = a.q[c * 2 + lane];
+      sg = a.g[c * 2 + lane];
+      imr = a.imm[imo + (a.met_ndim == 0 ? 0 : lane)];
+      smr = a.sqrt_mass[imo + (a.met_ndim == 0 ? 0 : lane)];
+    }
+    U_state = a.U[c];
+    eps = a.eps_c ? a.eps_c[c] : a.eps;
+    rng = rng_load(a, c);
+    begin_transition();
+  }
+
+#ifdef AEHMC_WIDE_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  for (;;) {
+    // ---- one leapfrog of the moving end (integrators.py:54-73), first half ------------------
+    const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
+    const double b = 0.5 * step_size, aa = 1 * step_size;
+    if (!fin && el) {
+      const double pp = p - b * g;
+      q = q + aa * (imr * pp);
+      p = pp;
+    }
+    if (lane == 0 && wave < 4) {
+      lr_w[wave] = q;
+      lr_fin[wave] = fin;
+    }
+    // the row-independent part of U and dU/dq (exp, log) ahead of the sweep: off the critical path
+    double ww = 0.0, ell = 0.0, n = 1.0, n2 = 1.0, lp_wn = 0.0;
+    if (!fin) {
+      ww = read_lane_f64(q, 0);
+      ell = read_lane_f64(q, 1);
+      n = exp(ell);
+      n2 = n * n;
+      lp_wn = (-0.5 * ww * ww - AEHMC_LOG_SQRT_2PI) + (log(n) - n + ell);  // lp_w + lp_n of k_linreg_finish
+    }
+    __syncthreads();
+    LRN_TICK(0);  // first half, publish, barrier
+    if (lr_fin[0] & lr_fin[1] & lr_fin[2] & lr_fin[3]) break;
+    // sum(x r) and sum(r^2), r = y - x w, over all rows for the four chains of the workgroup
+    {
+      double w4[4], sxr[4], srr[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        w4[k] = lr_w[k];
+        sxr[k] = srr[k] = 0.0;
+      }
+      // (the LDS rows are added while the first streamed block is on its way)
+      lr_rows_direct(a.X + NL, a.y + NL, a.N - NL, wave, lane, w4, sxr, srr, [&] {
+        lr_rows_lds<4, LR_BLOCK>(dyn_lds, dyn_lds + NL, NL, (int)threadIdx.x, w4, sxr, srr);
+      });
+      const double v[8] = {sxr[0], sxr[1], sxr[2], sxr[3], srr[0], srr[1], srr[2], srr[3]};
+      const double tot = wave_sum8(v, lane);  // lane l: wave total of v[l & 7]
+      if (lane < 8) lr_part[wave][lane] = tot;
+    }
+    LRN_TICK(1);  // row sweep
+    __syncthreads();
+    LRN_TICK(2);  // barrier
+    if (fin) continue;
+    double s_xr = lr_part[0][wave], s_rr = lr_part[0][4 + wave];
+#pragma unroll
+    for (int w = 1; w < LR_WAVES; w++) {
+      s_xr += lr_part[w][wave];
+      s_rr += lr_part[w][4 + wave];
+    }
+    double kd;
+    {  // U and dU/dq as k_linreg_finish, second half of the leapfrog
+      const double N = (double)a.N;
+      const double lp_y = -0.5 * (s_rr / n2) - N * AEHMC_LOG_SQRT_2PI - N * ell;
+      const double gg = lane == 0 ? -(-ww + s_xr / n2) : -(2.0 - n - N + s_rr / n2);
+      ct.U_cur = -(lp_wn + lp_y);
+      double kl = 0.0;
+      if (el) {
+        const double pp = p - b * gg;
+        g = gg;
+        p = pp;
+        kl = (imr * pp) * pp;
+      }
+      kd = sum2(kl);
+    }
+    LRN_TICK(3);  // target finish, second half
+
+    // ---- dynamic_integration body (trajectory.py:195-305) -----------------------------------
+    const int step = ct.step;
+    if (!ct.phantom) ct.nleap += 1;
+    int tmin, tmax;
+    if (step == 0) {
+      tmin = ct.tmin;  // termination.py:109-113: stale indices of the previous sub-trajectory
+      tmax = ct.tmax;
+    } else {
+      const int n1 = __ffs(~step) - 1;
+      tmax = __popc(step >> 1);
+      tmin = tmax - n1 + 1;
+    }
+    if (el) pb = (step == 0) ? p : pb + p;
+    if ((step & 1) == 0) {  // termination.py:115-131
+      const double pe = __shfl(p, e), pbe = __shfl(pb, e);
+      if ((lane >> 1) == tmax) {
+        ckp = pe;
+        cks = pbe;
+      }
+    }
+    ct.tmin = tmin;
+    ct.tmax = tmax;
+    const double E = ct.U_cur + 0.5 * kd;  // proposals.py:19-62
+    double delta = ct.H0 - E;
+    if (isnan(delta)) delta = -INFINITY;
+    const bool div = fabs(delta) > a.thr;
+    const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
+    bool term = false, take = false;
+    if (step == 0) {
+      ct.sub_E = E;
+      ct.sub_w = np_w;
+      ct.sub_slpa = np_slpa;
+      ct.length = 1;
+      take = true;
+    } else {
+      // progressive_uniform_sampling proposals.py:72-102 (+ :141-144), three lanes at once
+      const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
+      const int acc = rng_bernoulli(rng.g[2], sc.pa);
+      ct.sub_w = sc.sub_w;
+      ct.sub_slpa = sc.sub_slpa;
+      if (acc) {
+        ct.sub_E = E;
+        take = !ct.phantom;
+      }
+      ct.length += 1;
+      if (tmax >= tmin) {  // termination.py:133-187
+        int idx = tmax;
+        bool crit = false;
+        for (;;) {
+          const double pl = __shfl(ckp, 2 * idx + e), ks = __shfl(cks, 2 * idx + e);
+          double dl = 0.0, dr = 0.0;
+          if (el) {
+            const double pr = p;
+            const double vl = imr * pl, vr = imr * pr;
+            const double sub = pb - ks + pl;
+            const double rho = sub - (pr + pl) / 2;
+            dl = vl * rho;
+            dr = vr * rho;
+          }
+          const double d_l = sum2(dl), d_r = sum2(dr);
+          crit = (d_l <= 0) | (d_r <= 0);
+          const bool reached = (idx - 1) < tmin;
+          idx -= 1;
+          if (crit || reached) break;
+        }
+        term = crit;
+      }
+    }
+    if (take) {  // sub-trajectory proposal <- moving end (copy on accept)
+      const int s = ct.prop_slot ^ 1;
+      if (s) {
+        slot_q[1] = q;
+        slot_p[1] = p;
+        slot_g[1] = g;
+      } else {
+        slot_q[0] = q;
+        slot_p[0] = p;
+        slot_g[0] = g;
+      }
+      put2(ct.U_slot, s, ct.U_cur);
+    }
+
+    // ---- sub-trajectory / expansion control (trajectory.py:336, 537-608) --------------------
+    bool finalize = false, fin_div = false, fin_term = false;
+    if (step == 0 && div && !ct.phantom) {
+      finalize = true;
+      fin_div = true;
+    } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
+      if (ct.phantom) ct.done = 1;
+      else {
+        finalize = true;
+        fin_div = div;
+        fin_term = term;
+      }
+    } else {
+      ct.step = step + 1;
+    }
+    if (finalize) {
+      const int dir = ct.dir, oth = 1 - dir;
+      double dl = 0.0, dr = 0.0;
+      {
+        const double pc = p, po = pick2(end_p, oth);
+        const double vc = imr * pc, vo = imr * po;
+        const double s = psum + pb;
+        psum = s;
+        const double pl = dir ? po : pc, pr = dir ? pc : po;
+        const double vl = dir ? vo : vc, vr = dir ? vc : vo;
+        const double rho = s - (pr + pl) / 2;
+        if (el) {
+          dl = vl * rho;
+          dr = vr * rho;
+        }
+        if (dir) {
+          end_q[1] = q;
+          end_p[1] = pc;
+          end_g[1] = g;
+        } else {
+          end_q[0] = q;
+          end_p[0] = pc;
+          end_g[0] = g;
+        }
+      }
+      const double d_l = sum2(dl), d_r = sum2(dr);
+      const bool turning = (d_l <= 0) | (d_r <= 0);
+      put2(ct.U_end, dir, ct.U_cur);
+      const ExpansionScalars xs =
+          nuts_expansion_scalars(ct.sub_w, ct.prop_w, ct.sub_slpa, ct.prop_slpa, fin_div || fin_term, lane);
+      ct.acc_prob = xs.e_slpa / (double)ct.length;
+      double pbias = xs.e_ratio;
+      if (pbias > 1.0) pbias = 1.0;
+      if (pbias < 0.0) pbias = 0.0;
+      const int acc_b = rng_bernoulli(rng.g[3], pbias);
+      ct.prop_slpa = xs.la_slpa;
+      if (!(fin_div || fin_term)) {
+        ct.prop_w = xs.la_w;
+        if (acc_b) {
+          ct.prop_slot ^= 1;
+          ct.prop_E = ct.sub_E;
+        }
+      }
+      ct.ndoubl = ct.j + 1;
+      ct.out_div = fin_div;
+      ct.out_turn = turning;
+      const bool end_transition = fin_div || turning || fin_term || (ct.j + 1 == a.max_exp);
+      if (end_transition) {
+        if (step == 0 && fin_div) {  // trajectory.py:336: the scan still runs (phantom)
+          ct.phantom = 1;
+          ct.step = 1;
+        } else {
+          ct.done = 1;
+        }
+      } else {
+        ct.j += 1;
+        const int go_right = rng_bernoulli(rng.g[1], 0.5);
+        ct.dir = go_right;
+        ct.step = 0;
+        if (go_right != dir) {  // continue from the other end
+          q = pick2(end_q, go_right);
+          p = pick2(end_p, go_right);
+          g = pick2(end_g, go_right);
+          ct.U_cur = pick2(ct.U_end, go_right);
+        }
+      }
+    }
+
+    LRN_TICK(4);  // tree
+    // ---- the transition is over (a phantom scan cannot change its outputs): hand the proposal
+    // to the chain's state, record it, start the next transition or leave --------------------
+    if (ct.done) {
+      const int s = ct.prop_slot;
+      sq = pick2(slot_q, s);
+      sg = pick2(slot_g, s);
+      const double sp = pick2(slot_p, s);
+      U_state = pick2(ct.U_slot, s);
+      nleap_sum += ct.nleap;
+      if (m.samples && el) m.samples[((size_t)t_idx * a.C + c) * 2 + lane] = sq;
+      if (lane == 0) {
+        if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
+        if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
+      }
+      t_idx += 1;
+      if (t_idx == m.T) {
+        fin = true;
+        if (el) {
+          a.q[c * 2 + lane] = sq;
+          a.g[c * 2 + lane] = sg;
+          if (a.out.momentum) a.out.momentum[c * 2 + lane] = sp;
+        }
+        if (lane == 0) {
+          a.U[c] = U_state;
+          a.out.acceptance_probability[c] = ct.acc_prob;
+          if (a.out.num_doublings) a.out.num_doublings[c] = ct.ndoubl;
+          if (a.out.is_turning) a.out.is_turning[c] = ct.out_turn;
+          a.out.is_diverging[c] = ct.out_div;
+          if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
+          if (m.nleap_total) m.nleap_total[c] = nleap_sum;
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (k < a.nsites) pcg_store(a.rng + ((size_t)c * a.nsites + k) * 4, rng.g[k]);
+        }
+      } else {
+        begin_transition();
+      }
+    }
+    LRN_TICK(5);  // transition end / begin
+  }
+#ifdef AEHMC_WIDE_TIMING
+  if (lane == 0 && c < a.C)
+    for (int k = 0; k < 8; k++) a.ckp[c * 8 + k] = (double)tacc[k];
+  if (lane == 0 && wave >= 4 && (long long)blockIdx.x * 4 + wave - 4 < a.C)  // the row-serving waves
+    for (int k = 0; k < 8; k++) a.cks[((long long)blockIdx.x * 4 + wave - 4) * 8 + k] = (double)tacc[k];
+#endif
+}
+
+inline bool nuts_linreg_supported(int tkind, int met_ndim, long long D, long long max_exp) {
+  return tkind == AEHMC_T_LINREG && met_ndim < 2 && D == 2 && max_exp <= NUTS_LINREG_MAX_EXP;
+}
+
+inline hipError_t launch_nuts_linreg(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
+  const unsigned grid = (unsigned)((a.C + 3) / 4);
+  const size_t dyn = (size_t)2 * (a.N <= NUTS_LINREG_LDS_ROWS ? a.N : NUTS_LINREG_LDS_ROWS) * sizeof(double);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_linreg),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_nuts_linreg, dim3(grid), dim3(LR_BLOCK), dyn, st, a, m);
+  return hipGetLastError();
+}
+
+}  // namespace aehmc

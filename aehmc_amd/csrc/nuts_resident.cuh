@@ -22,7 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "engine.cuh"
-#include "linreg_rows.cuh"
+#include "linreg_rows.cuh"  // wave_sum8 and friends
 
 namespace aehmc {
 
@@ -57,26 +57,14 @@ __device__ __forceinline__ void team_sum2(double &x, double &y) {
   y = wave_sum(y);
 }
 
-// LR: the linear-regression target (examples/LinearRegression.ipynb:126-166, D = 2).  Its
-// gradient is a reduction over the N data rows, so the four wavefront-teams of a workgroup
-// evaluate it together: every thread streams its rows of (X, y) once per leapfrog (from L2)
-// for all four chains, and each wave keeps the tree of its own chain.  A wave whose chain
-// has finished keeps serving rows until the whole workgroup is done.
-template <int T, int R, bool LR = false>
-__global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
+template <int T, int R>
+__global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
   using TM = Team<T>;
-  static_assert(!LR || (T == 64 && R == 1), "LR: one wavefront per chain, D = 2");
-  __shared__ double lr_w[4], lr_part[LR_WAVES][8];
-  __shared__ int lr_done[4];
-  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long c = LR && wave >= 4 ? a.C  // row-serving wave: no chain
-                      : TM::SUB       ? ((long long)blockIdx.x * 256 + threadIdx.x) / T
-                                      : (long long)blockIdx.x * 4 + wave;
+  const long long c = TM::SUB ? ((long long)blockIdx.x * 256 + threadIdx.x) / T : (long long)blockIdx.x * 4 + wave;
   const int t = TM::SUB ? (int)(threadIdx.x % T) : lane;
-  const bool ghost = c >= a.C;  // a whole team leaves together ...
-  if (ghost && !LR) return;     // ... except with LR, where it stays to serve data rows
+  if (c >= a.C) return;  // a whole team leaves together
   const size_t row = (size_t)c * a.D;
   const bool lead = t == 0;
 
@@ -102,16 +90,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
   ChainRng rng = {};
   ChainCtl ct = {};
   double kd = 0.0, zero = 0.0;
-  if (LR && ghost) {
-    ct.done = 1;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      ok[r] = false;
-      p[r] = pb[r] = 0.0;
-      QSET(r, 0.0);
-      GSET(r, 0.0);
-    }
-  } else {
+  {
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const long long i = (long long)t + (long long)T * r;
@@ -190,68 +169,15 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
     ct.step = 0;
   }
   }
-  const double eps = (LR && ghost) ? 0.0 : (a.eps_c ? a.eps_c[c] : a.eps);
+  const double eps = a.eps_c ? a.eps_c[c] : a.eps;
 
-  while (LR || !ct.done) {
+  while (!ct.done) {
     // ---- one leapfrog of the moving end, in registers (integrators.py:54-73) ---------
     const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
     const double b = 0.5 * step_size, aa = 1 * step_size;
     double usum = 0.0;
     kd = 0.0;
-    if (LR) {
-      if (!ct.done && ok[0]) {
-        const double pp = p[0] - b * GGET(0);
-        QSET(0, QGET(0) + aa * (IMM(0) * pp));
-        p[0] = pp;
-      }
-      if (lane == 0 && wave < 4) {
-        lr_w[wave] = QGET(0);
-        lr_done[wave] = ct.done;
-      }
-      __syncthreads();
-      if (lr_done[0] & lr_done[1] & lr_done[2] & lr_done[3]) break;
-      // sum(x r) and sum(r^2), r = y - x w, over all rows for the four chains of the workgroup
-      // (same per-thread order as k_target_linreg with one slice)
-      double w4[4], sxr[4], srr[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        w4[k] = lr_w[k];
-        sxr[k] = srr[k] = 0.0;
-      }
-      lr_rows_stream(a.X, a.y, a.N, dyn_lds, wave, lane, w4, sxr, srr);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        sxr[k] = wave_sum(sxr[k]);
-        srr[k] = wave_sum(srr[k]);
-        if (lane == 0) {
-          lr_part[wave][2 * k] = sxr[k];
-          lr_part[wave][2 * k + 1] = srr[k];
-        }
-      }
-      __syncthreads();
-      if (ct.done) continue;
-      double s_xr = lr_part[0][2 * wave], s_rr = lr_part[0][2 * wave + 1];
-#pragma unroll
-      for (int w = 1; w < LR_WAVES; w++) {
-        s_xr += lr_part[w][2 * wave];
-        s_rr += lr_part[w][2 * wave + 1];
-      }
-      // U and dU/dq as k_linreg_finish (q = [w, log n])
-      const double qv = QGET(0);
-      const double ww = __shfl(qv, 0), ell = __shfl(qv, 1), n = exp(ell), n2 = n * n, N = (double)a.N;
-      const double lp_w = -0.5 * ww * ww - AEHMC_LOG_SQRT_2PI;
-      const double lp_n = log(n) - n + ell;
-      const double lp_y = -0.5 * (s_rr / n2) - N * AEHMC_LOG_SQRT_2PI - N * ell;
-      const double gg = lane == 0 ? -(-ww + s_xr / n2) : -(2.0 - n - N + s_rr / n2);
-      ct.U_cur = -(lp_w + lp_n + lp_y);
-      if (ok[0]) {
-        const double pp = p[0] - b * gg;
-        GSET(0, gg);
-        p[0] = pp;
-        kd = (IMM(0) * pp) * pp;
-      }
-      team_sum2<T>(usum, kd);
-    } else {
+    {
       // (global operands -- imm when it is not in registers -- are fetched BR elements at a
       // time: one round trip per batch instead of one per element)
 #pragma unroll
@@ -511,7 +437,7 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
       }
     }
   }
-  if (lead && !(LR && ghost)) {
+  if (lead) {
     if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
     pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, rng.g[1]);
     pcg_store(a.rng + ((size_t)c * a.nsites + 2) * 4, rng.g[2]);
@@ -528,22 +454,15 @@ __global__ __launch_bounds__(LR ? LR_BLOCK : Team<T>::BLOCK) void k_nuts_residen
 }
 
 inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
-  if (tkind == AEHMC_T_LINREG) return met_ndim < 2 && D == 2;
   // teams of 1 .. 64 lanes up to D = 512; larger chains take one workgroup each (nuts_wide.cuh)
   return (tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN) &&
          met_ndim < 2 && D <= 512;
 }
 
-template <int T, int R, bool LR = false>
+template <int T, int R>
 inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
   const unsigned grid = Team<T>::SUB ? (unsigned)((a.C * T + 255) / 256) : (unsigned)((a.C + 3) / 4);
-  const size_t dyn = LR ? LR_RING_BYTES : 0;
-  if (LR) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<T, R, LR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL((k_nuts_resident<T, R, LR>), dim3(grid), dim3(LR ? LR_BLOCK : Team<T>::BLOCK), dyn, st, a);
+  hipLaunchKernelGGL((k_nuts_resident<T, R>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a);
   return hipGetLastError();
 }
 // Team size: the smallest team that holds the chain (<= 4 elements per lane below a wave,
@@ -552,7 +471,6 @@ inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
 // control state wave-uniform (SGPRs, scalar branches).
 inline hipError_t launch_nuts_resident(const EngineArgs &a, hipStream_t st, int force_min_team = 0) {
   const long long D = a.D, C = a.C;
-  if (a.tkind == AEHMC_T_LINREG) return launch_nuts_resident_tr<64, 1, true>(a, st);
   if (D > 512) return hipErrorInvalidValue;  // one workgroup per chain: nuts_wide.cuh
   const int tmin = D <= 4 ? 1 : D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64;
   int twant = 64;

@@ -116,6 +116,41 @@ def test_nuts_sample_equals_repeated_steps():
     assert torch.equal(info.n_leapfrog, total) and torch.equal(info.state.position, i2.state.position)
 
 
+def test_regression_nuts_sample_equals_repeated_steps(regression_data):
+    """The regression kernel runs all N transitions of a sample() call in ONE launch, each chain
+    starting its next transition as soon as its own tree has ended (nuts_linreg.cuh): per-transition
+    positions, acceptance, divergence flags, the leapfrog total, the final state and the RNG state
+    equal, bit for bit, N separate calls of the kernel.  C = 6 leaves a workgroup half empty."""
+    from aehmc_amd import RandomStream, nuts, targets
+    X, y = regression_data
+    r = np.random.default_rng(5)
+    C, N = 6, 7
+    tgt = targets.LinearRegression(X, y)
+    imm, eps = np.array([2.13e-05, 4.43e-05]), 0.8
+    q0 = np.array([3.0, np.log(0.49)]) + 0.01 * r.normal(size=(C, 2))
+    r1, r2 = RandomStream(seeds=list(range(40, 40 + C))), RandomStream(seeds=list(range(40, 40 + C)))
+    k1, k2 = nuts.new_kernel(r1, tgt), nuts.new_kernel(r2, tgt)
+    s1 = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+    samples, info, acc, div = k1.sample(s1, eps, imm, N)
+    s2, total = s1, 0
+    lengths = []
+    for t in range(N):
+        i2, upd = k2(s2, eps, imm)
+        s2 = i2.state._replace(momentum=None)
+        total = total + i2.n_leapfrog
+        lengths.append(i2.n_leapfrog.cpu().numpy())
+        assert torch.equal(samples[t], i2.state.position), t
+        assert torch.equal(acc[t], i2.acceptance_probability), t
+        assert torch.equal(div[t].to(torch.int32), i2.is_diverging.to(torch.int32)), t
+    assert len(np.unique(np.array(lengths))) > 1  # the chains do run out of step with each other
+    assert torch.equal(info.n_leapfrog, total)
+    for f in ("position", "potential_energy", "potential_energy_grad", "momentum"):
+        assert torch.equal(getattr(info.state, f), getattr(i2.state, f)), f
+    for f in ("acceptance_probability", "num_doublings", "is_turning", "is_diverging"):
+        assert torch.equal(getattr(info, f), getattr(i2, f)), f
+    assert torch.equal(k1._nuts["holder"]["rng"], k2._nuts["holder"]["rng"])
+
+
 def test_readme_example_runs():
     """The snippet of this repo's README.md (reduced sizes)."""
     from aehmc_amd import RandomStream, nuts, targets, window_adaptation
