@@ -1239,6 +1239,51 @@ struct AdaptArgs {
   const double *p_accept, *position;
   aehmc_adapt_state s;
 };
+// The per-chain arithmetic of one warm-up update, shared by k_adapt_update and the kernels that run the
+// whole warm-up in one launch (nuts_linreg.cuh) -- the same instruction sequence, hence the same bits.
+struct DualAvg {  // algorithms.py:9-14
+  long long step;
+  double x, x_avg, g_avg, mu;
+};
+// algorithms.py:104-115 + step_size.py:97-98: returns the next step size exp(x)
+__device__ __forceinline__ double adapt_da_update(DualAvg &d, double target, double p_accept, double gamma, double t0,
+                                                  double kappa) {
+  const double x_old = d.x;
+  const double eta = 1.0 / ((double)d.step + t0);
+  const double gradient = target - p_accept;
+  d.g_avg = (1.0 - eta) * d.g_avg + eta * gradient;
+  d.x = d.mu - (sqrt((double)d.step) / gamma) * d.g_avg;
+  const double x_eta = pow((double)d.step, -kappa);
+  d.x_avg = x_eta * x_old + (1.0 - x_eta) * d.x_avg;
+  d.step += 1;
+  return exp(d.x);
+}
+// window_adaptation.py:177-178: dual averaging restarted around the current step size
+__device__ __forceinline__ void adapt_da_restart(DualAvg &d, double step_size) {
+  d.mu = step_size;  // da_init(step_size): the step size itself, not its log
+  d.step = 1;
+  d.x = 0.0;
+  d.x_avg = 0.0;
+  d.g_avg = 0.0;
+}
+// algorithms.py:187-197, one coordinate (n already counts the new draw)
+__device__ __forceinline__ void adapt_welford_elem(double v, long long n, double &mean, double &m2) {
+  const double delta = v - mean;
+  mean = mean + delta / (double)n;
+  const double ud = v - mean;
+  m2 = m2 + ud * delta;
+}
+// mass_matrix.py:83-118 (diagonal) + metrics.py:45,49, one coordinate; the Welford state is reset
+__device__ __forceinline__ void adapt_window_end_elem(long long n, double &mean, double &m2, double &imm,
+                                                      double &sqrt_mass) {
+  const double nn = (double)n;
+  const double cov = m2 / (double)(n - 1);
+  imm = (nn / (nn + 5)) * cov + 1e-3 * (5 / (nn + 5));
+  sqrt_mass = sqrt(1.0 / imm);
+  mean = 0.0;
+  m2 = 0.0;
+}
+
 __global__ __launch_bounds__(256) void k_adapt_init(AdaptArgs a, double initial_step_size) {
   const int lane = threadIdx.x & 63;
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1273,17 +1318,8 @@ __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= a.C) return;
   // dual averaging, fast and slow stages alike (algorithms.py:104-115, step_size.py:97-98)
-  long long step = a.s.da_step[c];
-  const double x_old = a.s.da_x[c];
-  const double eta = 1.0 / ((double)step + a.t0);
-  const double gradient = a.target - a.p_accept[c];
-  double g_avg = (1.0 - eta) * a.s.da_g_avg[c] + eta * gradient;
-  double x = a.s.da_mu[c] - (sqrt((double)step) / a.gamma) * g_avg;
-  const double x_eta = pow((double)step, -a.kappa);
-  double x_avg = x_eta * x_old + (1.0 - x_eta) * a.s.da_x_avg[c];
-  double mu = a.s.da_mu[c];
-  step += 1;
-  double step_size = exp(x);
+  DualAvg da = {a.s.da_step[c], a.s.da_x[c], a.s.da_x_avg[c], a.s.da_g_avg[c], a.s.da_mu[c]};
+  double step_size = adapt_da_update(da, a.target, a.p_accept[c], a.gamma, a.t0, a.kappa);
   long long n = a.s.wc_n[c];
   if (a.s.full) {
     // full covariance (algorithms.py:187-197 with np.outer, mass_matrix.py:83-118), one wavefront per
@@ -1334,50 +1370,38 @@ __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
       if (in_lds)
         for (long long idx = lane; idx < DD; idx += 64) a.s.sqrt_mass[c * DD + idx] = S[idx];
       n = 0;
-      mu = step_size;
-      step = 1;
-      x = 0.0;
-      x_avg = 0.0;
-      g_avg = 0.0;
+      adapt_da_restart(da, step_size);
     }
   } else {
   if (a.stage != 0) {  // Welford update with the new position (algorithms.py:187-197)
     n += 1;
     for (long long i = lane; i < a.D; i += 64) {
-      const double v = a.position[c * a.D + i];
-      double mean = a.s.wc_mean[c * a.D + i];
-      const double delta = v - mean;
-      mean = mean + delta / (double)n;
-      const double ud = v - mean;
+      double mean = a.s.wc_mean[c * a.D + i], m2 = a.s.wc_m2[c * a.D + i];
+      adapt_welford_elem(a.position[c * a.D + i], n, mean, m2);
       a.s.wc_mean[c * a.D + i] = mean;
-      a.s.wc_m2[c * a.D + i] = a.s.wc_m2[c * a.D + i] + ud * delta;
+      a.s.wc_m2[c * a.D + i] = m2;
     }
   }
   if (a.window_end) {  // slow_final: window_adaptation.py:165-182, mass_matrix.py:83-118
-    const double nn = (double)n;
     for (long long i = lane; i < a.D; i += 64) {
-      const double cov = a.s.wc_m2[c * a.D + i] / (double)(n - 1);
-      const double imm = (nn / (nn + 5)) * cov + 1e-3 * (5 / (nn + 5));
+      double mean = a.s.wc_mean[c * a.D + i], m2 = a.s.wc_m2[c * a.D + i], imm, sqrt_mass;
+      adapt_window_end_elem(n, mean, m2, imm, sqrt_mass);
       a.s.imm[c * a.D + i] = imm;
-      a.s.sqrt_mass[c * a.D + i] = sqrt(1.0 / imm);  // metrics.py:45,49
-      a.s.wc_mean[c * a.D + i] = 0.0;
-      a.s.wc_m2[c * a.D + i] = 0.0;
+      a.s.sqrt_mass[c * a.D + i] = sqrt_mass;
+      a.s.wc_mean[c * a.D + i] = mean;
+      a.s.wc_m2[c * a.D + i] = m2;
     }
     n = 0;
-    mu = step_size;  // da_init(step_size): the step size itself, not its log
-    step = 1;
-    x = 0.0;
-    x_avg = 0.0;
-    g_avg = 0.0;
+    adapt_da_restart(da, step_size);
   }
   }
-  if (a.last) step_size = exp(x_avg);  // window_adaptation.py:184-190
+  if (a.last) step_size = exp(da.x_avg);  // window_adaptation.py:184-190
   if (lane == 0) {
-    a.s.da_step[c] = step;
-    a.s.da_x[c] = x;
-    a.s.da_x_avg[c] = x_avg;
-    a.s.da_g_avg[c] = g_avg;
-    a.s.da_mu[c] = mu;
+    a.s.da_step[c] = da.step;
+    a.s.da_x[c] = da.x;
+    a.s.da_x_avg[c] = da.x_avg;
+    a.s.da_g_avg[c] = da.g_avg;
+    a.s.da_mu[c] = da.mu;
     a.s.wc_n[c] = n;
     a.s.step_size[c] = step_size;
   }

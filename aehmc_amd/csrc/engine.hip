@@ -66,6 +66,8 @@ struct aehmc_ctx {
   // matrix was not positive definite (separate words: one must not erase the other)
   int *h_err = nullptr, *d_err = nullptr;
   double prof_flops = 0.0;
+  int *d_sched = nullptr;  // warm-up schedule on the device: stage [n], is_window_end [n]
+  int64_t d_sched_n = 0;
 };
 
 #define HIPCHK(expr)                                                                     \
@@ -155,6 +157,7 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (ctx->sk_partial) (void)hipFree(ctx->sk_partial);
   if (ctx->sk_flags) (void)hipFree(ctx->sk_flags);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  if (ctx->d_sched) (void)hipFree(ctx->d_sched);
   for (int i = 0; i < NRING; i++)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -857,6 +860,38 @@ extern "C" int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64
   if (!ctx->has_tgt) FAIL("set_target and set_metric must be called first");
   if (!ctx->eps_c || !ctx->met.per_chain) FAIL("warm-up needs per-chain step sizes and a per-chain metric bound to the adaptation state");
   const int64_t D = ctx->tgt.D;
+  // regression target, diagonal mass matrix: the whole warm-up in ONE launch, every chain adapting
+  // and moving on at its own pace (nuts_linreg.cuh) -- the same arithmetic as the loop below
+  if (num_steps > 0 && ctx->opt_resident_nuts && !state->full && ctx->has_met && ctx->met.ndim == 1 &&
+      ctx->met.imm == state->imm && ctx->met.sqrt_mass == state->sqrt_mass && ctx->eps_c == state->step_size &&
+      nuts_linreg_supported(ctx->tgt.kind, ctx->met.ndim, D, max_num_expansions)) {
+    hipStream_t st = (hipStream_t)stream;
+    AdaptArgs aa;
+    if (int rc = adapt_args(ctx, C, D, state, aa)) return rc;
+    if (ctx->d_sched_n < num_steps) {
+      if (ctx->d_sched) HIPCHK(hipFree(ctx->d_sched));
+      ctx->d_sched = nullptr;
+      HIPCHK(hipMalloc(&ctx->d_sched, (size_t)2 * num_steps * sizeof(int)));
+      ctx->d_sched_n = num_steps;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_sched, stage, (size_t)num_steps * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->d_sched + num_steps, is_window_end, (size_t)num_steps * sizeof(int),
+                          hipMemcpyHostToDevice, st));
+    NutsSampleArgs multi{};
+    multi.T = num_steps;
+    multi.adapt = 1;
+    multi.stage = ctx->d_sched;
+    multi.window_end = ctx->d_sched + num_steps;
+    multi.target = target_acceptance_rate;
+    multi.gamma = aa.gamma; multi.t0 = aa.t0; multi.kappa = aa.kappa;
+    multi.ad = *state;
+    bool all_done = false;
+    if (int rc = nuts_run(ctx, C, rng, 0.0, max_num_expansions, divergence_threshold, q, U, g, out, st, &multi,
+                          &all_done))
+      return rc;
+    if (!all_done) FAIL("internal: the fused warm-up kernel was not taken");
+    return 0;
+  }
   for (int64_t i = 0; i < num_steps; i++) {
     if (int rc = nuts_run(ctx, C, rng, 0.0, max_num_expansions, divergence_threshold, q, U, g, out,
                           (hipStream_t)stream))

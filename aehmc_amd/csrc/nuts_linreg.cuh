@@ -35,6 +35,13 @@ struct NutsSampleArgs {
   double *acc_hist;        // [T][C]
   int *div_hist;           // [T][C]
   long long *nleap_total;  // [C] leapfrogs of all T transitions
+  // window adaptation inside the launch (window_adaptation.py:17-116, diagonal mass matrix): after
+  // its transition t a chain updates its own dual-averaging / Welford state with schedule entry t
+  // and goes on with the new step size (and, after a window end, the new metric)
+  int adapt;
+  const int *stage, *window_end;  // device arrays [T] (window_adaptation.py:230-327)
+  double target, gamma, t0, kappa;
+  aehmc_adapt_state ad;
 };
 
 #ifdef AEHMC_WIDE_TIMING  // developer build (make timing): cycles per phase of every chain wave -> a.ckp[c][8]
@@ -77,6 +84,9 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
   ChainRng rng = {};
   ChainCtl ct = {};
   long long t_idx = 0, nleap_sum = 0;
+  DualAvg da = {1, 0.0, 0.0, 0.0, 0.0};  // warm-up state of the chain (m.adapt)
+  long long wc_n = 0;
+  double wmean = 0.0, wm2 = 0.0;
 #pragma unroll
   for (int s = 0; s < 2; s++) end_q[s] = end_p[s] = end_g[s] = slot_q[s] = slot_p[s] = slot_g[s] = 0.0;
 
@@ -126,6 +136,18 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
     }
     U_state = a.U[c];
     eps = a.eps_c ? a.eps_c[c] : a.eps;
+    if (m.adapt) {
+      da.step = m.ad.da_step[c];
+      da.x = m.ad.da_x[c];
+      da.x_avg = m.ad.da_x_avg[c];
+      da.g_avg = m.ad.da_g_avg[c];
+      da.mu = m.ad.da_mu[c];
+      wc_n = m.ad.wc_n[c];
+      if (el) {
+        wmean = m.ad.wc_mean[c * 2 + lane];
+        wm2 = m.ad.wc_m2[c * 2 + lane];
+      }
+    }
     rng = rng_load(a, c);
     begin_transition();
   }
@@ -382,6 +404,21 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
         if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
         if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
       }
+      if (m.adapt) {  // the update of k_adapt_update, same order: step size, Welford, window end, last
+        const int stage = m.stage[t_idx], wend = m.window_end[t_idx];
+        double step_size = adapt_da_update(da, m.target, ct.acc_prob, m.gamma, m.t0, m.kappa);
+        if (stage != 0) {
+          wc_n += 1;
+          if (el) adapt_welford_elem(sq, wc_n, wmean, wm2);
+        }
+        if (wend) {
+          if (el) adapt_window_end_elem(wc_n, wmean, wm2, imr, smr);
+          wc_n = 0;
+          adapt_da_restart(da, step_size);
+        }
+        if (t_idx == m.T - 1) step_size = exp(da.x_avg);  // window_adaptation.py:184-190
+        eps = step_size;
+      }
       t_idx += 1;
       if (t_idx == m.T) {
         fin = true;
@@ -389,6 +426,12 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
           a.q[c * 2 + lane] = sq;
           a.g[c * 2 + lane] = sg;
           if (a.out.momentum) a.out.momentum[c * 2 + lane] = sp;
+          if (m.adapt) {
+            m.ad.wc_mean[c * 2 + lane] = wmean;
+            m.ad.wc_m2[c * 2 + lane] = wm2;
+            m.ad.imm[c * 2 + lane] = imr;
+            m.ad.sqrt_mass[c * 2 + lane] = smr;
+          }
         }
         if (lane == 0) {
           a.U[c] = U_state;
@@ -398,6 +441,15 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
           a.out.is_diverging[c] = ct.out_div;
           if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
           if (m.nleap_total) m.nleap_total[c] = nleap_sum;
+          if (m.adapt) {
+            m.ad.da_step[c] = da.step;
+            m.ad.da_x[c] = da.x;
+            m.ad.da_x_avg[c] = da.x_avg;
+            m.ad.da_g_avg[c] = da.g_avg;
+            m.ad.da_mu[c] = da.mu;
+            m.ad.wc_n[c] = wc_n;
+            m.ad.step_size[c] = eps;
+          }
 #pragma unroll
           for (int k = 0; k < 4; k++)
             if (k < a.nsites) pcg_store(a.rng + ((size_t)c * a.nsites + k) * 4, rng.g[k]);

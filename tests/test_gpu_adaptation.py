@@ -346,3 +346,31 @@ def test_fused_warmup_equals_step_by_step(full, D, C):
                      info.state.position.clone(), upd[srng].clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C,steps", [(6, 130), (9, 37)])
+def test_regression_warmup_in_one_launch_equals_step_by_step(regression_data, C, steps):
+    """Regression target, diagonal mass matrix: aehmc_nuts_warmup runs the WHOLE warm-up in one launch of
+    k_nuts_linreg -- every chain applies its own adaptation update after each of its transitions and
+    goes on without waiting for the others.  State, step sizes, inverse mass matrix, its square root,
+    the following transition and the RNG state equal the step-by-step loop (one launch per transition
+    plus k_adapt_update) bit for bit.  37 steps: a schedule without a slow window."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    X, y = regression_data
+    r = np.random.default_rng(C)
+    tgt = targets.LinearRegression(X, y)
+    q0 = np.array([3.0, np.log(0.49)]) + 0.01 * r.normal(size=(C, 2))
+    outs = []
+    for fused in (True, False):
+        srng = RandomStream(seeds=[700 + c for c in range(C)])
+        kernel = nuts.new_kernel(srng, tgt)
+        state = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+        state, (eps, imm), upd = window_adaptation.run(kernel, state, steps, fused=fused)
+        info, upd = kernel(state, eps, imm)
+        outs.append((state.position.clone(), state.potential_energy.clone(), state.potential_energy_grad.clone(),
+                     eps.value.clone(), imm.value.clone(), imm.sqrt_mass.clone(),
+                     info.state.position.clone(), info.n_leapfrog.clone(), upd[srng].clone()))
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), k
+    e = outs[0][3].cpu().numpy()
+    assert np.isfinite(e).all() and (e > 0).all() and len(np.unique(e)) == C  # per-chain step sizes
