@@ -374,14 +374,57 @@ def bench_c5(args, rank, world, device):
     chains_total = sum_over_ranks(C, device)
     if rank == 0:
         assert gathered.shape[0] == chains_total
+        rate = total / elapsed
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline_c5(X, y, info, eps, imm)
         print(json.dumps({
-            "metric": "leapfrog-steps/sec across all chains", "value": total / elapsed, "unit": "leapfrog-steps/s",
+            "metric": "leapfrog-steps/sec across all chains", "value": rate, "unit": "leapfrog-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"c5: linear regression, {N} rows, D=2, NUTS after {max(args.warmup, 20)} "
-                                   f"window-adaptation steps ({t_w:.2f} s), {C} chains/GPU",
-                       "chains_total": chains_total, "data_rows_per_s": total / elapsed * N},
-            "roofline": None, "cpu_baseline": None}))
+                                   f"window-adaptation steps ({t_w:.2f} s, one launch), {C} chains/GPU",
+                       "chains_total": chains_total, "data_rows_per_s": rate * N},
+            # neither HBM nor MFMA bounds this path: per leapfrog a chain needs 3 fp64 FMAs per data row
+            # (the rows come from L2 / LDS), so the figure of merit is the vector-FMA rate
+            "roofline": None,
+            "valu": {"bound": "fp64 vector FMA", "achieved": rate / world * N * 6 / 1e12, "peak": 78.6,
+                     "unit": "TFLOP/s", "frac": rate / world * N * 6 / 1e12 / 78.6,
+                     "note": "3 FMAs per row and leapfrog; the sweep also pulls 16 B per row and workgroup "
+                             "from L2 (4 chains share it): see DESIGN.md"},
+            "cpu_baseline": cpu}))
+
+
+def cpu_baseline_c5(X, y, info, eps, imm):
+    """c5 on the host: the C restatement runs NUTS transitions of the first chains from the GPU's
+    post-warm-up state (one thread, then OpenMP over chains, one chain per thread).  The oracle takes
+    one step size / metric per call, so the chains share the MEDIAN of the adapted per-chain values."""
+    from oracle import c_oracle as co
+    cores = os.cpu_count() or 1
+    otgt = co.Target(co.T_LINREG, 2, X=X, y=y)
+    pos = info.state.position.cpu().numpy()
+    e = float(np.median(eps.value.cpu().numpy()))
+    metric = co.Metric(np.median(imm.value.cpu().numpy().reshape(-1, 2), axis=0), 2)
+
+    def run(n, threads, reps):
+        rng = co.site_states([9000 + c for c in range(n)], 4)
+        q, U, g = co.new_state(otgt, pos[:n].copy())
+        t0, nl = time.perf_counter(), 0
+        for _ in range(reps):
+            nl += int(co.nuts_step(otgt, metric, rng, e, q, U, g, nthreads=threads)["n_leapfrog"].sum())
+        return nl, time.perf_counter() - t0
+
+    reps = 20
+    n1, dt1 = run(4, 1, reps)
+    used = min(cores, 256, pos.shape[0])
+    na, dta = run(used, used, reps)
+    return {"value": na / dta, "unit": "leapfrog-steps/s", "cores": used, "kind": "port",
+            "sample": f"{used} chains x {reps} NUTS transitions (median adapted step size / metric), OpenMP over "
+                      f"chains ({na} leapfrogs, {dta:.1f} s)",
+            "single_thread": {"value": n1 / dt1, "unit": "leapfrog-steps/s", "cores": 1,
+                              "sample": f"4 chains x {reps} NUTS transitions ({n1} leapfrogs, {dt1:.1f} s)"},
+            "host_cpu_count": cores,
+            "note": "C restatement of aehmc semantics (oracle/c), not Aesara; reported, not optimised"}
 
 
 def cpu_baseline(config, D, q0, target, imm, eps):
