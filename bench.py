@@ -166,7 +166,9 @@ def main():
     if os.environ.get("AEHMC_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     dist_backend = None
-    if world > 1:
+    # (a single rank started by torch.distributed.run still joins its one-rank group: the same RCCL
+    #  code path as the multi-GPU runs, which a 1-GPU box can exercise)
+    if world > 1 or os.environ.get("TORCHELASTIC_RUN_ID"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = dist_backend = os.environ.get("AEHMC_DIST_BACKEND", "nccl")

@@ -51,3 +51,51 @@ def test_bench_gpus2_starts_two_ranks():
              "--no-cpu-baseline", env=env)
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["chains_total"] == 128
     assert d["config"]["gather"]["bytes"] == 64 * 256 * 8 and d["value"] > 0
+
+
+def test_parallel_collectives_on_rccl_one_rank():
+    """The collectives of aehmc_amd/parallel.py on the REAL backend (nccl == RCCL) with a one-rank
+    group on this box's GPU: process-group creation with device_id, barrier(device_ids), the
+    all-reduces of the timing / leapfrog totals and the rank-0 gather (ragged and even) run through
+    RCCL's code paths rather than gloo's.  (World sizes > 1 need more GPUs than this box has: the
+    driver's 8-GPU run covers them; the sharding logic itself is tested with gloo on CPU.)"""
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from aehmc_amd import parallel
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl"
+parallel.barrier(dev)
+assert parallel.max_over_ranks(1.25, dev) == 1.25 and parallel.sum_over_ranks(7, dev) == 7
+x = torch.arange(12, dtype=torch.float64, device=dev).reshape(6, 2)
+g = parallel.gather_samples(x)
+assert torch.equal(g, x) and g.device == x.device
+g = parallel.gather_samples(x, dst=None)
+assert torch.equal(g, x)
+assert parallel.shard_chains(10) == (0, 10)
+dist.destroy_process_group()
+print("RCCL-OK")
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stderr[-3000:]
+
+
+def test_bench_one_rank_under_the_launcher_uses_rccl():
+    """bench.py as the driver launches it (torch.distributed.run, here with one process): the rank
+    initialises RCCL, and the line reports the backend it gathered over."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "2", "--warmup", "1", "--chains", "64", "--dim", "256",
+                          "--no-cpu-baseline", "--no-secondary"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["ranks_seen"] == 1 and d["value"] > 0
+    assert d["config"]["gather"]["backend"] == "nccl"

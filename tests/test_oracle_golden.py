@@ -208,9 +208,14 @@ def test_dynamic_integration_outcomes(step_size, div, term):
 
 
 # ------------------------------------------------------------------ numpy <-> C restatements
-@pytest.mark.parametrize("kind", ["scalar", "diag", "dense"])
+@pytest.mark.parametrize("kind", ["scalar", "diag", "dense", "dense40"])
 def test_c_matches_numpy_nuts(kind):
-    D = 1 if kind == "scalar" else 5  # reference: ndim-0 imm goes with a scalar position
+    """Two independent restatements (numpy: the reference's own array expressions with numpy /
+    scipy.linalg in place of Aesara ops; C: explicit loops) agree on whole transitions.  The dense
+    branch has no reference-held value: this cross-check, at D = 5 and D = 40, is what
+    stands behind it."""
+    D = 1 if kind == "scalar" else 40 if kind == "dense40" else 5  # reference: ndim-0 imm goes with a scalar position
+    kind = "dense" if kind == "dense40" else kind
     r = np.random.default_rng(3)
     mu, sigma = r.normal(size=D), 0.5 + r.random(D)
     if kind == "dense":
