@@ -244,6 +244,38 @@ def test_regression_nuts_matches_oracle(eng, regression_data, metric_kind, C, re
     eng.set_option("resident_nuts", 2)
 
 
+@pytest.mark.parametrize("N,metric_kind,max_exp", [(37, "diag", 10), (10177, "scalar", 10), (30001, "diag", 10),
+                                                  (30001, "diag", 2), (12288, "diag", 10)])
+def test_regression_nuts_row_counts_match_oracle(eng, N, metric_kind, max_exp):
+    """k_nuts_linreg over the row-count regimes of its sweep: fewer rows than threads (37), all rows in
+    LDS (<= 10176), LDS rows + streamed blocks + an odd tail (30001), LDS rows + whole blocks only
+    (12288 = 10176 + 2112: one 512-piece block per wave short of 8 waves), a scalar metric, and a
+    tree cut by max_num_expansions.  Row-wise noise so that the posterior has a real width."""
+    from aehmc_amd import RandomStream, nuts, targets
+    r = np.random.default_rng(N)
+    X = r.normal(size=N)
+    y = 3 * X + 0.5 * r.normal(size=N)
+    tgt, otgt = targets.LinearRegression(X, y), co.Target(co.T_LINREG, 2, X=X, y=y)
+    C = 5
+    imm = np.float64(1.0 / N) if metric_kind == "scalar" else np.array([1.0 / N, 0.5 / N])
+    eps = 0.5
+    seeds = [31 + c for c in range(C)]
+    q0 = np.array([3.0, np.log(0.5)]) + 0.02 * r.normal(size=(C, 2))
+    kernel = nuts.new_kernel(RandomStream(seeds=seeds), tgt, max_num_expansions=max_exp)
+    state = nuts.new_state(dev(q0), tgt)
+    rng = co.site_states(seeds, 4)
+    metric = co.Metric(imm, 2)
+    q, U, g = co.new_state(otgt, q0.copy())
+    lengths = []
+    for _ in range(3):
+        info, _ = kernel(state, eps, imm)
+        res = co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=max_exp)
+        check_state(info, q, U, g, res)
+        lengths.append(res["n_leapfrog"])
+        state = info.state._replace(momentum=None)
+    assert np.max(lengths) >= 3 and 0.1 < info.acceptance_probability.mean().item() <= 1.0  # real trajectories
+
+
 # ------------------------------------------------------------------ helpers
 def make_case(kind, tkind, D, r):
     from aehmc_amd import targets
