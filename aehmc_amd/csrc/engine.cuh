@@ -79,6 +79,22 @@ struct EngineArgs {
   aehmc_diagnostics out;
 };
 
+// optional per-transition outputs of a launch that runs T transitions
+struct NutsSampleArgs {
+  long long T;
+  double *samples;         // [T][C][D] positions after each transition
+  double *acc_hist;        // [T][C]
+  int *div_hist;           // [T][C]
+  long long *nleap_total;  // [C] leapfrogs of all T transitions
+  // window adaptation inside the launch (window_adaptation.py:17-116, diagonal mass matrix): after
+  // its transition t a chain updates its own dual-averaging / Welford state with schedule entry t
+  // and goes on with the new step size (and, after a window end, the new metric)
+  int adapt;
+  const int *stage, *window_end;  // device arrays [T] (window_adaptation.py:230-327)
+  double target, gamma, t0, kappa;
+  aehmc_adapt_state ad;
+};
+
 // two-entry arrays are picked with a select, never indexed dynamically (a dynamic index
 // into the kernel-argument struct or ChainCtl sends them to scratch memory)
 template <class T>
@@ -346,8 +362,8 @@ __device__ __forceinline__ ChainRng rng_load(const EngineArgs &a, long long c) {
   ChainRng r;
 #pragma unroll
   for (int k = 0; k < 4; k++) {  // static indices only (a dynamic one sends g[] to scratch)
-    r.g[k].state = 0;
-    r.g[k].inc = 0;
+    r.g[k].state = mk128(0, 0);
+    r.g[k].inc = mk128(0, 0);
     if (k < a.nsites) r.g[k] = pcg_load(a.rng + ((size_t)c * a.nsites + k) * 4);
   }
   return r;

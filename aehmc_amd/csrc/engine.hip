@@ -112,10 +112,12 @@ extern "C" int aehmc_create(aehmc_ctx **out, int device) {
   HIPCHK(hipSetDevice(device));
   // LCG jump-ahead table: state_{t+n} = A^n state_t + G_n inc  (rng.cuh)
   uint64_t jump[64][4];
-  u128 A = 1, G = 0;
+  typedef unsigned __int128 host_u128;
+  const host_u128 mult = (((host_u128)AEHMC_PCG_MULT_HI) << 64) | (host_u128)AEHMC_PCG_MULT_LO;
+  host_u128 A = 1, G = 0;
   for (int k = 0; k < 64; k++) {
-    G = G * AEHMC_PCG_MULT + 1;  // G_{k+1} = A * G_k + 1
-    A = A * AEHMC_PCG_MULT;
+    G = G * mult + 1;  // G_{k+1} = A * G_k + 1
+    A = A * mult;
     jump[k][0] = (uint64_t)(A >> 64);
     jump[k][1] = (uint64_t)A;
     jump[k][2] = (uint64_t)(G >> 64);
@@ -783,8 +785,14 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
                          (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf, a.ldw);
       HIPCHK(hipGetLastError());
       HIPCHK(launch_nuts_wide(a, st));
-    } else {
-      HIPCHK(launch_nuts_resident(a, st, ctx->opt_resident_min_team));
+    } else {  // teams of <= 64 lanes: any number of transitions in one launch
+      NutsSampleArgs m{};
+      m.T = 1;
+      if (multi) {
+        m = *multi;
+        *multi_done = true;
+      }
+      HIPCHK(launch_nuts_resident(a, m, st, ctx->opt_resident_min_team));
     }
     return prof_end(ctx, st, p);
   }

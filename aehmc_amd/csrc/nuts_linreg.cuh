@@ -28,22 +28,6 @@
 
 namespace aehmc {
 
-// optional per-transition outputs of a launch that runs T transitions
-struct NutsSampleArgs {
-  long long T;
-  double *samples;         // [T][C][D] positions after each transition
-  double *acc_hist;        // [T][C]
-  int *div_hist;           // [T][C]
-  long long *nleap_total;  // [C] leapfrogs of all T transitions
-  // window adaptation inside the launch (window_adaptation.py:17-116, diagonal mass matrix): after
-  // its transition t a chain updates its own dual-averaging / Welford state with schedule entry t
-  // and goes on with the new step size (and, after a window end, the new metric)
-  int adapt;
-  const int *stage, *window_end;  // device arrays [T] (window_adaptation.py:230-327)
-  double target, gamma, t0, kappa;
-  aehmc_adapt_state ad;
-};
-
 #ifdef AEHMC_WIDE_TIMING  // developer build (make timing): cycles per phase of every chain wave -> a.ckp[c][8]
 #define LRN_TICK(k)                                                  \
   do {                                                               \

@@ -57,8 +57,11 @@ __device__ __forceinline__ void team_sum2(double &x, double &y) {
   y = wave_sum(y);
 }
 
-template <int T, int R>
-__global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) {
+// MULTI: the launch runs m.T > 1 transitions (the RNG state, the leapfrog total ... stay live across
+// the tree loop, which costs ~35 VGPRs and a wavefront per SIMD: single transitions keep their own
+// instantiation).
+template <int T, int R, bool MULTI>
+__global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, NutsSampleArgs m) {
   using TM = Team<T>;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -90,18 +93,26 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
   ChainRng rng = {};
   ChainCtl ct = {};
   double kd = 0.0, zero = 0.0;
-  {
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const long long i = (long long)t + (long long)T * r;
     ok[r] = i < a.D;
     if (IM_REG) imr[r] = ok[r] ? a.imm[imo + (a.met_ndim == 0 ? 0 : i)] : 1.0;
-    QSET(r, ok[r] ? AT(a.q, r) : 0.0);
+  }
+  rng = rng_load(a, c);
+  double U_state = MULTI ? a.U[c] : 0.0;  // the chain's potential energy between transitions
+  long long nleap_sum = 0;
+  // m.T consecutive transitions in this launch (the user-level scan of tests/test_hmc.py:296-324): the
+  // chains of a wavefront start each transition together, wavefronts run independently of each other
+  for (long long t_idx = 0; t_idx < (MULTI ? m.T : 1); t_idx++) {
+  {
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    QSET(r, ok[r] ? AT(a.q, r) : 0.0);  // (after the first transition: what this thread wrote below)
     GSET(r, ok[r] ? AT(a.g, r) : 0.0);
   }
 
   // ---- momentum, site #1 (nuts.py:113 -> metrics.py:65-68) ------------------------
-  rng = rng_load(a, c);
   if (TM::SUB) {
     // every lane of the team walks the chain's stream itself and keeps its own elements
     const double *sm = a.sqrt_mass + imo;
@@ -116,14 +127,14 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
         }
       }
     }
-    if (lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
+    if (!MULTI && lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
   } else {
     {
       const double *sm = a.sqrt_mass + imo;
       const bool scalar = a.met_ndim == 0;
       double *dst = a.zbuf;
       wave_normals(rng.g[0], a.D, [=](long long i, double z) { dst[row + i] = (scalar ? sm[0] : sm[i]) * z; });
-      if (lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
+      if (!MULTI && lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
     }
     __threadfence_block();
   }
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
   }
   team_sum2<T>(kd, zero);
   {
-    const double U = a.U[c];
+    const double U = MULTI ? U_state : a.U[c];
     ct.H0 = U + 0.5 * kd;
     ct.prop_E = ct.H0;
     ct.prop_w = 0.0;
@@ -405,6 +416,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
             if (a.out.momentum) AT(a.out.momentum, r) = AT(pick2(a.slot_p, s), r);
           }
         }
+        if (MULTI) U_state = pick2(ct.U_slot, s);
         if (lead) {
           a.U[c] = pick2(ct.U_slot, s);
           a.out.acceptance_probability[c] = ct.acc_prob;
@@ -437,8 +449,22 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a) 
       }
     }
   }
+  // per-transition records of a multi-transition launch
+  if (MULTI) nleap_sum += ct.nleap;
+  if (MULTI && m.samples) {
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (ok[r]) (m.samples + ((size_t)t_idx * a.C + c) * a.D)[EI(r)] = AT(a.q, r);
+  }
+  if (MULTI && lead) {
+    if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
+    if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
+  }
+  }  // transitions
   if (lead) {
     if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
+    if (MULTI && m.nleap_total) m.nleap_total[c] = nleap_sum;
+    if (MULTI) pcg_store(a.rng + ((size_t)c * a.nsites + 0) * 4, rng.g[0]);
     pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, rng.g[1]);
     pcg_store(a.rng + ((size_t)c * a.nsites + 2) * 4, rng.g[2]);
     pcg_store(a.rng + ((size_t)c * a.nsites + 3) * 4, rng.g[3]);
@@ -460,16 +486,19 @@ inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
 }
 
 template <int T, int R>
-inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, hipStream_t st) {
+inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
   const unsigned grid = Team<T>::SUB ? (unsigned)((a.C * T + 255) / 256) : (unsigned)((a.C + 3) / 4);
-  hipLaunchKernelGGL((k_nuts_resident<T, R>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a);
+  const bool multi = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total;
+  if (multi) hipLaunchKernelGGL((k_nuts_resident<T, R, true>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a, m);
+  else hipLaunchKernelGGL((k_nuts_resident<T, R, false>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a, m);
   return hipGetLastError();
 }
 // Team size: the smallest team that holds the chain (<= 4 elements per lane below a wave,
 // <= 8-10 above), widened -- fewer chains per wavefront -- while that still leaves about
 // 4096 wavefronts in flight, because a wider team wastes lanes but keeps the per-chain RNG /
 // control state wave-uniform (SGPRs, scalar branches).
-inline hipError_t launch_nuts_resident(const EngineArgs &a, hipStream_t st, int force_min_team = 0) {
+inline hipError_t launch_nuts_resident(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st,
+                                       int force_min_team = 0) {
   const long long D = a.D, C = a.C;
   if (D > 512) return hipErrorInvalidValue;  // one workgroup per chain: nuts_wide.cuh
   const int tmin = D <= 4 ? 1 : D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64;
@@ -478,19 +507,19 @@ inline hipError_t launch_nuts_resident(const EngineArgs &a, hipStream_t st, int 
   const int T = force_min_team ? tmin : (tmin > twant ? tmin : twant);
   switch (T) {
     case 1:
-      if (D <= 1) return launch_nuts_resident_tr<1, 1>(a, st);
-      if (D <= 2) return launch_nuts_resident_tr<1, 2>(a, st);
-      return launch_nuts_resident_tr<1, 4>(a, st);
-    case 2: return launch_nuts_resident_tr<2, 4>(a, st);
-    case 4: return launch_nuts_resident_tr<4, 4>(a, st);
-    case 8: return launch_nuts_resident_tr<8, 4>(a, st);
-    case 16: return launch_nuts_resident_tr<16, 4>(a, st);
-    case 32: return launch_nuts_resident_tr<32, 4>(a, st);
+      if (D <= 1) return launch_nuts_resident_tr<1, 1>(a, m, st);
+      if (D <= 2) return launch_nuts_resident_tr<1, 2>(a, m, st);
+      return launch_nuts_resident_tr<1, 4>(a, m, st);
+    case 2: return launch_nuts_resident_tr<2, 4>(a, m, st);
+    case 4: return launch_nuts_resident_tr<4, 4>(a, m, st);
+    case 8: return launch_nuts_resident_tr<8, 4>(a, m, st);
+    case 16: return launch_nuts_resident_tr<16, 4>(a, m, st);
+    case 32: return launch_nuts_resident_tr<32, 4>(a, m, st);
     default:
-      if (D <= 64) return launch_nuts_resident_tr<64, 1>(a, st);
-      if (D <= 128) return launch_nuts_resident_tr<64, 2>(a, st);
-      if (D <= 256) return launch_nuts_resident_tr<64, 4>(a, st);
-      return launch_nuts_resident_tr<64, 8>(a, st);
+      if (D <= 64) return launch_nuts_resident_tr<64, 1>(a, m, st);
+      if (D <= 128) return launch_nuts_resident_tr<64, 2>(a, m, st);
+      if (D <= 256) return launch_nuts_resident_tr<64, 4>(a, m, st);
+      return launch_nuts_resident_tr<64, 8>(a, m, st);
   }
 }
 

@@ -15,7 +15,28 @@
 
 namespace aehmc {
 
-typedef unsigned __int128 u128;
+// 128-bit unsigned integers of the PCG64 state as two 64-bit halves with explicit arithmetic.  (With
+// `unsigned __int128` hipcc 7.2 lost the upper half of the loop-carried generator state inside the
+// inlined ziggurat redraw loop of k_nuts_resident<1,1>: the registers of an exp() coefficient were
+// multiplied in its place, so the redraws ran on a garbage state.  The RNG-state parity tests cover
+// every kernel family that draws normals, at sizes that take the redraw path.)
+struct u128 {
+  uint64_t hi, lo;
+};
+__host__ __device__ __forceinline__ u128 mk128(uint64_t hi, uint64_t lo) {
+  u128 r;
+  r.hi = hi;
+  r.lo = lo;
+  return r;
+}
+// (the arithmetic itself goes through the compiler's 128-bit integers -- one multiply-add chain with
+//  hardware carries -- but no 128-bit VALUE outlives these functions: states live as two 64-bit words)
+typedef unsigned __int128 wide_u128;
+__device__ __forceinline__ wide_u128 widen(u128 a) { return (((wide_u128)a.hi) << 64) | (wide_u128)a.lo; }
+__device__ __forceinline__ u128 narrow(wide_u128 a) { return mk128((uint64_t)(a >> 64), (uint64_t)a); }
+__device__ __forceinline__ u128 mul128(u128 a, u128 b) { return narrow(widen(a) * widen(b)); }  // low 128 bits
+__device__ __forceinline__ u128 add128(u128 a, u128 b) { return narrow(widen(a) + widen(b)); }
+__device__ __forceinline__ u128 muladd128(u128 a, u128 b, u128 c) { return narrow(widen(a) * widen(b) + widen(c)); }
 
 __constant__ uint64_t c_zig_ki[256] = {AEHMC_ZIG_KI_VALUES};
 __constant__ double c_zig_wi[256] = {AEHMC_ZIG_WI_VALUES};
@@ -25,7 +46,8 @@ __constant__ double c_zig_fi[256] = {AEHMC_ZIG_FI_VALUES};
 // Filled by aehmc_create().
 __constant__ uint64_t c_pcg_jump[64][4];
 
-#define AEHMC_PCG_MULT ((((u128)2549297995355413924ULL) << 64) | (u128)4865540595714422341ULL)
+#define AEHMC_PCG_MULT_HI 2549297995355413924ULL
+#define AEHMC_PCG_MULT_LO 4865540595714422341ULL
 
 struct Pcg64 {
   u128 state, inc;
@@ -33,22 +55,22 @@ struct Pcg64 {
 
 __device__ __forceinline__ Pcg64 pcg_load(const uint64_t *s) {
   Pcg64 r;
-  r.state = (((u128)s[0]) << 64) | (u128)s[1];
-  r.inc = (((u128)s[2]) << 64) | (u128)s[3];
+  r.state = mk128(s[0], s[1]);
+  r.inc = mk128(s[2], s[3]);
   return r;
 }
 __device__ __forceinline__ void pcg_store(uint64_t *s, const Pcg64 &r) {
-  s[0] = (uint64_t)(r.state >> 64);
-  s[1] = (uint64_t)r.state;
+  s[0] = r.state.hi;
+  s[1] = r.state.lo;
 }
 __device__ __forceinline__ uint64_t pcg_output(u128 s) {  // XSL-RR
-  uint64_t hi = (uint64_t)(s >> 64), lo = (uint64_t)s;
+  uint64_t hi = s.hi, lo = s.lo;
   uint64_t x = hi ^ lo;
   unsigned rot = (unsigned)(hi >> 58);
   return (x >> rot) | (x << ((-rot) & 63));
 }
 __device__ __forceinline__ uint64_t pcg_next64(Pcg64 &r) {
-  r.state = r.state * AEHMC_PCG_MULT + r.inc;
+  r.state = muladd128(r.state, mk128(AEHMC_PCG_MULT_HI, AEHMC_PCG_MULT_LO), r.inc);
   return pcg_output(r.state);
 }
 __device__ __forceinline__ double pcg_next_double(Pcg64 &r) {
@@ -191,7 +213,7 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
   return (((uint64_t)hi) << 32) | lo;
 }
 __device__ __forceinline__ u128 shfl_u128(u128 v, int src) {
-  return (((u128)shfl_u64((uint64_t)(v >> 64), src)) << 64) | (u128)shfl_u64((uint64_t)v, src);
+  return mk128(shfl_u64(v.hi, src), shfl_u64(v.lo, src));
 }
 
 // Draws z_0..z_{n-1} exactly as n sequential Generator.normal() calls would, with the
@@ -214,11 +236,11 @@ struct LaneSrc {  // raw outputs of lanes idx, idx+1, ... of the current round (
 template <class Store, class Tab = ZigTabConst>
 __device__ inline void wave_normals(Pcg64 &rng, long long n, Store store, const Tab &tab = Tab{}) {
   const int lane = threadIdx.x & 63;
-  const u128 Ak = (((u128)c_pcg_jump[lane][0]) << 64) | (u128)c_pcg_jump[lane][1];
-  const u128 GI = ((((u128)c_pcg_jump[lane][2]) << 64) | (u128)c_pcg_jump[lane][3]) * rng.inc;
+  const u128 Ak = mk128(c_pcg_jump[lane][0], c_pcg_jump[lane][1]);
+  const u128 GI = mul128(mk128(c_pcg_jump[lane][2], c_pcg_jump[lane][3]), rng.inc);
   long long pos = 0;  // normals delivered so far
   while (pos < n) {
-    const u128 sk = Ak * rng.state + GI;  // state after lane+1 steps
+    const u128 sk = muladd128(Ak, rng.state, GI);  // state after lane+1 steps
     const uint64_t raw = pcg_output(sk);
     const ZigDraw d = zig_fast(raw, tab);
     const unsigned long long fail = __ballot(!d.accept);

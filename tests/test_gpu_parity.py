@@ -276,6 +276,72 @@ def test_regression_nuts_row_counts_match_oracle(eng, N, metric_kind, max_exp):
     assert np.max(lengths) >= 3 and 0.1 < info.acceptance_probability.mean().item() <= 1.0  # real trajectories
 
 
+@pytest.mark.parametrize("family", ["nuts-linreg", "nuts-linreg-sample", "hmc-linreg", "hmc-fused-d1", "nuts-team1-sample",
+                                    "nuts-lockstep-d1", "nuts-wave-d1"])
+def test_rng_state_after_many_momentum_draws(eng, regression_data, family):
+    """Every kernel family that draws its momentum itself, with enough chains x transitions that the
+    ziggurat's redraw path (1.5 % of normals, a data-dependent loop on the generator state) is taken
+    dozens of times at small D: the per-chain generator states after the run equal numpy's / the
+    oracle's, and so do the discrete outputs.  (Round 2: with `unsigned __int128` state the compiler
+    lost the upper state word inside that loop in ONE instantiation -- k_nuts_resident<1,1> -- which no
+    test reached; rng.cuh now keeps explicit 64-bit halves.)"""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    r = np.random.default_rng(len(family))
+    C, T = 256, 4
+    seeds = [8000 + c for c in range(C)]
+    if "linreg" in family:
+        X, y = regression_data
+        tgt, otgt, D = targets.LinearRegression(X, y), co.Target(co.T_LINREG, 2, X=X, y=y), 2
+        imm, eps = np.array([2.13e-05, 4.43e-05]), 0.8
+        q0 = np.array([3.0, np.log(0.49)]) + 0.01 * r.normal(size=(C, 2))
+    else:
+        D = 1
+        mu, sigma, imm, eps = r.normal(size=D), 0.5 + r.random(D), 0.5 + r.random(D), 0.2
+        tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
+        q0 = r.normal(size=(C, D))
+    metric = co.Metric(imm, D)
+    q, U, g = co.new_state(otgt, q0.copy())
+    is_hmc = family.startswith("hmc")
+    rng = co.site_states(seeds, 2 if is_hmc else 4)
+    srng = RandomStream(seeds=seeds)
+    try:
+        if family == "nuts-team1-sample":
+            eng.set_option("resident_min_team", 1)
+        if family == "nuts-lockstep-d1":
+            eng.set_option("resident_nuts", 0)
+        if family == "nuts-wave-d1":
+            eng.set_option("resident_nuts", 1)
+        if is_hmc:
+            kernel = hmc.new_kernel(srng, tgt)
+            state = hmc.new_state(dev(q0), tgt)
+            _, info, _, _ = kernel.sample(state, eps, imm, 7, T)
+            for _ in range(T):
+                res = co.hmc_step(otgt, metric, rng, eps, 7, q, U, g)
+            rng_dev = kernel._hmc["holder"]["rng"] if hasattr(kernel, "_hmc") else None
+        else:
+            kernel = nuts.new_kernel(srng, tgt)
+            state = nuts.new_state(dev(q0), tgt)
+            if family.endswith("sample"):
+                _, info, _, _ = kernel.sample(state, eps, imm, T)
+            else:
+                for _ in range(T):
+                    info, _ = kernel(state, eps, imm)
+                    state = info.state._replace(momentum=None)
+            for _ in range(T):
+                res = co.nuts_step(otgt, metric, rng, eps, q, U, g)
+            rng_dev = kernel._nuts["holder"]["rng"]
+            assert np.array_equal(info.num_doublings.cpu().numpy().reshape(-1), res["num_doublings"])
+    finally:
+        eng.set_option("resident_min_team", 0)
+        eng.set_option("resident_nuts", 2)
+    if rng_dev is not None:
+        got = rng_dev.cpu().numpy().view(np.uint64).reshape(rng.shape)
+        bad = np.nonzero((got[:, :, :2] != rng[:, :, :2]).any(axis=(1, 2)))[0]
+        assert bad.size == 0, f"generator state differs for chains {bad.tolist()[:10]}"
+    np.testing.assert_allclose(info.state.position.cpu().numpy().reshape(q.shape), q, rtol=1e-7, atol=1e-10)
+    assert np.array_equal(info.is_diverging.cpu().numpy().reshape(-1), res["is_diverging"])
+
+
 # ------------------------------------------------------------------ helpers
 def make_case(kind, tkind, D, r):
     from aehmc_amd import targets
@@ -543,7 +609,7 @@ def test_nuts_resident_equals_lockstep_bitwise(eng, D, C):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("D,C", [(2, 70), (3, 33), (7, 50), (16, 9), (40, 19), (100, 13), (128, 5),
+@pytest.mark.parametrize("D,C", [(1, 300), (2, 70), (3, 33), (7, 50), (16, 9), (40, 19), (100, 13), (128, 5),
                                  (700, 4), (2048, 3), (3000, 3), (10000, 2)])
 def test_nuts_resident_teams_match_oracle(eng, D, C):
     """Sub-wavefront teams (D <= 128: 64/T chains per wave, divergent SIMT control flow) and

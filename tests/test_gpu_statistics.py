@@ -96,24 +96,42 @@ def test_nuts_mcse_matches_oracle():
     assert np.all(np.abs(gpu["mean"][0]) < 5 * gpu["mean"][1])
 
 
-def test_nuts_sample_equals_repeated_steps():
-    """nuts kernel.sample(N) == N calls of the kernel (host loop in the C-ABI)."""
+@pytest.mark.parametrize("D,C,min_team", [(20, 6, 0), (3, 50, 1), (10, 70, 1), (200, 5, 0), (1, 9, 1), (600, 3, 0)])
+def test_nuts_sample_equals_repeated_steps(D, C, min_team):
+    """nuts kernel.sample(N) == N calls of the kernel.  D <= 512: ONE launch of k_nuts_resident runs the N
+    transitions (teams of 64 lanes at D = 20 / 200, of 1 and 4 lanes with `resident_min_team`; the chains
+    of a wavefront start each transition together, wavefronts are independent); D = 600: host loop over
+    the workgroup-per-chain kernel.  Positions, acceptance, divergence per transition, leapfrog total,
+    final state and RNG state are identical."""
     from aehmc_amd import RandomStream, nuts, targets
-    r = np.random.default_rng(3)
-    D, C, N = 20, 6, 5
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    r = np.random.default_rng(3 + D)
+    N = 5
     q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
     tgt = targets.DiagGaussian(r.normal(size=D), 0.5 + r.random(D))
     k1 = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt)
     k2 = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt)
     s1 = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
-    samples, info, acc, div = k1.sample(s1, 0.2, imm, N)
-    s2, total = s1, 0
-    for t in range(N):
-        i2, _ = k2(s2, 0.2, imm)
-        s2 = i2.state._replace(momentum=None)
-        total = total + i2.n_leapfrog
-        assert torch.equal(samples[t], i2.state.position) and torch.equal(acc[t], i2.acceptance_probability)
-    assert torch.equal(info.n_leapfrog, total) and torch.equal(info.state.position, i2.state.position)
+    eng.set_option("resident_min_team", min_team)
+    try:
+        samples, info, acc, div = k1.sample(s1, 0.2, imm, N)
+        s2, total = s1, 0
+        for t in range(N):
+            i2, _ = k2(s2, 0.2, imm)
+            s2 = i2.state._replace(momentum=None)
+            total = total + i2.n_leapfrog
+            assert torch.equal(samples[t], i2.state.position), t
+            assert torch.equal(acc[t], i2.acceptance_probability), t
+            assert torch.equal(div[t].to(torch.int32), i2.is_diverging.to(torch.int32)), t
+    finally:
+        eng.set_option("resident_min_team", 0)
+    assert torch.equal(info.n_leapfrog, total)
+    for f in ("position", "potential_energy", "potential_energy_grad", "momentum"):
+        assert torch.equal(getattr(info.state, f), getattr(i2.state, f)), f
+    for f in ("acceptance_probability", "num_doublings", "is_turning", "is_diverging"):
+        assert torch.equal(getattr(info, f), getattr(i2, f)), f
+    assert torch.equal(k1._nuts["holder"]["rng"], k2._nuts["holder"]["rng"])
 
 
 def test_regression_nuts_sample_equals_repeated_steps(regression_data):
