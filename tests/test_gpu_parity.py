@@ -609,7 +609,7 @@ def test_nuts_resident_equals_lockstep_bitwise(eng, D, C):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("D,C", [(1, 300), (2, 70), (3, 33), (7, 50), (16, 9), (40, 19), (100, 13), (128, 5),
+@pytest.mark.parametrize("D,C", [(1, 300), (2, 70), (3, 33), (7, 50), (16, 9), (24, 21), (40, 19), (100, 13), (128, 5),
                                  (700, 4), (2048, 3), (3000, 3), (10000, 2)])
 def test_nuts_resident_teams_match_oracle(eng, D, C):
     """Sub-wavefront teams (D <= 128: 64/T chains per wave, divergent SIMT control flow) and

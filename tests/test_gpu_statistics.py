@@ -96,10 +96,12 @@ def test_nuts_mcse_matches_oracle():
     assert np.all(np.abs(gpu["mean"][0]) < 5 * gpu["mean"][1])
 
 
-@pytest.mark.parametrize("D,C,min_team", [(20, 6, 0), (3, 50, 1), (10, 70, 1), (200, 5, 0), (1, 9, 1), (600, 3, 0)])
+@pytest.mark.parametrize("D,C,min_team", [(20, 6, 0), (3, 50, 1), (10, 70, 1), (200, 5, 0), (1, 300, 1), (600, 3, 0),
+                                          (2, 40, 1), (7, 40, 1), (24, 20, 1), (40, 20, 1), (100, 12, 1), (100, 5, 0),
+                                          (400, 3, 0)])
 def test_nuts_sample_equals_repeated_steps(D, C, min_team):
     """nuts kernel.sample(N) == N calls of the kernel.  D <= 512: ONE launch of k_nuts_resident runs the N
-    transitions (teams of 64 lanes at D = 20 / 200, of 1 and 4 lanes with `resident_min_team`; the chains
+    transitions (every team size 1 ... 64 and every elements-per-lane variant of the kernel; the chains
     of a wavefront start each transition together, wavefronts are independent); D = 600: host loop over
     the workgroup-per-chain kernel.  Positions, acceptance, divergence per transition, leapfrog total,
     final state and RNG state are identical."""
