@@ -483,6 +483,36 @@ def test_dense_metric_not_positive_definite_is_an_error():
         kernel(state, 0.1, bad)
 
 
+@pytest.mark.parametrize("tk", ["std", "iso", "diag"])
+@pytest.mark.parametrize("D", [40, 100, 200, 400, 900, 1500, 3000, 6000, 9000])
+def test_hmc_every_fused_instantiation_matches_oracle(D, tk):
+    """One case per compiled variant of the single-launch HMC kernels: k_hmc_fused<R> for R = 1, 2, 4, 8,
+    16 elements per lane (D = 40 ... 900) and k_hmc_wide<256,8>, <512,8>, <1024,8>, <1024,10> (D = 1500
+    ... 9000), each for the three coordinate-wise targets -- three transitions through sample(), values,
+    acceptance, divergence and the generator state against the oracle.  (A compiler problem in one
+    instantiation of one kernel went unnoticed in round 1 because no test reached it.)"""
+    from aehmc_amd import RandomStream, hmc
+    r = np.random.default_rng(D + len(tk))
+    tgt, otgt, imm = make_case("diag", tk, D, r)
+    C, L, T = 5, 7, 3
+    seeds = [1500 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    eps = 0.25 / D ** 0.25
+    metric, rng = co.Metric(imm, D), co.site_states(seeds, 2)
+    q, U, g = co.new_state(otgt, q0.copy())
+    kernel = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
+    samples, info, acc, div = kernel.sample(hmc.new_state(dev(q0), tgt), eps, imm, L, T)
+    for t in range(T):
+        res = co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
+        np.testing.assert_allclose(samples[t].cpu().numpy(), q, rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(acc[t].cpu().numpy(), res["acceptance_probability"], rtol=RTOL)
+        assert np.array_equal(div[t].cpu().numpy(), res["is_diverging"])
+    check_state(info._replace(n_leapfrog=info.n_leapfrog // T), q, U, g, res, nuts=False)
+    got = kernel._hmc["holder"]["rng"].cpu().numpy().view(np.uint64).reshape(rng.shape)
+    assert np.array_equal(got[:, :, :2], rng[:, :, :2])
+    assert acc.mean().item() > 0.5
+
+
 @pytest.mark.parametrize("D,C,tk", [(1500, 5, "diag"), (3000, 3, "std"), (5000, 3, "iso"), (10000, 3, "diag")])
 def test_hmc_resident_large_d_matches_oracle(eng, D, C, tk):
     """D > 1024: momentum pre-pass (one wavefront per chain) + one workgroup per chain with the
@@ -669,6 +699,33 @@ def test_nuts_wide_deep_trees_match_oracle(D, tk):
         state = info.state._replace(momentum=None)
         deepest = max(deepest, int(res["num_doublings"].max()))
     assert deepest >= 8, deepest
+
+
+@pytest.mark.parametrize("tk", ["std", "iso", "diag"])
+@pytest.mark.parametrize("D", [700, 1500, 3000, 6000, 9000])
+def test_nuts_every_wide_instantiation_matches_oracle(D, tk):
+    """One case per compiled variant of the workgroup-per-chain NUTS kernel: k_nuts_wide<256,4>, <256,8>,
+    <512,8>, <512,16,q in LDS>, <512,20,q in LDS> (D = 700 ... 9000) x the three coordinate-wise
+    targets; trees of 4-6 doublings, two transitions, values, discrete outputs and generator state."""
+    from aehmc_amd import RandomStream, nuts
+    r = np.random.default_rng(3 * D + len(tk))
+    tgt, otgt, imm = make_case("diag", tk, D, r)
+    C = 3
+    seeds = [60 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    eps = 0.05 / D ** 0.25
+    srng = RandomStream(seeds=seeds)
+    kernel = nuts.new_kernel(srng, tgt)
+    state = nuts.new_state(dev(q0), tgt)
+    rng, metric = co.site_states(seeds, 4), co.Metric(imm, D)
+    q, U, g = co.new_state(otgt, q0.copy())
+    for _ in range(2):
+        info, updates = kernel(state, eps, imm)
+        res = co.nuts_step(otgt, metric, rng, eps, q, U, g)
+        check_state(info, q, U, g, res)
+        assert np.array_equal(updates[srng].cpu().numpy().view(np.uint64)[:, :, :2], rng[:, :, :2])
+        state = info.state._replace(momentum=None)
+    assert res["num_doublings"].max() >= 4
 
 
 def test_nuts_fused_equals_lockstep_bitwise(eng):
