@@ -738,6 +738,20 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
   FAIL("new_state: target kind not implemented");
 }
 
+// which kernel family a NUTS call takes (one place: aehmc_nuts_warmup asks before it commits to a
+// single-launch warm-up)
+enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE };
+static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions) {
+  const int tkind = ctx->tgt.kind, nd = ctx->met.ndim;
+  const int64_t D = ctx->tgt.D;
+  if (ctx->opt_resident_nuts && nuts_linreg_supported(tkind, nd, D, max_num_expansions)) return NUTS_PATH_LINREG;
+  const bool want_resident =
+      ctx->opt_resident_nuts == 1 || (ctx->opt_resident_nuts == 2 && (D > 256 || C >= 16384 || C <= 2048));
+  if (want_resident && nuts_resident_supported(tkind, nd, D)) return NUTS_PATH_TEAMS;  // D <= 512
+  if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
+  return NUTS_PATH_LOCKSTEP;
+}
+
 // One NUTS transition of every chain.  `multi` (optional): the caller wants multi->T transitions with
 // per-transition outputs; a kernel that runs them all in one launch does so and sets *multi_done,
 // otherwise ONE transition is run and the caller loops.
@@ -760,7 +774,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   // a few thousand chains of small D run faster in lock step.  The regression target always
   // takes its workgroup-cooperative resident kernel (nuts_linreg.cuh), which also runs any number
   // of consecutive transitions in one launch.
-  if (ctx->opt_resident_nuts && nuts_linreg_supported(a.tkind, a.met_ndim, a.D, max_num_expansions)) {
+  if (nuts_path(ctx, C, max_num_expansions) == NUTS_PATH_LINREG) {
     NutsSampleArgs m{};
     m.T = 1;
     if (multi) {
@@ -772,14 +786,11 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     HIPCHK(launch_nuts_linreg(a, m, st));
     return prof_end(ctx, st, p);
   }
-  const bool want_resident =
-      ctx->opt_resident_nuts == 1 ||
-      (ctx->opt_resident_nuts == 2 &&
-       (a.D > 256 || C >= 16384 || C <= 2048));
-  if (want_resident && (nuts_resident_supported(a.tkind, a.met_ndim, a.D) || nuts_wide_supported(a.tkind, a.met_ndim, a.D))) {
+  const int path = nuts_path(ctx, C, max_num_expansions);
+  if (path == NUTS_PATH_TEAMS || path == NUTS_PATH_WIDE) {
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (a.D > 512) {  // one workgroup per chain (nuts_wide.cuh): momentum drawn at one wavefront per chain first
+    if (path == NUTS_PATH_WIDE) {  // one workgroup per chain (nuts_wide.cuh): momentum drawn at one wavefront per chain first
       a.ldw = nuts_wide_ld(a.D);
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, a.rng, a.nsites, (long long)C,
                          (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf, a.ldw);
@@ -868,11 +879,13 @@ extern "C" int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64
   if (!ctx->has_tgt) FAIL("set_target and set_metric must be called first");
   if (!ctx->eps_c || !ctx->met.per_chain) FAIL("warm-up needs per-chain step sizes and a per-chain metric bound to the adaptation state");
   const int64_t D = ctx->tgt.D;
-  // regression target, diagonal mass matrix: the whole warm-up in ONE launch, every chain adapting
-  // and moving on at its own pace (nuts_linreg.cuh) -- the same arithmetic as the loop below
-  if (num_steps > 0 && ctx->opt_resident_nuts && !state->full && ctx->has_met && ctx->met.ndim == 1 &&
-      ctx->met.imm == state->imm && ctx->met.sqrt_mass == state->sqrt_mass && ctx->eps_c == state->step_size &&
-      nuts_linreg_supported(ctx->tgt.kind, ctx->met.ndim, D, max_num_expansions)) {
+  // diagonal mass matrix, regression target or a coordinate-wise target with D <= 512: the whole warm-up
+  // in ONE launch, the chains adapting and moving on at their own pace (nuts_linreg.cuh: every chain;
+  // nuts_resident.cuh: every wavefront) -- the same arithmetic as the loop below
+  const int path = ctx->has_met ? nuts_path(ctx, C, max_num_expansions) : NUTS_PATH_LOCKSTEP;
+  if (num_steps > 0 && (path == NUTS_PATH_LINREG || path == NUTS_PATH_TEAMS) && !state->full && ctx->met.ndim == 1 &&
+      ctx->met.per_chain && ctx->met.imm == state->imm && ctx->met.sqrt_mass == state->sqrt_mass &&
+      ctx->eps_c == state->step_size) {
     hipStream_t st = (hipStream_t)stream;
     AdaptArgs aa;
     if (int rc = adapt_args(ctx, C, D, state, aa)) return rc;

@@ -102,6 +102,20 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
   rng = rng_load(a, c);
   double U_state = MULTI ? a.U[c] : 0.0;  // the chain's potential energy between transitions
   long long nleap_sum = 0;
+  // window adaptation inside the launch (m.adapt; window_adaptation.py:17-116, diagonal mass matrix, one
+  // row of the state arrays per chain): the team's scalars in registers, Welford sums / metric in memory
+  DualAvg da = {1, 0.0, 0.0, 0.0, 0.0};
+  long long wc_n = 0;
+  double eps_adapt = 0.0;
+  if (MULTI && m.adapt) {
+    da.step = m.ad.da_step[c];
+    da.x = m.ad.da_x[c];
+    da.x_avg = m.ad.da_x_avg[c];
+    da.g_avg = m.ad.da_g_avg[c];
+    da.mu = m.ad.da_mu[c];
+    wc_n = m.ad.wc_n[c];
+    eps_adapt = m.ad.step_size[c];
+  }
   // m.T consecutive transitions in this launch (the user-level scan of tests/test_hmc.py:296-324): the
   // chains of a wavefront start each transition together, wavefronts run independently of each other
   for (long long t_idx = 0; t_idx < (MULTI ? m.T : 1); t_idx++) {
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
     ct.step = 0;
   }
   }
-  const double eps = a.eps_c ? a.eps_c[c] : a.eps;
+  const double eps = (MULTI && m.adapt) ? eps_adapt : (a.eps_c ? a.eps_c[c] : a.eps);
 
   while (!ct.done) {
     // ---- one leapfrog of the moving end, in registers (integrators.py:54-73) ---------
@@ -460,10 +474,52 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
     if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
     if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
   }
+  if (MULTI && m.adapt) {  // the update of k_adapt_update, same order: step size, Welford, window end, last
+    const int stage = m.stage[t_idx], wend = m.window_end[t_idx];
+    double step_size = adapt_da_update(da, m.target, ct.acc_prob, m.gamma, m.t0, m.kappa);
+    if (stage != 0) {
+      wc_n += 1;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (ok[r]) {
+          double mean = AT(m.ad.wc_mean, r), m2 = AT(m.ad.wc_m2, r);
+          adapt_welford_elem(AT(a.q, r), wc_n, mean, m2);
+          AT(m.ad.wc_mean, r) = mean;
+          AT(m.ad.wc_m2, r) = m2;
+        }
+    }
+    if (wend) {
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (ok[r]) {
+          double mean = AT(m.ad.wc_mean, r), m2 = AT(m.ad.wc_m2, r), imm, sqrt_mass;
+          adapt_window_end_elem(wc_n, mean, m2, imm, sqrt_mass);
+          AT(m.ad.imm, r) = imm;  // (== a.imm / a.sqrt_mass: the metric bound to this call)
+          AT(m.ad.sqrt_mass, r) = sqrt_mass;
+          AT(m.ad.wc_mean, r) = mean;
+          AT(m.ad.wc_m2, r) = m2;
+          if (IM_REG) imr[IM_REG ? r : 0] = imm;
+        }
+      wc_n = 0;
+      adapt_da_restart(da, step_size);
+      __threadfence_block();  // the next momentum draw reads other lanes' sqrt_mass elements
+    }
+    if (t_idx == m.T - 1) step_size = exp(da.x_avg);  // window_adaptation.py:184-190
+    eps_adapt = step_size;
+  }
   }  // transitions
   if (lead) {
     if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
     if (MULTI && m.nleap_total) m.nleap_total[c] = nleap_sum;
+    if (MULTI && m.adapt) {
+      m.ad.da_step[c] = da.step;
+      m.ad.da_x[c] = da.x;
+      m.ad.da_x_avg[c] = da.x_avg;
+      m.ad.da_g_avg[c] = da.g_avg;
+      m.ad.da_mu[c] = da.mu;
+      m.ad.wc_n[c] = wc_n;
+      m.ad.step_size[c] = eps_adapt;
+    }
     if (MULTI) pcg_store(a.rng + ((size_t)c * a.nsites + 0) * 4, rng.g[0]);
     pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, rng.g[1]);
     pcg_store(a.rng + ((size_t)c * a.nsites + 2) * 4, rng.g[2]);
@@ -488,7 +544,7 @@ inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
 template <int T, int R>
 inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
   const unsigned grid = Team<T>::SUB ? (unsigned)((a.C * T + 255) / 256) : (unsigned)((a.C + 3) / 4);
-  const bool multi = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total;
+  const bool multi = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total || m.adapt;
   if (multi) hipLaunchKernelGGL((k_nuts_resident<T, R, true>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a, m);
   else hipLaunchKernelGGL((k_nuts_resident<T, R, false>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a, m);
   return hipGetLastError();

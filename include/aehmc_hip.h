@@ -194,9 +194,10 @@ int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t stage, int3
  * `is_window_end` [num_steps] are HOST arrays from build_schedule.  Before the call the caller binds
  * the per-chain metric to state->imm / state->sqrt_mass (aehmc_set_metric, per_chain = 1) and the step
  * sizes to state->step_size (aehmc_set_step_sizes); the update kernel rewrites them in place.
- * `out` receives the diagnostics of the last warm-up transition.  Regression target with a diagonal
- * mass matrix: the whole warm-up is ONE launch in which every chain adapts and moves on at its own
- * pace (same arithmetic, same results as the loop). */
+ * `out` receives the diagnostics of the last warm-up transition.  Diagonal mass matrix with the
+ * regression target, or with a coordinate-wise target of D <= 512 on the register-resident kernel:
+ * the whole warm-up is ONE launch in which the chains adapt and move on at their own pace (same
+ * arithmetic, same results as the loop). */
 int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t num_steps, const int32_t *stage,
                       const int32_t *is_window_end, double target_acceptance_rate,
                       int64_t max_num_expansions, double divergence_threshold, double *q, double *U,
@@ -204,8 +205,8 @@ int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t num_step
 
 /* num_samples consecutive NUTS transitions per chain (the user-level scan of
  * tests/test_hmc.py:296-324); same optional outputs as aehmc_hmc_sample plus the per-chain
- * leapfrog total [C].  `out` describes the last transition.  (Regression target: one launch for all
- * num_samples transitions.) */
+ * leapfrog total [C].  `out` describes the last transition.  (Regression target and register-resident
+ * kernel, D <= 512: one launch for all num_samples transitions.) */
 int aehmc_nuts_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
                       int64_t max_num_expansions, double divergence_threshold, int64_t num_samples,
                       double *q, double *U, double *g, const aehmc_diagnostics *out, double *samples,

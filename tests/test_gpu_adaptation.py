@@ -374,3 +374,37 @@ def test_regression_warmup_in_one_launch_equals_step_by_step(regression_data, C,
         assert torch.equal(a, b), k
     e = outs[0][3].cpu().numpy()
     assert np.isfinite(e).all() and (e > 0).all() and len(np.unique(e)) == C  # per-chain step sizes
+
+
+@pytest.mark.parametrize("D,C", [(1, 70), (2, 40), (3, 33), (10, 20), (24, 9), (40, 9), (100, 5), (200, 4), (400, 3)])
+def test_warmup_in_one_launch_every_team_size(D, C):
+    """Coordinate-wise targets, D <= 512, diagonal mass matrix: the whole warm-up is one launch of
+    k_nuts_resident (every team size / elements-per-lane variant, `resident_min_team`); the chains of a
+    wavefront adapt after each of their transitions (Welford sums and the metric in the adaptation
+    state's own arrays, the team's dual-averaging scalars in registers) and wavefronts do not wait for
+    each other.  Equal to the step-by-step loop bit for bit: state, parameters, next transition, RNG."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    r = np.random.default_rng(7 * D + C)
+    mu, sigma = r.normal(size=D), 0.5 + r.random(D)
+    tgt = targets.DiagGaussian(mu, sigma)
+    q0 = mu + sigma * r.normal(size=(C, D))
+    outs = []
+    eng.set_option("resident_min_team", 1)
+    try:
+        for fused in (True, False):
+            srng = RandomStream(seeds=[300 + c for c in range(C)])
+            kernel = nuts.new_kernel(srng, tgt)
+            state = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+            state, (eps, imm), upd = window_adaptation.run(kernel, state, 110, fused=fused)
+            info, upd = kernel(state, eps, imm)
+            outs.append((state.position.clone(), state.potential_energy.clone(), eps.value.clone(), imm.value.clone(),
+                         imm.sqrt_mass.clone(), info.state.position.clone(), info.n_leapfrog.clone(),
+                         upd[srng].clone()))
+    finally:
+        eng.set_option("resident_min_team", 0)
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), k
+    m = outs[0][3].cpu().numpy()
+    assert np.isfinite(m).all() and (m > 0).all() and not np.allclose(m, 1.0)  # the metric did adapt
