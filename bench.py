@@ -52,6 +52,27 @@ def build_c3(D, device, rho=0.5):
     return Sigma.contiguous(), P.contiguous()
 
 
+def other_configs():
+    """The other single-GPU BASELINE configs (c1, c2, c5) as further `secondary` entries of the default
+    line, so that their numbers are in the driver's record too: each runs in a child process of its own
+    (`bench.py --config cN --no-cpu-baseline`, default steps), after this process's own measurements."""
+    out = []
+    for cfg in ("c2", "c5", "c1"):
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK",
+                                                                     "TORCHELASTIC_RUN_ID")}
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--no-cpu-baseline"],
+                               capture_output=True, text=True, timeout=300, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(line[-1])
+            out.append({"config": cfg, "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+                        "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+                        "roofline": d.get("roofline"), "valu": d.get("valu")})
+        except Exception as e:  # a failing side measurement must not cost the main line
+            out.append({"config": cfg, "error": repr(e)[:300]})
+    return out
+
+
 def diag_case(kind, D, C, device):
     """Secondary workloads (diagonal / scalar mass: HBM-bound): D-dim isotropic Gaussian,
     diagonal inverse mass matrix of ones, eps = 0.5 D^-1/4, C chains; `kind` nuts (default depth) or
@@ -109,7 +130,8 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
                 "note": "achieved = counted HBM bytes per transition / kernel time; the chain state is on chip, so the "
                         "counted bytes are far below the streaming figure (48 D / 88 D per leapfrog)"}
         roof["frac"] = roof["achieved"] / PEAK_HBM_GBS if traffic else None
-        out.append({"workload": f"{D}-dim isotropic Gaussian, diagonal mass, {'NUTS depth 10' if kind == 'nuts' else 'HMC L=32'}, "
+        out.append({"config": f"diag-{kind}",
+                    "workload": f"{D}-dim isotropic Gaussian, diagonal mass, {'NUTS depth 10' if kind == 'nuts' else 'HMC L=32'}, "
                                 f"{C} chains", "value": nl / dt, "unit": "leapfrog-steps/s", "ms_per_transition": dt / (steps * per_call) * 1e3,
                     "leapfrogs_per_transition": nl / (steps * per_call), "roofline": roof})
     return out
@@ -312,6 +334,7 @@ def main():
         del state, info, kernel, target, imm, gathered
         torch.cuda.empty_cache()
         secondary = bench_secondary(eng, device, max(args.steps, 3), 2)
+        secondary += other_configs()
 
     print(json.dumps({
         "metric": "leapfrog-steps/sec across all chains", "value": value, "unit": "leapfrog-steps/s",
