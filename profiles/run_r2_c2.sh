@@ -14,3 +14,4 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_IN
   rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$tag -o c2 -- $CMD > $O/pmc_$tag.log 2>&1
 done
 python3 $R/profiles/summarize_r2_diag.py $O | grep -E "k_hmc_fused"
+python3 $R/profiles/summarize_r2_c2.py $O
