@@ -300,7 +300,8 @@ def main():
                     "kernel": "gemm_nt_f64_streamk_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
                     "avg_rows_per_launch": flops / (2.0 * D * D), "gemm_share_of_step_time": kern_ms / 1e3 / elapsed,
                     "parity_note": "c3's arithmetic is the dense branch, which no reference value pins (SURVEY.md 8c): parity "
-                                   "is HIP == C restatement, checked at this depth in tests/test_gpu_configs.py"}
+                                   "is HIP == C restatement, checked at this depth in tests/test_gpu_configs.py, and c3 == the isotropic "
+                                   "D=1e4 problem on the diagonal kernels under q' = chol(Sigma) q (same file)"}
     else:
         # fused HMC kernel (100 transitions per launch, state in registers): the HBM traffic is the I/O of a
         # launch, counted by rocprofv3; the kernel is bound by fp64 VALU issue (profiles/r2/c2_pmc_summary.json)

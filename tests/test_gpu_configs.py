@@ -159,3 +159,51 @@ def test_config4_two_gpu_shard(c3_model):
         assert torch.equal(i2.state.position, pos[sl])
         assert torch.equal(i2.acceptance_probability, acc[sl])
         assert torch.equal(i2.n_leapfrog, info.n_leapfrog[sl])
+
+
+@pytest.mark.timeout(900)
+def test_config3_equals_the_isotropic_problem_under_its_cholesky_map(c3_model):
+    """c3 AS BENCHMARKED against an independent kernel family through an exact invariance.  A NUTS
+    transition is equivariant under q' = L q for lower-triangular L (tests/test_oracle_golden.py:
+    test_dense_branch_equals_diagonal_branch_under_triangular_map).  c3's metric is Sigma = L L^T and its
+    target precision is Sigma^-1, so c3 is the image under L = chol(Sigma) of the D = 1e4 ISOTROPIC
+    Gaussian with the identity (diagonal) metric at the same step size -- bench.py's secondary NUTS
+    workload, which runs on k_nuts_wide (registers / LDS, no GEMM) instead of the lock-step MFMA path.
+    64 chains, depth 10, two transitions, same seeds: identical leapfrog counts, doublings and flags,
+    identical RNG consumption, q'_t = L q_t, equal energies and acceptance probabilities.  The diagonal
+    branch is pinned by the reference's golden values; this carries that to c3's dense arithmetic
+    (dense-MVN gradient GEMM, metric GEMM, L^-T momentum, dense U-turn and kinetic products) at full D."""
+    from aehmc_amd import RandomStream, nuts, targets
+    Sigma, P = c3_model
+    C = 64
+    L = torch.linalg.cholesky(Sigma)
+    seeds = [4000 + c for c in range(C)]
+    q_iso = torch.as_tensor(np.random.default_rng(77).standard_normal((C, D)), device="cuda")
+    q_c3 = q_iso @ L.T
+    mu = torch.zeros(D, dtype=torch.float64, device="cuda")
+    runs = {}
+    for name, tgt, imm, q0 in (("c3", targets.DenseMVN(mu, P), Sigma, q_c3),
+                               ("iso", targets.IsoGaussian(), torch.ones(D, dtype=torch.float64, device="cuda"), q_iso)):
+        srng = RandomStream(seeds=seeds)
+        kernel = nuts.new_kernel(srng, tgt, max_num_expansions=10)
+        state = nuts.new_state(q0.clone(), tgt)
+        infos = []
+        for _ in range(2):
+            info, upd = kernel(state, EPS, imm)
+            state = info.state._replace(momentum=None)
+            infos.append(info)
+        runs[name] = (infos, upd[srng].clone())
+    for t in range(2):
+        a, b = runs["c3"][0][t], runs["iso"][0][t]
+        for f in ("n_leapfrog", "num_doublings", "is_turning", "is_diverging"):
+            assert torch.equal(getattr(a, f), getattr(b, f)), (t, f)
+        scale = a.state.position.abs().max().item()
+        assert (a.state.position - b.state.position @ L.T).abs().max().item() < 1e-9 * scale
+        assert (a.state.momentum @ L - b.state.momentum).abs().max().item() < 1e-8           # p' = L^-T p
+        np.testing.assert_allclose(a.state.potential_energy.cpu().numpy(), b.state.potential_energy.cpu().numpy(),
+                                   rtol=1e-10)
+        np.testing.assert_allclose(a.acceptance_probability.cpu().numpy(), b.acceptance_probability.cpu().numpy(),
+                                   rtol=1e-8)
+    assert torch.equal(runs["c3"][1], runs["iso"][1])
+    nl = runs["c3"][0][0].n_leapfrog
+    assert nl.max().item() >= 33 and len(torch.unique(nl)) >= 2  # real, unequal trees

@@ -343,6 +343,60 @@ def test_rng_state_after_many_momentum_draws(eng, regression_data, family):
     assert np.array_equal(info.is_diverging.cpu().numpy().reshape(-1), res["is_diverging"])
 
 
+@pytest.mark.parametrize("D,sampler", [(200, "nuts"), (64, "nuts"), (200, "hmc"), (700, "nuts")])
+def test_dense_path_equals_diagonal_path_under_triangular_map(D, sampler):
+    """The product's dense path (dense-MVN target + dense inverse mass matrix: fp64 MFMA GEMMs, L^-T
+    momentum, lock-step engine) against its diagonal path (resident kernels) through the invariance of
+    tests/test_oracle_golden.py::test_dense_branch_equals_diagonal_branch_under_triangular_map: the image
+    of a diagonal problem under a lower-triangular map q' = A q has the same tree shapes, RNG
+    consumption and acceptance, and q'_t = A q_t.  Both dense modes (`dense_linear` 1 / 0)."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    r = np.random.default_rng(D)
+    mu, sigma, m = r.normal(size=D), 0.5 + r.random(D), 0.5 + r.random(D)
+    A = np.diag(0.7 + 0.6 * r.random(D)) + 0.3 * np.tril(r.normal(size=(D, D)), -1) / np.sqrt(D)
+    Ainv = np.linalg.inv(A)
+    P = Ainv.T @ np.diag(1 / sigma ** 2) @ Ainv
+    imm = A @ np.diag(m) @ A.T
+    P, imm = 0.5 * (P + P.T), 0.5 * (imm + imm.T)
+    C, eps = 9, 0.3 / D ** 0.25
+    seeds = [90 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    mod = nuts if sampler == "nuts" else hmc
+    extra = () if sampler == "nuts" else (11,)
+
+    def run(tgt, metric, start, mode):
+        eng.set_option("dense_linear", mode)
+        srng = RandomStream(seeds=seeds)
+        kernel = mod.new_kernel(srng, tgt)
+        state = mod.new_state(dev(start), tgt)
+        outs = []
+        for _ in range(3):
+            info, upd = kernel(state, eps, metric, *extra)
+            state = info.state._replace(momentum=None)
+            outs.append(info)
+        return outs, upd[srng].cpu().numpy().copy()
+
+    try:
+        diag, rng_d = run(targets.DiagGaussian(mu, sigma), m, q0, 1)
+        for mode in (1, 0):
+            dense, rng_m = run(targets.DenseMVN(A @ mu, P), imm, q0 @ A.T, mode)
+            for a, b in zip(dense, diag):
+                assert torch.equal(a.n_leapfrog, b.n_leapfrog) and torch.equal(a.is_diverging, b.is_diverging)
+                if sampler == "nuts":
+                    assert torch.equal(a.num_doublings, b.num_doublings) and torch.equal(a.is_turning, b.is_turning)
+                np.testing.assert_allclose(a.state.position.cpu().numpy(), b.state.position.cpu().numpy() @ A.T,
+                                           rtol=1e-9, atol=1e-10)
+                np.testing.assert_allclose(a.state.momentum.cpu().numpy(), b.state.momentum.cpu().numpy() @ Ainv,
+                                           rtol=1e-8, atol=1e-9)
+                np.testing.assert_allclose(a.acceptance_probability.cpu().numpy(),
+                                           b.acceptance_probability.cpu().numpy(), rtol=1e-9)
+            assert np.array_equal(rng_m, rng_d)
+    finally:
+        eng.set_option("dense_linear", 1)
+
+
 # ------------------------------------------------------------------ helpers
 def make_case(kind, tkind, D, r):
     from aehmc_amd import targets

@@ -266,3 +266,67 @@ def test_c_matches_numpy_hmc():
         st = info.state._replace(momentum=None)
         np.testing.assert_allclose(q[0], info.state.position, rtol=1e-12, atol=1e-14)
         assert res["acceptance_probability"][0] == pytest.approx(info.acceptance_probability, rel=1e-10)
+
+
+# ------------------------------------------------------------------ the dense branch against the pinned diagonal branch
+def _triangular_pair(D, seed):
+    """A diagonal problem (DiagGaussian(mu, sigma), inverse mass diag m) and its image under q' = A q
+    with A LOWER TRIANGULAR (positive diagonal): dense MVN(A mu, A^-T diag(sigma^-2) A^-1) with the
+    dense inverse mass matrix A diag(m) A^T, whose Cholesky factor is exactly A diag(sqrt m)."""
+    r = np.random.default_rng(seed)
+    mu, sigma, m = r.normal(size=D), 0.5 + r.random(D), 0.5 + r.random(D)
+    A = np.diag(0.7 + 0.6 * r.random(D)) + 0.3 * np.tril(r.normal(size=(D, D)), -1) / np.sqrt(D)
+    Ainv = np.linalg.inv(A)
+    P = Ainv.T @ np.diag(1 / sigma ** 2) @ Ainv
+    imm = A @ np.diag(m) @ A.T
+    return mu, sigma, m, A, 0.5 * (P + P.T), 0.5 * (imm + imm.T)
+
+
+@pytest.mark.parametrize("sampler", ["nuts", "hmc"])
+def test_dense_branch_equals_diagonal_branch_under_triangular_map(sampler):
+    """No reference value exists for a dense-metric trajectory.  But the whole transition
+    is equivariant under q' = A q for lower-triangular A: the momentum L'^-T z of the mapped problem is
+    A^-T applied to the diagonal problem's sqrt(1/m) z (same draws z), leapfrogs, energies, U-turn
+    products and acceptance probabilities coincide, so the chains satisfy q'_t = A q_t with IDENTICAL
+    tree shapes and RNG consumption -- in exact arithmetic, and to rounding here.  This ties every
+    dense-branch operation of both restatements (Cholesky / L^-T momentum, dense velocity, kinetic
+    energy, is_turning, dense-MVN gradient) to the diagonal branch, which the reference's golden values
+    pin (G1, G2, the unit tables)."""
+    D, C = 7, 5
+    mu, sigma, m, A, P, imm = _triangular_pair(D, 1)
+    q0 = np.random.default_rng(2).normal(size=(C, D))
+    seeds = [10 + c for c in range(C)]
+    ns = 4 if sampler == "nuts" else 2
+    td, tm = co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma), co.Target(co.T_DENSE_MVN, D, mu=A @ mu, prec=P)
+    md, mm = co.Metric(m, D), co.Metric(imm, D)
+    rd, rm = co.site_states(seeds, ns), co.site_states(seeds, ns)
+    qd, Ud, gd = co.new_state(td, q0.copy())
+    qm, Um, gm = co.new_state(tm, (q0 @ A.T).copy())
+    const = Ud[0] - Um[0]  # sum(log sigma) + D log sqrt(2 pi): the dense-MVN potential carries no constant
+    for t in range(4):
+        if sampler == "nuts":
+            a = co.nuts_step(td, md, rd, 0.3, qd, Ud, gd, max_exp=7)
+            b = co.nuts_step(tm, mm, rm, 0.3, qm, Um, gm, max_exp=7)
+            assert a["num_doublings"].tolist() == b["num_doublings"].tolist()
+            assert a["is_turning"].tolist() == b["is_turning"].tolist()
+        else:
+            a = co.hmc_step(td, md, rd, 0.3, 9, qd, Ud, gd)
+            b = co.hmc_step(tm, mm, rm, 0.3, 9, qm, Um, gm)
+        assert a["n_leapfrog"].tolist() == b["n_leapfrog"].tolist() and a["is_diverging"].tolist() == b["is_diverging"].tolist()
+        np.testing.assert_allclose(qm, qd @ A.T, rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(b["momentum"], a["momentum"] @ np.linalg.inv(A), rtol=1e-10, atol=1e-11)  # p' = A^-T p
+        np.testing.assert_allclose(Um, Ud - const, rtol=1e-11)
+        np.testing.assert_allclose(gm, gd @ np.linalg.inv(A), rtol=1e-10, atol=1e-11)                          # g' = A^-T g
+        np.testing.assert_allclose(b["acceptance_probability"], a["acceptance_probability"], rtol=1e-11)
+        assert np.array_equal(rd, rm)  # same RNG consumption at every site
+    if sampler == "nuts":  # ... and the numpy restatement's dense branch on chain 0
+        kern = no.nuts_kernel(no.RandomStream(seeds[0]), no.DenseMVN(A @ mu, P), max_num_expansions=7)
+        st = no.new_state(A @ q0[0], no.DenseMVN(A @ mu, P))
+        rd0 = co.site_states(seeds[:1], 4)
+        q1, U1, g1 = co.new_state(td, q0[:1].copy())
+        for t in range(3):
+            info = kern(st, 0.3, imm)
+            st = info.state._replace(momentum=None)
+            res = co.nuts_step(td, md, rd0, 0.3, q1, U1, g1, max_exp=7)
+            assert info.n_leapfrog == res["n_leapfrog"][0] and info.num_doublings == res["num_doublings"][0]
+            np.testing.assert_allclose(info.state.position, A @ q1[0], rtol=1e-10, atol=1e-12)
