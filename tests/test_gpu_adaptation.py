@@ -408,3 +408,32 @@ def test_warmup_in_one_launch_every_team_size(D, C):
         assert torch.equal(a, b), k
     m = outs[0][3].cpu().numpy()
     assert np.isfinite(m).all() and (m > 0).all() and not np.allclose(m, 1.0)  # the metric did adapt
+
+
+def test_regression_window_adaptation_matches_oracle(regression_data):
+    """c5's pipeline end to end against the restatements on identical seeds: window_adaptation.run on the
+    regression posterior (the one-launch warm-up of k_nuts_linreg) vs oracle/np_adaptation driven by
+    the C oracle's NUTS kernel, chain by chain -- step sizes, inverse mass matrices and the state after
+    warm-up.  As in test_window_adaptation_matches_oracle the horizon is short (60 steps: fast buffer,
+    one slow window with its mass-matrix update, fast buffer) because the adaptation loop feeds the
+    step size back into the trajectory and amplifies last-bit differences."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    X, y = regression_data
+    C, num_steps = 3, 60
+    r = np.random.default_rng(9)
+    tgt, otgt = targets.LinearRegression(X, y), co.Target(co.T_LINREG, 2, X=X, y=y)
+    seeds = [660 + c for c in range(C)]
+    q0 = np.array([3.0, np.log(0.49)]) + 0.01 * r.normal(size=(C, 2))
+    kernel = nuts.new_kernel(RandomStream(seeds=seeds), tgt)
+    state = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+    last, (eps, imm), _ = window_adaptation.run(kernel, state, num_steps)
+    eps_g, imm_g, pos_g = eps.value.cpu().numpy(), imm.value.cpu().numpy(), last.position.cpu().numpy()
+    otarget = no.LinearRegression(X, y)
+    for c in range(C):
+        ok = OracleNuts(otgt, seeds[c], 2)
+        Uo, go = otarget(q0[c])
+        st = no.IntegratorState(q0[c], None, Uo, go)
+        st, (eps_o, imm_o) = na.run(ok, st, num_steps)
+        assert eps_g[c] == pytest.approx(eps_o, rel=1e-6)
+        np.testing.assert_allclose(imm_g[c], imm_o, rtol=1e-6)
+        np.testing.assert_allclose(pos_g[c], st.position, rtol=1e-6, atol=1e-9)
