@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_ctl_get_U(EngineArgs a, double *U) {
 }
 __global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C, long long n,
                                                      double *out) {
-  __shared__ double ztab[512];
+  __shared__ double ztab[ZIG_LDS_DOUBLES];
   const ZigTabLds tab = zig_tab_to_lds(ztab);
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C,
 __global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites, long long C, long long D,
                                                        const double *sqrt_mass, long long sm_cs, int met_ndim,
                                                        double *zbuf, long long ld) {
-  __shared__ double ztab[512];
+  __shared__ double ztab[ZIG_LDS_DOUBLES];
   const ZigTabLds tab = zig_tab_to_lds(ztab);
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;

@@ -51,7 +51,7 @@ inline bool hmc_fused_supported(int tkind, int met_ndim, long long D) {
 template <int R, int TK>
 __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double zlds[];  // [4 waves][R*64]
-  __shared__ double ztab[512];
+  __shared__ double ztab[ZIG_LDS_DOUBLES];
   const ZigTabLds tab = zig_tab_to_lds(ztab);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long c = (long long)blockIdx.x * 4 + w;

@@ -86,25 +86,31 @@ struct ZigDraw {
 };
 // where the fast path reads its two tables: constant memory (wave-uniform index -> scalar
 // loads) or a copy in LDS (per-lane index: ~5x shorter latency than the vector-memory path)
+constexpr int ZIG_LDS_DOUBLES = 768;  // wi, ki, fi: 256 entries each
 struct ZigTabConst {
   __device__ __forceinline__ double wi(int i) const { return c_zig_wi[i]; }
   __device__ __forceinline__ uint64_t ki(int i) const { return c_zig_ki[i]; }
+  __device__ __forceinline__ double fi(int i) const { return c_zig_fi[i]; }
 };
 struct ZigTabLds {
   const double *w;
   const uint64_t *k;
+  const double *f;
   __device__ __forceinline__ double wi(int i) const { return w[i]; }
   __device__ __forceinline__ uint64_t ki(int i) const { return k[i]; }
+  __device__ __forceinline__ double fi(int i) const { return f[i]; }
 };
-// copies the fast-path tables into `lds` (512 x 8 B); every thread of the block must call it
+// copies the tables into `lds` (ZIG_LDS_DOUBLES x 8 B); every thread of the block must call it
 __device__ __forceinline__ ZigTabLds zig_tab_to_lds(double *lds) {
   uint64_t *k = reinterpret_cast<uint64_t *>(lds + 256);
+  double *f = lds + 512;
   for (int i = threadIdx.x; i < 256; i += blockDim.x) {
     lds[i] = c_zig_wi[i];
     k[i] = c_zig_ki[i];
+    f[i] = c_zig_fi[i];
   }
   __syncthreads();
-  return ZigTabLds{lds, k};
+  return ZigTabLds{lds, k, f};
 }
 template <class Tab>
 __device__ __forceinline__ ZigDraw zig_fast(uint64_t r, const Tab &tab) {
@@ -254,17 +260,46 @@ __device__ inline void wave_normals(Pcg64 &rng, long long n, Store store, const 
     // Rejections are resolved in lane order; `dropped` collects the lanes that deliver nothing
     // (consumed by a rejection's redraws, or cut off behind a restart), and every surviving
     // lane stores once at the end, shifted down by the dropped lanes below it.
+    //
+    // The common rejection -- a wedge test (idx != 0), 99.6 % of them -- needs ONE more uniform, which
+    // is the raw output the NEXT lane already holds, and its outcome is a pure function of the two
+    // raw values.  So every failing lane evaluates its own wedge test in parallel (one vector exp for
+    // the whole wave instead of a wave-uniform one per rejection), and the walk below only shifts
+    // bit masks: an accepted wedge drops lane f+1 (consumed as the uniform) and lane f delivers its x;
+    // a rejected one drops lanes f and f+1, and the redraw IS the draw that starts at lane f+2
+    // (delivered by that lane itself).  Tail draws (idx == 0) and a rejection in lane 63 (its
+    // uniform lies in the next round) keep the generic scalar path.
+    unsigned long long wacc = 0, tailm = 0;
+    if (fail) {
+      const uint64_t raw_next = (uint64_t)__shfl_down((unsigned long long)raw, 1);
+      bool w = false;
+      if (!d.accept && d.idx != 0)
+        w = ((tab.fi(d.idx - 1) - tab.fi(d.idx)) * u64_to_unit(raw_next) + tab.fi(d.idx)) < exp(-0.5 * d.x * d.x);
+      wacc = __ballot(w);
+      tailm = __ballot(!d.accept && d.idx == 0);
+    }
     double x = d.x;
     unsigned long long dropped = 0;
+    unsigned long long wlive = 0;  // lanes that deliver through an accepted wedge: the stream stands one lane further
     int cur = 0;                // rejections are looked for at lanes >= cur
     bool serial = false;        // rng.state was advanced by the generator itself (restart)
-    int ev_f = -1, ev_end = -1; // last resolved rejection: its lane, the last lane it consumed
+    int ev_f = -1, ev_end = -1; // last rejection resolved on the generic path: its lane, the last lane it consumed
     for (;;) {
       const unsigned long long m = cur < 64 ? (fail & (~0ULL << cur)) : 0ULL;
       if (!m) break;
       const int f = __ffsll((long long)m) - 1;
       const int before = f - __popcll(dropped & ((1ULL << f) - 1));  // normals delivered by lanes < f
       if ((long long)before >= want) break;                           // the request ends before lane f
+      if (f < 63 && !((tailm >> f) & 1ULL)) {  // wedge: masks only
+        if ((wacc >> f) & 1ULL) {
+          dropped |= 1ULL << (f + 1);
+          wlive |= 1ULL << f;
+        } else {
+          dropped |= 3ULL << f;
+        }
+        cur = f + 2;
+        continue;
+      }
       ZigDraw df;
       df.x = __longlong_as_double((long long)shfl_u64((uint64_t)__double_as_longlong(d.x), f));
       df.rabs = shfl_u64(d.rabs, f);
@@ -299,7 +334,7 @@ __device__ inline void wave_normals(Pcg64 &rng, long long n, Store store, const 
       if (mine && o < want) store(pos + o, x);
       const unsigned long long lastm = __ballot(mine && o == want - 1);
       const int L = __ffsll((long long)lastm) - 1;
-      rng.state = shfl_u128(sk, L == ev_f ? ev_end : L);
+      rng.state = shfl_u128(sk, ((wlive >> L) & 1ULL) ? L + 1 : (L == ev_f ? ev_end : L));
       return;
     }
   }
