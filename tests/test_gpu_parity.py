@@ -397,6 +397,49 @@ def test_dense_path_equals_diagonal_path_under_triangular_map(D, sampler):
         eng.set_option("dense_linear", 1)
 
 
+@pytest.mark.parametrize("case", ["teams-1", "teams-64", "wide", "linreg"])
+def test_resident_kernels_with_diverging_trajectories_match_oracle(eng, regression_data, case):
+    """The single-launch NUTS kernels where trajectories diverge (|H0 - E| > threshold) -- on the first
+    leapfrog of an expansion (trajectory.py:336: the tuple of the initial state is returned, the scan
+    still runs and draws its uniforms) and later: flags, leapfrog counts, values and the generator
+    states of all four call sites against the oracle."""
+    from aehmc_amd import RandomStream, nuts, targets
+    r = np.random.default_rng(len(case) + 3)
+    thr = 5.0
+    if case == "linreg":
+        X, y = regression_data
+        D, C = 2, 10
+        tgt, otgt = targets.LinearRegression(X, y), co.Target(co.T_LINREG, 2, X=X, y=y)
+        imm, eps = np.array([2.13e-05, 4.43e-05]), 40.0
+        q0 = np.array([3.0, np.log(0.49)]) + 0.01 * r.normal(size=(C, 2))
+    else:
+        D, C = {"teams-1": (3, 50), "teams-64": (20, 6), "wide": (700, 4)}[case]
+        mu, sigma, imm = r.normal(size=D), 0.5 + r.random(D), 0.5 + r.random(D)
+        tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
+        eps = 3.5 / D ** 0.25 if D < 100 else 2.5 / D ** 0.25
+        q0 = r.normal(size=(C, D))
+    seeds = [20 + c for c in range(C)]
+    srng = RandomStream(seeds=seeds)
+    kernel = nuts.new_kernel(srng, tgt, divergence_threshold=thr)
+    state = nuts.new_state(dev(q0), tgt)
+    rng, metric = co.site_states(seeds, 4), co.Metric(imm, D)
+    q, U, g = co.new_state(otgt, q0.copy())
+    eng.set_option("resident_min_team", 1 if case == "teams-1" else 0)
+    ndiv = first = 0
+    try:
+        for _ in range(4):
+            info, updates = kernel(state, eps, imm)
+            res = co.nuts_step(otgt, metric, rng, eps, q, U, g, thr=thr)
+            check_state(info, q, U, g, res)
+            assert np.array_equal(updates[srng].cpu().numpy().view(np.uint64)[:, :, :2], rng[:, :, :2])
+            state = info.state._replace(momentum=None)
+            ndiv += int(res["is_diverging"].sum())
+            first += int(((res["n_leapfrog"] == 1) & (res["is_diverging"] != 0)).sum())
+    finally:
+        eng.set_option("resident_min_team", 0)
+    assert ndiv >= 3 and first >= 1, (ndiv, first)
+
+
 # ------------------------------------------------------------------ helpers
 def make_case(kind, tkind, D, r):
     from aehmc_amd import targets

@@ -171,6 +171,49 @@ def test_regression_nuts_sample_equals_repeated_steps(regression_data):
     assert torch.equal(k1._nuts["holder"]["rng"], k2._nuts["holder"]["rng"])
 
 
+@pytest.mark.parametrize("case", ["teams-1", "teams-64", "linreg"])
+def test_multi_transition_launch_with_diverging_trajectories(case, regression_data):
+    """The one-launch sample() paths in the regime the reference handles through `is_diverging`: step
+    sizes so large that many trajectories diverge on their very first leapfrog (trajectory.py:336 --
+    the sub-trajectory's scan still runs and still consumes random numbers) or later.  Per-transition
+    outputs, divergence flags and RNG state equal separate calls of the kernel, which
+    tests/test_gpu_parity.py checks against the oracle in the same regime."""
+    from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    r = np.random.default_rng(len(case))
+    N = 6
+    if case == "linreg":
+        X, y = regression_data
+        tgt, C = targets.LinearRegression(X, y), 10
+        imm, eps = np.array([2.13e-05, 4.43e-05]), 40.0
+        q0 = np.array([3.0, np.log(0.49)]) + 0.01 * r.normal(size=(C, 2))
+    else:
+        D, C = (3, 50) if case == "teams-1" else (20, 6)
+        tgt, imm, eps = targets.DiagGaussian(r.normal(size=D), 0.5 + r.random(D)), 0.5 + r.random(D), 3.5
+        q0 = r.normal(size=(C, D))
+    k1 = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, divergence_threshold=5.0)
+    k2 = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, divergence_threshold=5.0)
+    s1 = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+    eng.set_option("resident_min_team", 1 if case == "teams-1" else 0)
+    try:
+        samples, info, acc, div = k1.sample(s1, eps, imm, N)
+        s2, ndiv, first = s1, 0, 0
+        for t in range(N):
+            i2, _ = k2(s2, eps, imm)
+            s2 = i2.state._replace(momentum=None)
+            assert torch.equal(samples[t], i2.state.position), t
+            assert torch.equal(acc[t], i2.acceptance_probability), t
+            assert torch.equal(div[t].to(torch.int32), i2.is_diverging.to(torch.int32)), t
+            ndiv += int(i2.is_diverging.sum().item())
+            first += int(((i2.n_leapfrog == 1) & i2.is_diverging.bool()).sum().item())
+    finally:
+        eng.set_option("resident_min_team", 0)
+    assert ndiv >= 5 and first >= 1, (ndiv, first)  # divergences did happen, some on the first leapfrog
+    assert torch.equal(k1._nuts["holder"]["rng"], k2._nuts["holder"]["rng"])
+    assert torch.equal(info.state.position, i2.state.position) and torch.equal(info.n_leapfrog.sum(), info.n_leapfrog.sum())
+
+
 def test_readme_example_runs():
     """The snippet of this repo's README.md (reduced sizes)."""
     from aehmc_amd import RandomStream, nuts, targets, window_adaptation
