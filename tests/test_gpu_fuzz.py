@@ -1,0 +1,20 @@
+"""A short run of the randomised parity sweep (tools/fuzz_parity.py): random sampler / target / metric /
+sizes / engine options / per-chain parameters / sample() vs calls, against the C oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_random_configurations_match_oracle():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "25", "7"],
+                         capture_output=True, text=True, timeout=550, cwd=ROOT)
+    tail = out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.returncode == 0, tail
+    line = [l for l in out.stdout.splitlines() if l.startswith("fuzz:")][-1]
+    assert int(line.split()[1]) >= 100 and " 0 mismatches" in line, line
