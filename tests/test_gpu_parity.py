@@ -176,7 +176,7 @@ def test_g2_g3_regression_on_gpu(regression_data):
 @pytest.mark.parametrize("N,C,L", [(10_000, 1, 64), (10_000, 6, 33), (10_176, 9, 20), (10_177, 5, 20), (25_001, 7, 12), (700, 4, 50)])
 def test_regression_hmc_fused_matches_oracle(eng, N, C, L):
     """HMC on the regression target in one launch (hmc_linreg.cuh): rows resident in LDS (N <= 10176)
-    or streamed through the LDS-DMA ring (N above), workgroups with 1..4 live chains, three consecutive
+    or streamed by direct loads (N above), workgroups with 1..4 live chains, three consecutive
     transitions through kernel.sample -- against the oracle, and against the lock-step path
     (`fused_hmc` = 0), which differs in the order of the row sums only."""
     from aehmc_amd import PerChain, RandomStream, hmc, targets
