@@ -123,7 +123,8 @@ def one(case):
         pos = info.state.position.cpu().numpy().reshape(q.shape)
         np.testing.assert_allclose(pos, q, rtol=RTOL, atol=1e-10)
         np.testing.assert_allclose(info.state.potential_energy.cpu().numpy().reshape(-1), U, rtol=RTOL, atol=1e-10)
-        np.testing.assert_allclose(info.acceptance_probability.cpu().numpy().reshape(-1), res["acceptance_probability"], rtol=1e-8, atol=1e-12)
+        # (exp of an energy DIFFERENCE: rounding of energies of size 1e3-1e4 is amplified -- the north star's 1e-6 here)
+        np.testing.assert_allclose(info.acceptance_probability.cpu().numpy().reshape(-1), res["acceptance_probability"], rtol=1e-6, atol=1e-12)
         got = holder.cpu().numpy().view(np.uint64).reshape(rng.shape)
         assert np.array_equal(got[:, :, :2], rng[:, :, :2]), "generator state"
     finally:
