@@ -883,7 +883,8 @@ extern "C" int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64
   // in ONE launch, the chains adapting and moving on at their own pace (nuts_linreg.cuh: every chain;
   // nuts_resident.cuh: every wavefront) -- the same arithmetic as the loop below
   const int path = ctx->has_met ? nuts_path(ctx, C, max_num_expansions) : NUTS_PATH_LOCKSTEP;
-  if (num_steps > 0 && (path == NUTS_PATH_LINREG || path == NUTS_PATH_TEAMS) && !state->full && ctx->met.ndim == 1 &&
+  if (num_steps > 0 && (path == NUTS_PATH_LINREG || path == NUTS_PATH_TEAMS) && !state->full &&
+      (ctx->met.ndim == 1 || (ctx->met.ndim == 0 && D == 1 && path == NUTS_PATH_TEAMS)) &&
       ctx->met.per_chain && ctx->met.imm == state->imm && ctx->met.sqrt_mass == state->sqrt_mass &&
       ctx->eps_c == state->step_size) {
     hipStream_t st = (hipStream_t)stream;

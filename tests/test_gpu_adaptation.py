@@ -437,3 +437,30 @@ def test_regression_window_adaptation_matches_oracle(regression_data):
         assert eps_g[c] == pytest.approx(eps_o, rel=1e-6)
         np.testing.assert_allclose(imm_g[c], imm_o, rtol=1e-6)
         np.testing.assert_allclose(pos_g[c], st.position, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("min_team", [0, 1])
+def test_scalar_position_warmup_in_one_launch(min_team):
+    """The reference's own warm-up test shape (tests/test_hmc.py:13-97: a SCALAR position, so a scalar
+    inverse mass matrix per chain): one launch == step-by-step loop, bit for bit."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    C = 70
+    tgt = targets.DiagGaussian(np.array([1.0]), np.array([2.0]))
+    outs = []
+    eng.set_option("resident_min_team", min_team)
+    try:
+        for fused in (True, False):
+            srng = RandomStream(seeds=list(range(C)))
+            kernel = nuts.new_kernel(srng, tgt)
+            state = nuts.new_state(torch.ones(C, dtype=torch.float64, device="cuda"), tgt, num_chains=C)
+            state, (eps, imm), _ = window_adaptation.run(kernel, state, 150, fused=fused)
+            info, upd = kernel(state, eps, imm)
+            outs.append((state.position.clone(), eps.value.clone(), imm.value.clone(), info.state.position.clone(),
+                         upd[srng].clone()))
+    finally:
+        eng.set_option("resident_min_team", 0)
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), k
+    assert outs[0][2].shape == (C,) and not torch.allclose(outs[0][2], torch.ones_like(outs[0][2]))
