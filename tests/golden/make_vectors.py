@@ -107,3 +107,43 @@ json.dump({"derived": derived2,
            "note": "derived vectors come from oracle/c (this repo), not from the reference; the dense branch is unpinned "
                    "by the reference (no published value exists)"}, open(out2, "w"))
 print("wrote", out2, os.path.getsize(out2), "bytes")
+
+
+# v3 (round 2): the regression target (the rows are regenerated from `data_seed`, as the notebook's own cell does)
+# and a scalar-sized chain set large enough to take the ziggurat's redraw path several times
+def linreg_case(name, sampler, N, C, eps, n_transitions, seed0, data_seed, L=0, max_exp=10):
+    r = np.random.default_rng(data_seed)
+    X = r.normal(0, 1, size=N)
+    y = 3 * X + 0.5 * r.normal(0, 1, size=N)
+    otgt = co.Target(co.T_LINREG, 2, X=X, y=y)
+    imm = np.array([0.25 / N, 0.5 / N]).round(12)
+    metric = co.Metric(imm, 2)
+    seeds = [seed0 + c for c in range(C)]
+    q0 = (np.array([3.0, np.log(0.5)]) + (0.5 / np.sqrt(N)) * np.random.default_rng(data_seed + 1).normal(size=(C, 2))).round(9)
+    q, U, g = co.new_state(otgt, q0.copy())
+    rng = co.site_states(seeds, 4 if sampler == "nuts" else 2)
+    steps = []
+    for _ in range(n_transitions):
+        res = (co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=max_exp) if sampler == "nuts"
+               else co.hmc_step(otgt, metric, rng, eps, L, q, U, g))
+        steps.append(dict(position=q.tolist(), potential_energy=U.tolist(),
+                          acceptance_probability=res["acceptance_probability"].tolist(),
+                          is_diverging=res["is_diverging"].astype(int).tolist(), n_leapfrog=res["n_leapfrog"].tolist(),
+                          num_doublings=res.get("num_doublings", np.zeros(C, int)).tolist(),
+                          is_turning=res.get("is_turning", np.zeros(C, bool)).astype(int).tolist()))
+    return dict(name=name, sampler=sampler, D=2, C=C, metric_kind="diag", target_kind="linreg", N=N, data_seed=data_seed,
+                imm=imm.tolist(), eps=eps, L=L, max_exp=max_exp, seeds=seeds, q0=q0.tolist(), steps=steps,
+                mu=[], sigma=[], prec=None)
+
+
+derived3 = [
+    linreg_case("nuts_linreg_n1500", "nuts", 1500, 6, 0.5, 3, 100, 7),
+    linreg_case("nuts_linreg_n12000", "nuts", 12000, 5, 0.5, 2, 110, 8),
+    linreg_case("hmc_linreg_n1500", "hmc", 1500, 6, 0.3, 2, 120, 9, L=12),
+    case("nuts_d1_40_chains", "nuts", 1, 40, "diag", "diag", 0.3, 4, 130),
+]
+out3 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vectors_v3.json")
+json.dump({"derived": derived3,
+           "note": "derived vectors come from oracle/c (this repo), not from the reference; regression rows: "
+                   "r = default_rng(data_seed); X = r.normal(0, 1, N); y = 3 X + 0.5 r.normal(0, 1, N)"}, open(out3, "w"))
+print("wrote", out3, os.path.getsize(out3), "bytes")

@@ -9,14 +9,24 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = json.load(open(os.path.join(HERE, "golden", "vectors_v1.json")))
 FIX["derived"] = FIX["derived"] + json.load(open(os.path.join(HERE, "golden", "vectors_v2.json")))["derived"]
+FIX["derived"] = FIX["derived"] + json.load(open(os.path.join(HERE, "golden", "vectors_v3.json")))["derived"]
+
+
+def _regression_rows(case):
+    r = np.random.default_rng(case["data_seed"])
+    X = r.normal(0, 1, size=case["N"])
+    return X, 3 * X + 0.5 * r.normal(0, 1, size=case["N"])
 
 
 def _oracle_run(case):
     from oracle import c_oracle as co
     D, C = case["D"], case["C"]
     kind = {"std_normal": co.T_STD_NORMAL, "iso": co.T_ISO_GAUSSIAN, "diag": co.T_DIAG_GAUSSIAN,
-            "dense": co.T_DENSE_MVN}[case["target_kind"]]
-    if case["target_kind"] == "dense":
+            "dense": co.T_DENSE_MVN, "linreg": co.T_LINREG}[case["target_kind"]]
+    if case["target_kind"] == "linreg":
+        X, y = _regression_rows(case)
+        otgt = co.Target(kind, 2, X=X, y=y)
+    elif case["target_kind"] == "dense":
         otgt = co.Target(kind, D, mu=np.array(case["mu"]), prec=np.array(case["prec"]))
     else:
         otgt = co.Target(kind, D, mu=np.array(case["mu"]), sigma=np.array(case["sigma"]))
@@ -46,7 +56,9 @@ def test_hip_reproduces_fixtures(case):
     from aehmc_amd import RandomStream, hmc, nuts, targets
     D = case["D"]
     tgt = {"std_normal": targets.StdNormal, "iso": targets.IsoGaussian}.get(case["target_kind"])
-    if case["target_kind"] == "dense":
+    if case["target_kind"] == "linreg":
+        tgt = targets.LinearRegression(*_regression_rows(case))
+    elif case["target_kind"] == "dense":
         tgt = targets.DenseMVN(np.array(case["mu"]), np.array(case["prec"]))
     else:
         tgt = tgt() if tgt else targets.DiagGaussian(np.array(case["mu"]), np.array(case["sigma"]))
