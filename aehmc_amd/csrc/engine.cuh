@@ -836,10 +836,17 @@ __global__ __launch_bounds__(256) void k_step_linear(EngineArgs a) {
   ChainCtl ct = a.ctl[c];
   if (ct.done) return;
   double U_new = 0.0;
-  if (PHASE == 3 && BOOK) {  // last leapfrog stage fused into the bookkeeping pass
+  if ((PHASE & 3) == 3 && BOOK) {  // last leapfrog stage fused into the bookkeeping pass
     ChainRng rng = rng_load(a, c);
     nuts_book<true, 1>(a, c, lane, ct, rng);
     rng_store(a, c, lane, rng, 1, 3);
+    // PHASE 3 + 12: a chain that goes on takes the first stages of its NEXT leapfrog right here -- the
+    // vectors the bookkeeping has just written are still in L2, and the step needs one launch less
+    if ((PHASE & 12) == 12 && !ct.done) {
+      __threadfence_block();
+      double U_next = 0.0;
+      if (leap_linear<12>(a, c, lane, ct.dir, U_next)) ct.U_cur = U_next;
+    }
     if (lane == 0) a.ctl[c] = ct;
     return;
   }

@@ -66,6 +66,7 @@ struct aehmc_ctx {
   // matrix was not positive definite (separate words: one must not erase the other)
   int *h_err = nullptr, *d_err = nullptr;
   double prof_flops = 0.0;
+  bool fuse_pre = false, pre_done = false;  // NUTS lock-step loop, dense-linear mode: see launch_leapfrog
   int *d_sched = nullptr;  // warm-up schedule on the device: stage [n], is_window_end [n]
   int64_t d_sched_n = 0;
 };
@@ -666,11 +667,16 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
     return 0;
   }
   if (a.linear) {  // dense metric, v carried by linearity: one metric GEMM (w' = imm g')
-    LAUNCH((k_step_linear<12, false>), C, st, a);
+    // (NUTS lock-step loop: the first stages of every leapfrog but the first ride in the previous
+    //  step's bookkeeping launch -- k_step_linear<15, true>)
+    if (!(book && ctx->pre_done)) LAUNCH((k_step_linear<12, false>), C, st, a);
     if (text)
       if (target_ext()) return -1;
     if (metric_mul(ctx, C, a.cur_g, ctx->met.imm, a.cur_w, st, ri, nr)) return -1;
-    if (book) LAUNCH((k_step_linear<3, true>), C, st, a);
+    if (book && ctx->fuse_pre) {
+      LAUNCH((k_step_linear<15, true>), C, st, a);
+      ctx->pre_done = true;
+    } else if (book) LAUNCH((k_step_linear<3, true>), C, st, a);
     else LAUNCH((k_step_linear<3, false>), C, st, a);
     return 0;
   }
@@ -814,6 +820,8 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     return prof_end(ctx, st, p);
   }
   ctx->rows_hint = 0;
+  ctx->fuse_pre = a.linear != 0;
+  ctx->pre_done = false;
   if (int rc = launch_begin(ctx, a, true, st)) return rc;
   long long maxsteps = 0;
   for (int j = 0; j < max_num_expansions; j++) maxsteps += (1LL << j) + 1;  // 2**j + 1 per expansion
@@ -853,6 +861,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     batch++;
   }
   ctx->rows_hint = 0;
+  ctx->fuse_pre = ctx->pre_done = false;
   return 0;
 }
 
