@@ -24,7 +24,7 @@ def one(case):
     if tk == "linreg":
         D, mk = 2, ("diag" if mk == "scalar" else mk)
     elif tk == "dense" or mk == "dense":
-        D = int(r.choice([2, 5, 33, 64, 65, 130, 300]))
+        D = int(r.choice([2, 5, 33, 64, 65, 130, 300, 520, 1030], p=[0.15, 0.15, 0.15, 0.1, 0.1, 0.15, 0.1, 0.05, 0.05]))
     else:
         D = int(r.choice([1, 2, 3, 5, 8, 17, 31, 64, 65, 100, 128, 129, 257, 512, 513, 700, 1100, 2100, 4100, 6000]))
     if mk == "scalar" and D > 1 and tk != "linreg":
@@ -33,7 +33,8 @@ def one(case):
     if D > 2000:
         C = min(C, 5)
     opts = {"resident_nuts": int(r.choice([0, 1, 2])), "resident_min_team": int(r.integers(0, 2)),
-            "fused_hmc": int(r.integers(0, 2)), "dense_linear": int(r.integers(0, 2)), "fused_nuts": int(r.integers(0, 2))}
+            "fused_hmc": int(r.integers(0, 2)), "dense_linear": int(r.integers(0, 2)), "fused_nuts": int(r.integers(0, 2)),
+            "streamk": int(r.choice([0, 1, 2])), "compact": int(r.integers(0, 2))}
     mu, sigma = r.normal(size=D), 0.5 + r.random(D)
     if tk == "linreg":
         N = int(r.choice([37, 1000, 10176, 10177, 23001]))
@@ -128,7 +129,8 @@ def one(case):
         got = holder.cpu().numpy().view(np.uint64).reshape(rng.shape)
         assert np.array_equal(got[:, :, :2], rng[:, :, :2]), "generator state"
     finally:
-        for k, v in (("resident_nuts", 2), ("resident_min_team", 0), ("fused_hmc", 1), ("dense_linear", 1), ("fused_nuts", 0)):
+        for k, v in (("resident_nuts", 2), ("resident_min_team", 0), ("fused_hmc", 1), ("dense_linear", 1), ("fused_nuts", 0),
+                     ("streamk", 2), ("compact", 1)):
             eng.set_option(k, v)
     return desc
 
