@@ -12,6 +12,15 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def _run(*args, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True,
                          text=True, timeout=600, cwd=ROOT, env=env)
@@ -63,7 +72,7 @@ def test_parallel_collectives_on_rccl_one_rank():
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from aehmc_amd import parallel
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", device_id=dev)
@@ -80,7 +89,8 @@ dist.destroy_process_group()
 print("RCCL-OK")
 """
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    out = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([sys.executable, "-c", code, ROOT, str(_free_port())], capture_output=True, text=True,
+                         timeout=600, env=env)
     assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stderr[-3000:]
 
 
@@ -89,7 +99,7 @@ def test_bench_one_rank_under_the_launcher_uses_rccl():
     initialises RCCL, and the line reports the backend it gathered over."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                          "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"),
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
                           "--gpus", "1", "--steps", "2", "--warmup", "1", "--chains", "64", "--dim", "256",
                           "--no-cpu-baseline", "--no-secondary"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
