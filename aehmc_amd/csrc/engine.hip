@@ -783,7 +783,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   if (nuts_path(ctx, C, max_num_expansions) == NUTS_PATH_LINREG) {
     NutsSampleArgs m{};
     m.T = 1;
-    if (multi) {
+    if (multi && multi_done) {
       m = *multi;
       *multi_done = true;
     }
@@ -805,7 +805,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     } else {  // teams of <= 64 lanes: any number of transitions in one launch
       NutsSampleArgs m{};
       m.T = 1;
-      if (multi) {
+      if (multi && multi_done) {
         m = *multi;
         *multi_done = true;
       }
