@@ -8,6 +8,9 @@
  * Each function cites the reference file:line (under /root/reference) it follows.
  * PARITY UNPINNED (no published reference value): dense-metric trajectories, and RNG
  * consumption after a sub-trajectory whose first step diverged (trajectory.py:336).
+ * The dense branch is tied to the pinned diagonal branch by an exact invariance instead:
+ * a transition is equivariant under q' = A q for lower-triangular A
+ * (tests/test_oracle_golden.py::test_dense_branch_equals_diagonal_branch_under_triangular_map).
  * The RNG restates numpy 2.2.6's PCG64 / random_standard_normal / random_binomial
  * (third party; reached by the reference through aesara RandomStream, "scheme A":
  * one spawned SeedSequence child per RNG call site) and is checked bit-for-bit

@@ -17,8 +17,12 @@ Every function cites the reference file:line (relative to /root/reference) it fo
 PARITY UNPINNED for two things the reference publishes no value for: (1) dense-metric
 trajectories (only the exact kinetic-energy / is_turning unit cases of tests/test_metrics.py
 exist), (2) RNG consumption after a sub-trajectory whose first step diverged
-(trajectory.py:336: we assume the inner scan still executes).  For those, parity means
-"HIP == this restatement", nothing more.
+(trajectory.py:336: we assume the inner scan still executes -- its RNG updates are outputs
+of the compiled function, so a lazy ifelse cannot skip it).  For those, parity means
+"HIP == this restatement"; for (1) there is in addition an exact invariance that ties the dense
+branch to the pinned diagonal one: a whole transition is equivariant under q' = A q for
+lower-triangular A (tests/test_oracle_golden.py::
+test_dense_branch_equals_diagonal_branch_under_triangular_map).
 
 Third-party arithmetic that is NOT in /root/reference: aesara>=2.8.11 / aeppl>=0.1.4
 (pyproject.toml:18-19, lower bounds only).  Their RNG is restated as "scheme A":
