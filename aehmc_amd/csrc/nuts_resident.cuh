@@ -14,6 +14,10 @@
 // ~1 pair read per step), the trajectory ends at expansion boundaries and the proposal on
 // accept -- instead of the 88*D bytes per leapfrog of a streaming implementation.
 //
+// MULTI instantiations run m.T consecutive transitions per launch (kernel.sample(T)) and, with m.adapt,
+// the window-adaptation update after each of them (window_adaptation.run in one launch): per-transition
+// records go to m.samples / m.acc_hist / m.div_hist, the generator states stay in registers in between.
+//
 // Diagonal / scalar metric (shared or per chain), coordinate-wise targets.  Arithmetic and
 // its order are those of the lock-step path in engine.cuh (for T = 64 bit for bit, tested);
 // reference: nuts.py:56-153, trajectory.py:154-374,428-714, termination.py:85-235,
