@@ -109,3 +109,18 @@ def test_bench_one_rank_under_the_launcher_uses_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["ranks_seen"] == 1 and d["value"] > 0
     assert d["config"]["gather"]["backend"] == "nccl"
+
+
+def test_integration_md_binding_snippet_runs():
+    """The ctypes stub INTEGRATION.md shows a reference maintainer is executed verbatim: it must load the
+    library, run one NUTS transition through the C-ABI and leave finite results (a doc that drifts from
+    include/aehmc_hip.h -- a struct field added, a signature changed -- fails here)."""
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    code = code.replace('"libaehmc_hip.so"', repr(os.path.join(ROOT, "aehmc_amd", "libaehmc_hip.so")))  # (not on the loader path here)
+    prog = code + ("\ntorch.cuda.synchronize()\nacc, nl = out['acceptance_probability'], out['n_leapfrog']\n"
+                   "assert torch.isfinite(q).all() and torch.isfinite(acc).all() and (nl > 0).all() and acc.mean() > 0.5\n"
+                   "print('SNIPPET-OK', float(acc.mean()))\n")
+    out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "SNIPPET-OK" in out.stdout, out.stderr[-3000:]
