@@ -6,16 +6,21 @@
 // chains: per leapfrog all eight wavefronts sweep (X, y) once from L2 for the four chains together
 // (linreg_rows.cuh: direct 16-byte loads, double-buffered in registers, three fused multiply-adds
 // per row and chain; the first 10176 rows stay in the CU's LDS for the whole launch and never
-// touch the vector-memory path again), and wavefronts 0-3 each keep the tree of one chain.  D = 2, so the whole
-// transition state of a chain lives in registers of its wavefront -- element e of every vector in
-// lane e, the U-turn checkpoints (termination.py:12-16) of level i in lanes 2i, 2i+1 of two more
-// registers; the tree touches no memory at all.
+// touch the vector-memory path again), and wavefronts 0-3 each keep the tree of one chain.
+// D = 2, so the whole transition state of a chain lives in registers of its wavefront -- element
+// e of every vector in lane e, the U-turn checkpoints (termination.py:12-16) of level i in lanes
+// 2i, 2i+1 of two more registers; the tree touches no memory at all.
 //
 // Chains are independent, so nothing is synchronised at transition boundaries: a chain whose tree
 // has ended draws its next momentum and goes on in the very next sweep while its neighbours are
 // still inside their trees (the sweep serves four chains whatever transition each is in).  With
 // the short, unequal trees of a warmed-up sampler (2 or 5 leapfrogs, rarely more) a launch of T
 // transitions costs about T x the MEAN tree length instead of T x the longest tree on the GPU.
+// With m.adapt the launch is a whole window-adaptation warm-up (window_adaptation.py:17-116,
+// diagonal mass matrix): after each of its transitions a chain applies its own dual-averaging /
+// Welford / window-end update (the arithmetic of k_adapt_update) and goes on with the new
+// parameters -- early warm-up trees range from 1 to 1023 leapfrogs, which is where not waiting
+// for the slowest chain pays most.
 //
 // Diagonal / scalar metric (shared or per chain).  Arithmetic and its order are those of nuts_book
 // (engine.cuh) / k_nuts_resident; reference: nuts.py:56-153, trajectory.py:154-374,428-714,
