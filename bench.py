@@ -33,6 +33,20 @@ PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X FP64 matrix peak (AMD datasheet; = 256 CU
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
+PEAK_FP64_VALU_TFLOPS = 78.6  # fp64 vector peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (datasheet)
+
+
+def pmc_summary(name):
+    """Counter summaries are collected OFFLINE (rocprofv3 --pmc cannot run inside the bench): the newest
+    committed profiles/rN/<name> and its path, so that every roofline entry that divides offline counters
+    by this run's timings says where they came from (`traffic_source`)."""
+    for rnd in ("r3", "r2", "r1"):
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(path):
+            return json.load(open(path)), f"profiles/{rnd}/{name} (separate rocprofv3 --pmc passes of the same workload)"
+    return None, None
+
+
 def build_c3(D, device, rho=0.5):
     """Sigma_ij = rho^|i-j| s_i s_j, s_i = 1 + (i mod 3); precision is tridiagonal
     analytically but stored and applied DENSE; imm = Sigma."""
@@ -67,7 +81,7 @@ def other_configs():
             d = json.loads(line[-1])
             out.append({"config": cfg, "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
                         "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
-                        "roofline": d.get("roofline"), "valu": d.get("valu")})
+                        "roofline": d.get("roofline")})
         except Exception as e:  # a failing side measurement must not cost the main line
             out.append({"config": cfg, "error": repr(e)[:300]})
     return out
@@ -96,8 +110,7 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
     COUNTED by rocprofv3 (FETCH_SIZE x 2 + WRITE_SIZE of the kernels of one transition, separate
     --pmc passes of the same workload: profiles/r2/diag_pmc_summary.json) / the transition's kernel
     time measured here with HIP events on the launch stream."""
-    pmc_path = os.path.join(ROOT, "profiles", "r2", "diag_pmc_summary.json")
-    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) and (D, C) == (10_000, 4096) else None
+    pmc, pmc_src = pmc_summary("diag_pmc_summary.json") if (D, C) == (10_000, 4096) else (None, None)
     out = []
     for kind, main_kernel in (("nuts", "k_nuts_wide"), ("hmc", "k_hmc_wide")):
         state, step = diag_case(kind, D, C, device)
@@ -125,6 +138,7 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
         alg = (48.0 if kind == "hmc" else 88.0) * D * nl / (steps * per_call)  # SURVEY 8d streaming figure, for reference only
         roof = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "kernel": main_kernel + " (+ k_draw_momentum)",
                 "avg_launch_ms": avg_ms, "launches": kern_n * per_call, "traffic": traffic,
+                "traffic_source": pmc_src if traffic else None,
                 "achieved": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
                 "streaming_bytes_per_transition": alg,
                 "note": "achieved = counted HBM bytes per transition / kernel time; the chain state is on chip, so the "
@@ -137,27 +151,71 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
     return out
 
 
-def launch_ranks(n):
+def launch_ranks(n, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one process per
     GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches
-    the GPU -- children are new processes, nothing is exec'ed over an initialised HIP runtime."""
+    the GPU -- children are new processes, nothing is exec'ed over an initialised HIP runtime.
+    The children are polled: the first rank that exits non-zero (or a wall-clock timeout,
+    AEHMC_BENCH_TIMEOUT seconds, default 3600) ends the run -- its siblings, which would otherwise
+    wait for it in a collective for ever, are terminated, the failing rank's stderr tail is relayed
+    and the exit status is non-zero."""
+    import tempfile
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("AEHMC_BENCH_TIMEOUT", "3600"))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = tempfile.TemporaryFile(mode="w+") if r == 0 else subprocess.DEVNULL
+        err = tempfile.TemporaryFile(mode="w+")
+        logs.append((out, err))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out)
+                                      stdout=out, stderr=err, text=True))
+
+    def tail(f, nbytes=3000):
+        f.flush()
+        f.seek(0)
+        return f.read()[-nbytes:]
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    deadline = time.monotonic() + timeout_s
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0]} exited with code {rcs[bad[0]]}"
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            failed = f"timeout after {timeout_s:.0f} s (ranks still running: {[r for r, rc in enumerate(rcs) if rc is None]})"
+            bad = [r for r, rc in enumerate(rcs) if rc is None][:1]
+            break
+        time.sleep(0.2)
+    if failed:
+        stop_all()
+        for r in bad:
+            sys.stderr.write(f"bench.py: ---- stderr tail of rank {r} ----\n{tail(logs[r][1])}\n")
+        sys.exit(f"bench.py: {failed}; sibling ranks terminated")
+    sys.stdout.write(tail(logs[0][0], 1 << 22))
     sys.stdout.flush()
-    if any(rcs):
-        sys.exit(f"bench.py: rank exit codes {rcs}")
 
 
 def main():
@@ -168,7 +226,8 @@ def main():
                                                              "clocks of an idle GPU take longer than that to come up)")
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs; c4 = c3 with 32768 chains split over the ranks (strong scaling)")
-    ap.add_argument("--chains", type=int, default=4096, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: 4096; c5: 1024 = 8192 over 8 GPUs; "
+                                                             "c4: 32768 / ranks)")
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the diagonal-mass secondary lines")
@@ -177,6 +236,8 @@ def main():
         args.steps = {"c1": 20, "c2": 20, "c5": 100}.get(args.config, 5)
     if args.warmup is None:
         args.warmup = {"c1": 5, "c2": 5, "c5": 1000}.get(args.config, 1)
+    if args.chains is None:
+        args.chains = {"c5": 1024}.get(args.config, 4096)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         have = torch.cuda.device_count()  # counts devices without initialising the GPU
@@ -188,6 +249,8 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("AEHMC_BENCH_FAIL_RANK") == str(rank) and world > 1:  # tests: a rank that dies early
+        sys.exit("bench.py: injected failure of this rank (AEHMC_BENCH_FAIL_RANK)")
     # dry-run knobs for a 1-GPU box: AEHMC_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and
     # AEHMC_DIST_BACKEND=gloo swaps RCCL for gloo (the driver's multi-GPU runs use neither)
     if os.environ.get("AEHMC_BENCH_ONE_DEVICE") == "1":
@@ -199,10 +262,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = dist_backend = os.environ.get("AEHMC_DIST_BACKEND", "nccl")
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("AEHMC_BENCH_PG_TIMEOUT", "900")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
 
@@ -290,10 +355,10 @@ def main():
         avg_s = kern_ms / 1e3 / max(kern_n, 1)
         achieved = flops / avg_s / 1e12
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r2", "c3_pmc_summary.json")
-        if os.path.exists(pmc) and D == 10_000 and C == 4096:  # measured offline: rocprofv3 --pmc cannot run inside the bench
-            traffic = json.load(open(pmc))["gemm_summary"]["traffic_bytes_per_launch_avg"]
-            traffic_src = "profiles/r2/c3_pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2)"
+        pj, src = pmc_summary("c3_pmc_summary.json")
+        if pj and D == 10_000 and C == 4096:
+            traffic = pj["gemm_summary"]["traffic_bytes_per_launch_avg"]
+            traffic_src = src + "; FETCH_SIZE x 2 + WRITE_SIZE"
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": (2.0 * flops / (2.0 * D * D) * D + D * D) * 8,
@@ -303,29 +368,34 @@ def main():
                                    "is HIP == C restatement, checked at this depth in tests/test_gpu_configs.py, and c3 == the isotropic "
                                    "D=1e4 problem on the diagonal kernels under q' = chol(Sigma) q (same file)"}
     else:
-        # fused HMC kernel (100 transitions per launch, state in registers): the HBM traffic is the I/O of a
-        # launch, counted by rocprofv3; the kernel is bound by fp64 VALU issue (profiles/r2/c2_pmc_summary.json)
+        # fused HMC kernel (100 transitions per launch, state in registers): HBM sees only the I/O of a launch
+        # (idle); the bound is fp64 VALU issue.  achieved / peak are leapfrog rates: peak = the issue ceiling at the
+        # kernel's COUNTED instructions per transition (rocprofv3 SQ_INSTS_VALU), 1024 SIMDs x 2.4 GHz /
+        # (4 waves x 4 cycles x instructions per wave and transition).
         avg_s = kern_ms / 1e3 / max(kern_n, 1)
-        traffic, valu = None, None
-        pmc = os.path.join(ROOT, "profiles", "r2", "c2_pmc_summary.json")
-        if os.path.exists(pmc) and D == 100 and C == 4096:  # measured offline (separate rocprofv3 --pmc passes)
-            pj = json.load(open(pmc))
-            traffic = pj["derived"]["hbm_bytes_per_launch"]
-            ipt = pj["derived"]["valu_instructions_per_wave_per_transition"]
-            ceil = pj["derived"]["valu_issue_ceiling_leapfrogs_per_s_at_this_instruction_count"]
-            valu = {"instructions_per_wave_per_transition": ipt,
-                    "leapfrog_fp64_instructions_per_transition": pj["derived"]["leapfrog_fp64_instructions_per_transition"],
-                    "issue_ceiling_leapfrogs_per_s": ceil, "frac_of_issue_ceiling": value / ceil,
-                    "busy_fraction_rocprof": pj["derived"]["valu_busy_fraction_of_kernel_time_at_2.4GHz"],
-                    "note": "one wavefront per chain, 4 per SIMD; a 64-lane fp64 VALU instruction occupies its 16-lane SIMD "
-                            "for 4 cycles; ceiling = 1024 SIMDs x 2.4 GHz / (4 waves x 4 cycles x instructions per transition)"}
-        achieved = (traffic / avg_s / 1e9) if traffic else 40.0 * D * C * 100 / avg_s / 1e9
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "kernel": "k_hmc_fused",
-                    "avg_launch_ms": avg_s * 1e3, "launches": kern_n, "valu": valu,
-                    "note": "achieved = counted HBM bytes per launch (q, dU/dq in and out once, momentum out, histories) / "
-                            "launch time: the chain state stays in VGPRs for 100 transitions x 32 leapfrogs, so HBM is idle "
-                            "and the bound that matters is fp64 VALU issue -- see `valu`"}
+        pj, src = pmc_summary("c2_pmc_summary.json")
+        if not (pj and D == 100 and C == 4096):
+            pj, src = None, None
+        flop_rate = value / world * 9.0 * D / 1e12  # ~9 D flop per leapfrog
+        roofline = {"bound": "valu", "unit": "leapfrog-steps/s", "kernel": "k_hmc_fused", "avg_launch_ms": avg_s * 1e3,
+                    "launches": kern_n, "achieved": value / world, "peak": None, "frac": None, "traffic": None,
+                    "traffic_source": src,
+                    "fp64_flops": {"achieved": flop_rate, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": flop_rate / PEAK_FP64_VALU_TFLOPS,
+                                   "note": "9 D flop per leapfrog (SURVEY.md 8d) against the fp64 vector peak"}}
+        if pj:
+            d = pj["derived"]
+            ceil = d["valu_issue_ceiling_leapfrogs_per_s_at_this_instruction_count"]
+            roofline.update({
+                "peak": ceil, "frac": value / world / ceil, "traffic": d["hbm_bytes_per_launch"],
+                "hbm": {"achieved": d["hbm_bytes_per_launch"] / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": d["hbm_bytes_per_launch"] / avg_s / 1e9 / PEAK_HBM_GBS,
+                        "note": "q, dU/dq in and out once per launch of 100 transitions: HBM is idle"},
+                "valu": {"instructions_per_wave_per_transition": d["valu_instructions_per_wave_per_transition"],
+                         "leapfrog_fp64_instructions_per_transition": d["leapfrog_fp64_instructions_per_transition"],
+                         "busy_fraction_rocprof": d["valu_busy_fraction_of_kernel_time_at_2.4GHz"]},
+                "note": "one wavefront per chain, 4 per SIMD; a 64-lane fp64 VALU instruction occupies its 16-lane SIMD for "
+                        "4 cycles; peak = the issue ceiling at the counted instruction count, frac = achieved / peak"})
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -380,7 +450,7 @@ def bench_c5(args, rank, world, device):
     window adaptation, 8192 chains over 8 GPUs (1024 per rank by default here)."""
     from aehmc_amd import RandomStream, nuts, targets, window_adaptation
     from aehmc_amd.parallel import barrier, gather_samples, max_over_ranks, sum_over_ranks
-    C = 1024 if args.chains == 4096 else args.chains
+    C = args.chains
     rng = np.random.default_rng(0)
     N = 100_000
     X = rng.normal(0, 1, size=(N,))
@@ -389,10 +459,13 @@ def bench_c5(args, rank, world, device):
     q0 = np.array([3.0, np.log(0.5)]) + 0.05 * np.random.default_rng(1 + rank).normal(size=(C, 2))
     kernel = nuts.new_kernel(RandomStream(seeds=[5000 + rank * C + c for c in range(C)]), target)
     state = nuts.new_state(torch.as_tensor(q0, device=device), target)
+    from aehmc_amd.engine import get_engine
+    eng = get_engine(device)
     t_w = time.perf_counter()
     state, (eps, imm), _ = window_adaptation.run(kernel, state, max(args.warmup, 20))
     torch.cuda.synchronize(device)
     t_w = time.perf_counter() - t_w
+    eng.profile_enable(True)
     barrier(device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -401,29 +474,45 @@ def bench_c5(args, rank, world, device):
     torch.cuda.synchronize(device)
     barrier(device)
     elapsed = max_over_ranks(time.perf_counter() - t0, device)
-    total = sum_over_ranks(int(info.n_leapfrog.sum().item()), device)
+    total_rank = int(info.n_leapfrog.sum().item())
+    total = sum_over_ranks(total_rank, device)
     chains_total = sum_over_ranks(C, device)
+    kern_ms, kern_n, _ = eng.profile_read()
+    eng.profile_enable(False)
     if rank == 0:
         assert gathered.shape[0] == chains_total
         rate = total / elapsed
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline_c5(X, y, info, eps, imm)
+        # The dominant kernel is k_nuts_linreg (the whole sample() call is ONE launch of it).  Neither HBM nor
+        # MFMA bounds it: per leapfrog a chain needs 3 fp64 FMAs (6 flop) per data row, the rows (16 B each) come
+        # from L2 / LDS once per leapfrog round of a 4-chain workgroup.  achieved = algorithmic flop of the launch
+        # (6 x rows x this rank's leapfrogs) / its duration (HIP events on the launch stream); counters offline.
+        avg_s = kern_ms / 1e3 / max(kern_n, 1)
+        flops = 6.0 * N * total_rank / max(kern_n, 1)
+        achieved = flops / avg_s / 1e12
+        pj, src = pmc_summary("c5_pmc_summary.json")
+        if not (pj and C == 1024):
+            pj, src = None, None
+        roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP64_VALU_TFLOPS, "kernel": "k_nuts_linreg", "avg_launch_ms": avg_s * 1e3,
+                    "launches": kern_n, "algorithmic_flops_per_launch": flops,
+                    "algorithmic_l2_bytes_per_launch": 16.0 * N * total_rank / 4 / max(kern_n, 1),
+                    "traffic": pj["derived"]["hbm_bytes_per_launch"] if pj else None, "traffic_source": src,
+                    "counters": pj["derived"] if pj else None,
+                    "note": "3 FMAs per row, chain and leapfrog against the fp64 vector peak; the sweep of a 4-chain "
+                            "workgroup also pulls 16 B per row through its CU's 64 B/clk vector-memory path (rows beyond "
+                            "the 10176 kept in LDS), which bounds a sweep at about the same time as the FMAs: DESIGN.md"}
         print(json.dumps({
             "metric": "leapfrog-steps/sec across all chains", "value": rate, "unit": "leapfrog-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"c5: linear regression, {N} rows, D=2, NUTS after {max(args.warmup, 20)} "
                                    f"window-adaptation steps ({t_w:.2f} s, one launch), {C} chains/GPU",
-                       "chains_total": chains_total, "data_rows_per_s": rate * N},
-            # neither HBM nor MFMA bounds this path: per leapfrog a chain needs 3 fp64 FMAs per data row
-            # (the rows come from L2 / LDS), so the figure of merit is the vector-FMA rate
-            "roofline": None,
-            "valu": {"bound": "fp64 vector FMA", "achieved": rate / world * N * 6 / 1e12, "peak": 78.6,
-                     "unit": "TFLOP/s", "frac": rate / world * N * 6 / 1e12 / 78.6,
-                     "note": "3 FMAs per row and leapfrog; the sweep also pulls 16 B per row and workgroup "
-                             "from L2 (4 chains share it): see DESIGN.md"},
-            "cpu_baseline": cpu}))
+                       "chains_total": chains_total, "data_rows_per_s": rate * N,
+                       "leapfrogs_per_step": total / args.steps},
+            "roofline": roofline, "cpu_baseline": cpu}))
 
 
 def cpu_baseline_c5(X, y, info, eps, imm):
@@ -464,7 +553,7 @@ def cpu_baseline(config, D, q0, target, imm, eps):
     from oracle import c_oracle as co
     cores = os.cpu_count() or 1
 
-    def run(n, threads):
+    def run(n, threads, max_exp=None):
         seeds = [1000 + c for c in range(n)]
         if config == "c3":
             rng = co.site_states(seeds, 4)
@@ -482,12 +571,23 @@ def cpu_baseline(config, D, q0, target, imm, eps):
     if config == "c3":
         otgt = co.Target(co.T_DENSE_MVN, D, mu=np.zeros(D), prec=target.precision.cpu().numpy())
         metric = co.Metric(imm.cpu().numpy(), D)
-        max_exp = 2  # bounded: 2 + 3 = 5 leapfrogs per chain (a full-depth tree is ~57: minutes on a CPU)
-        # every mat-vec streams an 800 MB matrix: the all-cores leg is DRAM-bound well below the core count,
-        # so 64 chains (= threads that get work) saturate it within the time budget
-        n_all = min(cores, 64, q0.shape[0])
-        what = (f"NUTS transition truncated at max_num_expansions={max_exp} (5 leapfrogs/chain), same D / target / "
-                f"dense metric as the GPU run")
+        # bounded sample: ONE chain through a whole depth-10 transition on one thread (~35-70 leapfrogs), and an
+        # all-cores leg truncated at max_num_expansions=4 (2 + 3 + 5 + 9 = 19 leapfrogs per chain; a full tree is
+        # ~57).  Every mat-vec streams an 800 MB matrix, so the all-cores leg is DRAM-bound well below the core
+        # count: 32 chains (= threads that get work) saturate it within the time budget.
+        n_all = min(cores, 32, q0.shape[0])
+        what = ("NUTS transition truncated at max_num_expansions=4 (19 leapfrogs/chain), same D / target / dense "
+                "metric as the GPU run")
+        nl1, dt1 = run(1, 1, 10)
+        used = min(cores, n_all)
+        nla, dta = run(n_all, used, 4)
+        return {"value": nla / dta, "unit": "leapfrog-steps/s", "cores": used, "kind": "port",
+                "sample": f"{n_all} chains x {what}, {used} OpenMP threads over chains ({nla} leapfrogs, {dta:.1f} s)",
+                "single_thread": {"value": nl1 / dt1, "unit": "leapfrog-steps/s", "cores": 1,
+                                  "sample": f"1 chain x one full NUTS transition at max_tree_depth=10 ({nl1} leapfrogs, "
+                                            f"{dt1:.1f} s)"},
+                "host_cpu_count": cores,
+                "note": "C restatement of aehmc semantics (oracle/c), not Aesara; reported, not optimised"}
     else:
         otgt, metric = co.Target(co.T_ISO_GAUSSIAN, D), co.Metric(np.ones(D), D)
         # (one oracle call = one transition of all chains: ~1e8 flop, so the fork / join of a 256-thread
@@ -495,13 +595,13 @@ def cpu_baseline(config, D, q0, target, imm, eps):
         reps, n_all = 20, q0.shape[0]
         cores = min(cores, 32)
         what = f"{reps} HMC transitions (L=32) per chain"
-    nl1, dt1 = run(1 if config == "c3" else 8, 1)
+    nl1, dt1 = run(8, 1)
     used = min(cores, n_all)  # threads that get a chain
     nla, dta = run(n_all, used)
     return {"value": nla / dta, "unit": "leapfrog-steps/s", "cores": used, "kind": "port",
             "sample": f"{n_all} chains x {what}, {used} OpenMP threads over chains ({nla} leapfrogs, {dta:.1f} s)",
             "single_thread": {"value": nl1 / dt1, "unit": "leapfrog-steps/s", "cores": 1,
-                              "sample": f"{1 if config == 'c3' else 8} chain(s) x {what} ({nl1} leapfrogs, {dt1:.1f} s)"},
+                              "sample": f"8 chains x {what} ({nl1} leapfrogs, {dt1:.1f} s)"},
             "host_cpu_count": cores,
             "note": "C restatement of aehmc semantics (oracle/c), not Aesara; reported, not optimised"}
 

@@ -2,12 +2,16 @@
 seeding and the one exchange step (sample gather)."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -76,3 +80,15 @@ def test_bench_refuses_mismatched_world():
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
                              capture_output=True, text=True, timeout=300)
         assert out.returncode != 0 and "GPU(s) visible" in out.stderr
+
+
+def test_bench_a_failing_rank_ends_the_run():
+    """A rank that dies before the rendezvous must not leave its siblings (and the driver) waiting: the parent
+    terminates them, relays the failing rank's stderr and exits non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(AEHMC_BENCH_ONE_DEVICE="1", AEHMC_DIST_BACKEND="gloo", AEHMC_BENCH_FAIL_RANK="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--chains", "64", "--dim", "256", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert "rank 1 exited with code" in out.stderr and "injected failure" in out.stderr
