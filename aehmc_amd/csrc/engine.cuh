@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long 
 // metric products are per-chain mat-vecs instead of one GEMM over all chains.  Up to
 // AEHMC_PC_LDS_MAX_D the factorisation of a chain's matrix runs in LDS, above it in global memory.
 constexpr int AEHMC_PC_LDS_MAX_D = 64;
-constexpr int AEHMC_PC_DENSE_MAX_D = 2048;
+constexpr int AEHMC_PC_DENSE_MAX_D = 512;  // (tested and timed up to here: tests/test_gpu_adaptation.py)
 // out[c, i] = sum_j mats[c, i, j] x[c, j]  (j ascending); one wavefront per (live) chain
 __global__ __launch_bounds__(256) void k_matvec_pc(const double *mats, const double *x, double *out, long long C,
                                                    long long D, const int *row_idx, const int *n_rows) {
@@ -1192,7 +1192,8 @@ __global__ __launch_bounds__(256) void k_matvec_pc_rows(const double *mats, cons
                                                         long long C, long long D, const int *row_idx,
                                                         const int *n_rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long w = blockIdx.y;
+  const long long nrb = (D + 63) / 64;  // row blocks per chain; grid = nrb x C in one dimension (no 65535 limit on C)
+  const long long w = blockIdx.x / nrb, rb = blockIdx.x % nrb;
   long long c = w;
   if (row_idx) {
     if (w >= *n_rows) return;
@@ -1200,7 +1201,7 @@ __global__ __launch_bounds__(256) void k_matvec_pc_rows(const double *mats, cons
   }
   const double *m = mats + (size_t)c * D * D, *xr = x + (size_t)c * D;
   for (int k = 0; k < 16; k++) {
-    const long long i = (long long)blockIdx.x * 64 + wave * 16 + k;
+    const long long i = rb * 64 + wave * 16 + k;
     if (i >= D) break;
     double s = 0.0;
     for (long long j = lane; j < D; j += 64) s += m[i * D + j] * xr[j];
@@ -1428,6 +1429,23 @@ __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
     a.s.wc_n[c] = n;
     a.s.step_size[c] = step_size;
   }
+}
+
+// step_size.dual_averaging_adaptation's update alone (step_size.py:97-98, algorithms.py:104-115), one
+// thread per chain: the arithmetic of adapt_da_update, hence the bits of the warm-up kernels
+__global__ __launch_bounds__(256) void k_dual_averaging(long long C, double target, double gamma, double t0,
+                                                         double kappa, const double *p_accept, long long *step,
+                                                         double *x, double *x_avg, double *g_avg, const double *mu,
+                                                         double *step_size_out) {
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  DualAvg da = {step[c], x[c], x_avg[c], g_avg[c], mu[c]};
+  const double eps = adapt_da_update(da, target, p_accept[c], gamma, t0, kappa);
+  step[c] = da.step;
+  x[c] = da.x;
+  x_avg[c] = da.x_avg;
+  g_avg[c] = da.g_avg;
+  if (step_size_out) step_size_out[c] = eps;
 }
 
 __global__ __launch_bounds__(256) void k_fill_i64(long long *x, long long n, long long v) {

@@ -397,6 +397,22 @@ extern "C" int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t 
   return 0;
 }
 
+extern "C" int aehmc_dual_averaging_update(aehmc_ctx *ctx, int64_t C, double target_acceptance_rate, double gamma,
+                                           double t0, double kappa, const double *acceptance_probability,
+                                           int64_t *step, double *iterates, double *iterates_avg,
+                                           double *gradient_avg, const double *shrinkage_pts,
+                                           double *step_size_out, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (C <= 0 || !acceptance_probability || !step || !iterates || !iterates_avg || !gradient_avg || !shrinkage_pts)
+    FAIL("dual_averaging_update: bad arguments");
+  hipLaunchKernelGGL(k_dual_averaging, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (long long)C, target_acceptance_rate, gamma, t0, kappa, acceptance_probability,
+                     (long long *)step, iterates, iterates_avg, gradient_avg, shrinkage_pts, step_size_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return -2;
   if (!strcmp(name, "fused_hmc")) {
@@ -547,7 +563,14 @@ static int prof_end(aehmc_ctx *ctx, hipStream_t st, bool on) {
 // A stream-K hand-off that timed out leaves garbage partial sums: every entry point that waits
 // for the device (lagging poll, profile_read, aehmc_synchronize) and every GEMM launch reports it.
 static int check_device_errors(aehmc_ctx *ctx) {
-  if (ctx->h_err && ctx->h_err[0]) FAIL("stream-K GEMM: a workgroup hand-off timed out (results invalid)");
+  if (ctx->h_err && ctx->h_err[0]) {
+    // reported once: the ctx stays usable (e.g. after set_option("streamk", 0)); the lock-step loop's
+    // per-call state is reset because the call that saw the failure returns from the middle of it
+    ctx->h_err[0] = 0;
+    ctx->rows_hint = 0;
+    ctx->fuse_pre = ctx->pre_done = false;
+    FAIL("stream-K GEMM: a workgroup hand-off timed out (results invalid)");
+  }
   return 0;
 }
 extern "C" int aehmc_synchronize(aehmc_ctx *ctx, void *stream) {
@@ -584,7 +607,7 @@ static int metric_mul(aehmc_ctx *ctx, int64_t C, const double *X, const double *
       hipLaunchKernelGGL(k_matvec_pc, chain_grid(C), dim3(256), 0, st, mat, X, out, (long long)C, (long long)D,
                          row_idx, n_rows);
     else
-      hipLaunchKernelGGL(k_matvec_pc_rows, dim3((unsigned)((D + 63) / 64), (unsigned)C), dim3(256), 0, st, mat, X,
+      hipLaunchKernelGGL(k_matvec_pc_rows, dim3((unsigned)(((D + 63) / 64) * C)), dim3(256), 0, st, mat, X,
                          out, (long long)C, (long long)D, row_idx, n_rows);
     HIPCHK(hipGetLastError());
     return 0;
@@ -887,6 +910,10 @@ extern "C" int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->has_tgt) FAIL("set_target and set_metric must be called first");
   if (!ctx->eps_c || !ctx->met.per_chain) FAIL("warm-up needs per-chain step sizes and a per-chain metric bound to the adaptation state");
+  // every path samples with the bound arrays while the update kernel rewrites the state's: they must be the same
+  if (ctx->met.imm != state->imm || ctx->met.sqrt_mass != state->sqrt_mass || ctx->eps_c != state->step_size)
+    FAIL("warm-up: the bound per-chain metric / step sizes are not the adaptation state's own arrays "
+         "(bind state->imm, state->sqrt_mass with aehmc_set_metric and state->step_size with aehmc_set_step_sizes)");
   const int64_t D = ctx->tgt.D;
   // diagonal mass matrix, regression target or a coordinate-wise target with D <= 512: the whole warm-up
   // in ONE launch, the chains adapting and moving on at their own pace (nuts_linreg.cuh: every chain;
@@ -894,8 +921,7 @@ extern "C" int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64
   const int path = ctx->has_met ? nuts_path(ctx, C, max_num_expansions) : NUTS_PATH_LOCKSTEP;
   if (num_steps > 0 && (path == NUTS_PATH_LINREG || path == NUTS_PATH_TEAMS) && !state->full &&
       (ctx->met.ndim == 1 || (ctx->met.ndim == 0 && D == 1 && path == NUTS_PATH_TEAMS)) &&
-      ctx->met.per_chain && ctx->met.imm == state->imm && ctx->met.sqrt_mass == state->sqrt_mass &&
-      ctx->eps_c == state->step_size) {
+      ctx->met.per_chain) {
     hipStream_t st = (hipStream_t)stream;
     AdaptArgs aa;
     if (int rc = adapt_args(ctx, C, D, state, aa)) return rc;

@@ -16,7 +16,7 @@
 namespace aehmc {
 
 // 128-bit unsigned integers of the PCG64 state as two 64-bit halves with explicit arithmetic.  (With
-// `unsigned __int128` hipcc 7.2 lost the upper half of the loop-carried generator state inside the
+// `unsigned __int128` state hipcc 7.2 lost the upper half of the loop-carried generator state inside the
 // inlined ziggurat redraw loop of k_nuts_resident<1,1>: the registers of an exp() coefficient were
 // multiplied in its place, so the redraws ran on a garbage state.  The RNG-state parity tests cover
 // every kernel family that draws normals, at sizes that take the redraw path.)
@@ -29,14 +29,18 @@ __host__ __device__ __forceinline__ u128 mk128(uint64_t hi, uint64_t lo) {
   r.lo = lo;
   return r;
 }
-// (the arithmetic itself goes through the compiler's 128-bit integers -- one multiply-add chain with
-//  hardware carries -- but no 128-bit VALUE outlives these functions: states live as two 64-bit words)
-typedef unsigned __int128 wide_u128;
-__device__ __forceinline__ wide_u128 widen(u128 a) { return (((wide_u128)a.hi) << 64) | (wide_u128)a.lo; }
-__device__ __forceinline__ u128 narrow(wide_u128 a) { return mk128((uint64_t)(a >> 64), (uint64_t)a); }
-__device__ __forceinline__ u128 mul128(u128 a, u128 b) { return narrow(widen(a) * widen(b)); }  // low 128 bits
-__device__ __forceinline__ u128 add128(u128 a, u128 b) { return narrow(widen(a) + widen(b)); }
-__device__ __forceinline__ u128 muladd128(u128 a, u128 b, u128 c) { return narrow(widen(a) * widen(b) + widen(c)); }
+// The arithmetic is written on the 64-bit halves too (round 3): the low 128 bits of a product are
+//   lo = a.lo * b.lo (low word),  hi = umulhi(a.lo, b.lo) + a.hi * b.lo + a.lo * b.hi   (mod 2^64),
+// and a sum carries with a compare -- no `__int128` value or operation exists in the IR, so the pass that
+// lost the upper word has nothing to work on, whatever instantiation or compiler comes next.
+__device__ __forceinline__ u128 mul128(u128 a, u128 b) {  // low 128 bits
+  return mk128(__umul64hi(a.lo, b.lo) + a.hi * b.lo + a.lo * b.hi, a.lo * b.lo);
+}
+__device__ __forceinline__ u128 add128(u128 a, u128 b) {
+  const uint64_t lo = a.lo + b.lo;
+  return mk128(a.hi + b.hi + (lo < a.lo ? 1ULL : 0ULL), lo);
+}
+__device__ __forceinline__ u128 muladd128(u128 a, u128 b, u128 c) { return add128(mul128(a, b), c); }
 
 __constant__ uint64_t c_zig_ki[256] = {AEHMC_ZIG_KI_VALUES};
 __constant__ double c_zig_wi[256] = {AEHMC_ZIG_WI_VALUES};

@@ -17,13 +17,52 @@ from . import _lib
 from .targets import Target
 
 
-def _content_key(arr: np.ndarray):
-    """Key a host array by CONTENT: numpy inputs may be edited in place between calls (the
-    reference re-reads the matrix on every call), so id() alone must never hit the cache."""
-    buf = memoryview(np.ascontiguousarray(arr)).cast("B")
+_FULL_HASH_BYTES = 64 << 20
+_warned_big_host_array = False
+
+
+def _digest(buf):
     if xxhash is not None:
         return xxhash.xxh3_128_hexdigest(buf)
     return hashlib.blake2b(buf, digest_size=16).hexdigest()
+
+
+def _content_key(arr: np.ndarray):
+    """Key a host array by CONTENT: numpy inputs may be edited in place between calls (the
+    reference re-reads the matrix on every call), so id() alone must never hit the cache.
+
+    Up to 64 MB the whole array is hashed (xxh3: ~10 GB/s).  Above that -- an 800 MB dense matrix at
+    D = 1e4 would cost 0.1-1 s per step() call, as much as the transition itself -- the key is the
+    buffer's address, shape and strides plus the hash of a strided 1/256 sample and of the first and
+    last MB: an in-place edit that misses the sample needs ``set_metric(..., force=True)`` /
+    ``set_target(..., force=True)``.  Passing a torch tensor (keyed by identity and version counter,
+    already on the device) avoids both the hashing and the upload; a warning says so once."""
+    global _warned_big_host_array
+    a = np.ascontiguousarray(arr)
+    buf = memoryview(a).cast("B")
+    if a.nbytes <= _FULL_HASH_BYTES:
+        return _digest(buf)
+    if not _warned_big_host_array:
+        _warned_big_host_array = True
+        import warnings
+        warnings.warn(f"aehmc_amd: a {a.nbytes >> 20} MB host array is re-checked (sampled hash) on every call and "
+                      "re-uploaded when it changes; pass a torch tensor on the device to skip both "
+                      "(in-place edits of a large numpy array need force=True)", stacklevel=4)
+    flat = a.reshape(-1)
+    sample = np.ascontiguousarray(flat[::256])
+    mb = (1 << 20) // a.itemsize
+    return ("sampled", a.__array_interface__["data"][0], a.shape, a.strides,
+            _digest(memoryview(sample).cast("B")), _digest(memoryview(flat[:mb]).cast("B")),
+            _digest(memoryview(flat[-mb:]).cast("B")))
+
+
+def _param_key(v):
+    """Cache key of one target / metric parameter: torch tensors by identity + version counter, anything
+    else (numpy arrays, lists, scalars) by content."""
+    if isinstance(v, torch.Tensor):
+        return ("t", id(v), v._version, tuple(v.shape))
+    arr = np.asarray(v, dtype=np.float64)
+    return ("n", arr.shape, _content_key(arr))
 
 
 def _asymmetry(t: torch.Tensor) -> float:
@@ -97,11 +136,14 @@ class Engine:
         return ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ------------------------------------------------------------------ binding
-    def set_target(self, target: Target, D: int):
-        key = (id(target), D)
-        if self._target_key == key:
+    def set_target(self, target: Target, D: int, force: bool = False):
+        # keyed by the CONTENT of the parameters (numpy arrays edited in place between calls must be seen,
+        # as for the metric below), not by the identity of the Target object
+        params = target.params()
+        key = (type(target), D, tuple((k, _param_key(v)) for k, v in sorted(params.items())))
+        if self._target_key == key and not force:
             return
-        p = {k: _dev_f64(v, self.device) for k, v in target.params().items()}
+        p = {k: _dev_f64(v, self.device) for k, v in params.items()}
         if target.dim is not None and target.dim != D:
             raise ValueError(f"target has dimension {target.dim}, position has {D}")
         c = _lib.CTarget(kind=target.kind, D=D, N=0)
@@ -115,7 +157,7 @@ class Engine:
         self._target_key, self.D = key, D
         self._ws = None
 
-    def set_metric(self, inverse_mass_matrix, D: int):
+    def set_metric(self, inverse_mass_matrix, D: int, force: bool = False):
         """gaussian_metric(inverse_mass_matrix) -- aehmc/metrics.py:44-63."""
         imm = inverse_mass_matrix
         if isinstance(imm, PerChain):
@@ -129,7 +171,7 @@ class Engine:
         else:  # numpy / python scalars may be mutated in place: keyed by content, whatever the size
             arr = np.asarray(imm, dtype=np.float64)
             key = (arr.shape, _content_key(arr), D)
-        if self._metric_key == key:
+        if self._metric_key == key and not force:
             return
         t = _dev_f64(imm, self.device)
         if ndim == 2:
@@ -381,6 +423,13 @@ class Engine:
         self._check(self.lib.aehmc_adapt_update(self.ctx, C, D, int(stage), int(window_end), int(last),
                                                 float(target), p_accept.data_ptr(), position.data_ptr(),
                                                 ct.byref(cstate), self.stream), "aehmc_adapt_update")
+
+    def dual_averaging_update(self, target, gamma, t0, kappa, p_accept, step, x, x_avg, g_avg, mu, step_size_out):
+        self._check(self.lib.aehmc_dual_averaging_update(
+            self.ctx, step.numel(), float(target), float(gamma), float(t0), float(kappa), p_accept.data_ptr(),
+            step.data_ptr(), x.data_ptr(), x_avg.data_ptr(), g_avg.data_ptr(), mu.data_ptr(),
+            step_size_out.data_ptr() if step_size_out is not None else None, self.stream),
+            "aehmc_dual_averaging_update")
 
     def profile_enable(self, on=True):
         self._check(self.lib.aehmc_profile_enable(self.ctx, int(on)), "aehmc_profile_enable")

@@ -15,6 +15,14 @@ _M64 = (1 << 64) - 1
 
 
 class RandomStream:
+    """``RandomStream(seed)`` (one chain) or ``RandomStream(seeds=[...])`` (one seed per chain).
+
+    Resuming: a kernel returns ``updates = {srng: states}`` with the generator states ``[C, n, 4]`` of
+    its call sites after the transition (the reference threads them through ``updates`` the same way,
+    README.md:49-51, nuts.py:138-153).  ``RandomStream.from_state(states, seeds=...)`` rebuilds a stream
+    whose NEXT kernel continues exactly there -- save ``states.cpu().numpy()`` with the chain state,
+    restore later, get the transitions an unbroken run would have produced."""
+
     def __init__(self, seed=None, seeds=None):
         if seeds is None:
             seeds = [seed]
@@ -24,13 +32,54 @@ class RandomStream:
         self.seeds = [int(s) if s is not None else None for s in np.atleast_1d(seeds).tolist()]
         self._seed_seqs = [np.random.SeedSequence(s) for s in self.seeds]
         self._n_spawned = 0
+        self._resume = None  # generator states handed to the next kernel instead of fresh spawns
+
+    @classmethod
+    def from_state(cls, states, seed=None, seeds=None, batched=None):
+        """Stream whose next ``sites(n)`` returns the saved states ``[C, n, 4]`` (uint64 / int64 bit
+        patterns; a device tensor, numpy array or nested list) instead of spawning.  With the original
+        ``seed`` / ``seeds`` the spawn counter moves on as well, so kernels built AFTER the resumed one
+        get the same call sites as in an unbroken session; without them a further kernel raises."""
+        if hasattr(states, "detach"):
+            states = states.detach().cpu().numpy()
+        arr = np.ascontiguousarray(np.asarray(states))
+        if arr.dtype != np.uint64:
+            arr = arr.astype(np.int64).view(np.uint64)
+        if arr.ndim != 3 or arr.shape[2] != 4:
+            raise ValueError(f"generator states must be [C, n_sites, 4], got {arr.shape}")
+        C = arr.shape[0]
+        if seeds is None and seed is None:
+            self = cls(seeds=[None] * C)
+            self._seed_seqs = None
+            self.batched = (C > 1) if batched is None else bool(batched)
+        else:
+            self = cls(seed=seed, seeds=seeds)
+            if self.num_chains != C:
+                raise ValueError(f"{self.num_chains} seeds for {C} saved chains")
+            if batched is not None:
+                self.batched = bool(batched)
+        self._resume = arr.copy()
+        return self
 
     @property
     def num_chains(self) -> int:
-        return len(self._seed_seqs)
+        return len(self.seeds)
 
     def sites(self, n: int) -> np.ndarray:
         """Next ``n`` RNG call sites for every chain -> uint64 [C, n, 4]."""
+        if self._resume is not None:
+            if self._resume.shape[1] != n:
+                raise ValueError(f"the saved state holds {self._resume.shape[1]} call sites, the kernel being built "
+                                 f"has {n} (NUTS: 4, HMC: 2)")
+            out, self._resume = self._resume, None
+            if self._seed_seqs is not None:  # keep the spawn sequence where the unbroken session would be
+                for ss in self._seed_seqs:
+                    ss.spawn(n)
+                self._n_spawned += n
+            return out
+        if self._seed_seqs is None:
+            raise ValueError("this stream was rebuilt from saved states without its seeds: it can resume ONE kernel; "
+                             "pass seed= / seeds= to RandomStream.from_state to build further ones")
         out = np.empty((self.num_chains, n, 4), dtype=np.uint64)
         for c, ss in enumerate(self._seed_seqs):
             for k, child in enumerate(ss.spawn(n)):

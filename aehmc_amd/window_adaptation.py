@@ -36,9 +36,9 @@ def build_schedule(num_steps: int, initial_buffer_size: int = 75, final_buffer_s
 
 
 def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matrix_full=False,
-        initial_step_size=1.0, target_acceptance_rate=0.80, fused=True
+        initial_step_size=1.0, target_acceptance_rate=0.80, fused=True, num_integration_steps=None
         ) -> Tuple[IntegratorState, Tuple, Dict]:
-    """Warm a (NUTS) kernel up for ``num_steps`` transitions (reference:
+    """Warm a kernel up for ``num_steps`` transitions (reference:
     aehmc/window_adaptation.py:17-116).  Returns ``(last_chain_state, (step_size,
     inverse_mass_matrix), updates)`` where the parameters are ``PerChain`` values -- one
     step size and one (diagonal or dense) inverse mass matrix per chain, exactly as running the
@@ -47,7 +47,15 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     With a NUTS kernel of this package the whole loop runs inside one C-ABI call
     (``aehmc_nuts_warmup``: transition, adaptation update, transition, ... enqueued back to back);
     ``fused=False`` -- and any other kernel -- takes the step-by-step loop below, which issues the
-    same kernels in the same order (identical results)."""
+    same kernels in the same order (identical results).
+
+    An HMC kernel (``hmc.new_kernel``) takes a fourth argument; pass its fixed trajectory length as
+    ``num_integration_steps`` and the loop calls ``kernel(state, step_size, imm, num_integration_steps)``
+    (the reference's loop calls ``kernel(chain_state, *parameters)``, window_adaptation.py:66, so there an
+    HMC kernel has to be wrapped in a lambda that closes over the length -- which works here too)."""
+    if getattr(kernel, "_hmc", None) is not None and num_integration_steps is None:
+        raise ValueError("window_adaptation.run with an HMC kernel needs num_integration_steps")
+    extra = () if num_integration_steps is None else (int(num_integration_steps),)
     eng = get_engine()
     pos = initial_state.position
     srng_chains = getattr(kernel, "num_chains", None)
@@ -56,9 +64,9 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     C, D = layout.C, layout.D
     scalar_position = (len(layout.user_shape) - (1 if batched else 0)) == 0
     full = bool(is_mass_matrix_full) and not scalar_position  # mass_matrix.py:54-57: a scalar stays a scalar
-    if full and D > 2048:  # C x D x D doubles per array: memory is the real bound
+    if full and D > 512:  # one wavefront factors each chain's matrix: tested and timed up to here
         raise ValueError("is_mass_matrix_full keeps one dense D x D matrix per chain (as the reference does) and "
-                         "is supported up to D = 2048")
+                         "is supported up to D = 512")
     st, cst = eng.adapt_alloc(C, D, full)
     eng.adapt_init(C, D, float(initial_step_size), cst)
     schedule = build_schedule(int(num_steps))
@@ -82,7 +90,7 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     else:
         state, updates = initial_state, {}
     for i, (stage, window_end) in enumerate(schedule):
-        info, updates = kernel(state, PerChain(st["step_size"]), imm_param())
+        info, updates = kernel(state, PerChain(st["step_size"]), imm_param(), *extra)
         state = info.state._replace(momentum=None)
         eng.adapt_update(C, D, stage, window_end, i == len(schedule) - 1, float(target_acceptance_rate),
                          info.acceptance_probability.reshape(C).contiguous(),

@@ -66,7 +66,7 @@ typedef struct {
 typedef struct {
   int32_t ndim;
   int32_t per_chain;       /* 1: imm / sqrt_mass are [C,1] (ndim 0), [C,D] (ndim 1) or [C,D,D]
-                              (ndim 2, D <= 2048), one per chain -- what per-chain window
+                              (ndim 2, D <= 512), one per chain -- what per-chain window
                               adaptation produces; sqrt_mass must be given
                               (aehmc_metric_sqrt_per_chain computes the dense one); 0: shared */
   int64_t D;
@@ -89,7 +89,7 @@ typedef struct {
   double *step_size;                     /* [C] */
   double *imm, *sqrt_mass;               /* [C,D] */
   int32_t full;                          /* 1: is_mass_matrix_full -- wc_m2, imm and sqrt_mass are
-                                            [C,D,D] (full covariance per chain, D <= 2048) */
+                                            [C,D,D] (full covariance per chain, D <= 512) */
   int32_t reserved;
   double *work;                          /* full && D > 64: [C,D,D] scratch of the window-end
                                             factorisation (smaller D: LDS; may be NULL) */
@@ -189,6 +189,18 @@ int aehmc_adapt_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t stage, int3
                        const double *acceptance_probability, const double *position,
                        const aehmc_adapt_state *state, void *stream);
 
+/* step_size.dual_averaging_adaptation(target, gamma, t0, kappa) -> update (step_size.py:9-100 over
+ * algorithms.dual_averaging, algorithms.py:17-115) as a stand-alone building block around any kernel
+ * (tests/test_step_size.py:13-88 wraps hmc.new_kernel with it): one update of the C per-chain states
+ * (step [C] int64, iterates x = log step size, iterates_avg, gradient_avg, shrinkage_pts mu, all [C],
+ * in place) with gradient = target_acceptance_rate - acceptance_probability.  The states start as
+ * algorithms.py:56-76 says: step 1, x = x_avg = gradient_avg = 0, mu as given.  `step_size_out` [C]
+ * (may be NULL) receives exp(x) of the updated iterate -- what the test feeds to the next transition. */
+int aehmc_dual_averaging_update(aehmc_ctx *ctx, int64_t C, double target_acceptance_rate, double gamma,
+                                double t0, double kappa, const double *acceptance_probability,
+                                int64_t *step, double *iterates, double *iterates_avg, double *gradient_avg,
+                                const double *shrinkage_pts, double *step_size_out, void *stream);
+
 /* window_adaptation.run (window_adaptation.py:17-116) for a NUTS kernel: num_steps x (one transition
  * with the current per-chain parameters, then aehmc_adapt_update), enqueued in one call.  `stage` /
  * `is_window_end` [num_steps] are HOST arrays from build_schedule.  Before the call the caller binds
@@ -213,7 +225,7 @@ int aehmc_nuts_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size
                       double *acceptance_history, int32_t *divergence_history,
                       int64_t *n_leapfrog_total, void *stream);
 
-/* sqrt_mass[c] = chol(imm[c])^-T (metrics.py:56-58) for C dense D x D matrices, D <= 2048 (one
+/* sqrt_mass[c] = chol(imm[c])^-T (metrics.py:56-58) for C dense D x D matrices, D <= 512 (one
  * wavefront per matrix: in LDS up to D = 64, in a temporary device buffer above) */
 int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D, const double *imm, double *sqrt_mass,
                                 void *stream);

@@ -152,7 +152,7 @@ def test_metric_sqrt_per_chain_matches_numpy():
     from aehmc_amd.engine import EngineError, get_engine
     eng = get_engine()
     r = np.random.default_rng(3)
-    for D in (1, 2, 5, 17, 64, 65, 130, 300):  # LDS up to 64, global memory above
+    for D in (1, 2, 5, 17, 64, 65, 130, 300, 512):  # LDS up to 64, global memory above; 512 = the documented maximum
         C = 7
         A = r.normal(size=(C, D, D))
         imm = A @ A.transpose(0, 2, 1) / D + 0.5 * np.eye(D)
@@ -164,10 +164,10 @@ def test_metric_sqrt_per_chain_matches_numpy():
     bad = np.stack([np.eye(3), np.diag([1.0, -1.0, 1.0])])
     with pytest.raises(EngineError, match="positive definite"):
         eng.set_metric(PerChain(torch.as_tensor(bad, device="cuda")), 3)
-    with pytest.raises(EngineError, match="up to D = 2048"):
+    with pytest.raises(EngineError, match="up to D = 512"):
         eng.lib.aehmc_metric_sqrt_per_chain.restype  # (the limit is checked before any allocation)
         z = torch.zeros(1, dtype=torch.float64, device="cuda")
-        eng._check(eng.lib.aehmc_metric_sqrt_per_chain(eng.ctx, 1, 2049, z.data_ptr(), z.data_ptr(), eng.stream),
+        eng._check(eng.lib.aehmc_metric_sqrt_per_chain(eng.ctx, 1, 513, z.data_ptr(), z.data_ptr(), eng.stream),
                    "aehmc_metric_sqrt_per_chain")
 
 

@@ -207,3 +207,85 @@ def test_config3_equals_the_isotropic_problem_under_its_cholesky_map(c3_model):
     assert torch.equal(runs["c3"][1], runs["iso"][1])
     nl = runs["c3"][0][0].n_leapfrog
     assert nl.max().item() >= 33 and len(torch.unique(nl)) >= 2  # real, unequal trees
+
+
+# ------------------------------------------------------------------ config c5 at its real size
+def _c5_problem(C):
+    """bench.py's c5 workload: the notebook's generator scaled to 1e5 rows, D = 2, rank 0's chains."""
+    from aehmc_amd import RandomStream, nuts, targets
+    rng = np.random.default_rng(0)
+    N = 100_000
+    X = rng.normal(0, 1, size=(N,))
+    y = 3 * X + rng.normal(0, 1)
+    tgt = targets.LinearRegression(X, y)
+    q0 = np.array([3.0, np.log(0.5)]) + 0.05 * np.random.default_rng(1).normal(size=(C, 2))
+    srng = RandomStream(seeds=[5000 + c for c in range(C)])
+    kernel = nuts.new_kernel(srng, tgt)
+    state = nuts.new_state(dev(q0), tgt)
+    return X, y, tgt, srng, kernel, state
+
+
+@pytest.mark.timeout(900)
+def test_config5_full_size_matches_oracle_after_warmup():
+    """c5 AS BENCHMARKED -- 1e5 rows, 1024 chains, the 1000-step window adaptation in one launch -- then three
+    transitions of every chain with its own adapted step size and inverse mass matrix.  Eight of the 1024
+    chains (first and last of the launch, both chains of the last workgroup, four in between) against the C
+    restatement started from the GPU's post-warm-up state and generator states: positions, energies,
+    gradients, momenta and acceptance statistics to 1e-9, leapfrog counts, doublings, flags and the
+    generator states after every transition identical.  (The sums over 1e5 rows are added in another order
+    than the oracle's: 1e-13.)"""
+    from aehmc_amd import window_adaptation
+    C = 1024
+    X, y, tgt, srng, kernel, state = _c5_problem(C)
+    otgt = co.Target(co.T_LINREG, 2, X=X, y=y)
+    state, (eps, imm), upd = window_adaptation.run(kernel, state, 1000)
+    e, m = eps.value.cpu().numpy(), imm.value.cpu().numpy()
+    assert np.isfinite(e).all() and (e > 0).all() and np.median(e) < 0.5 and (m > 0).all()
+    picks = [0, 1, 2, 3, 257, 514, 1022, 1023]
+    rng = {c: upd[srng][c].cpu().numpy().view(np.uint64).reshape(1, 4, 4).copy() for c in picks}
+    host = {c: co.new_state(otgt, state.position[c:c + 1].cpu().numpy().copy()) for c in picks}
+    for c in picks:  # the warm-up's running state equals a fresh evaluation at its position
+        np.testing.assert_allclose(host[c][1], state.potential_energy[c].item(), rtol=1e-11)
+    total = 0
+    for t in range(3):
+        info, upd = kernel(state, eps, imm)
+        state = info.state._replace(momentum=None)
+        for c in picks:
+            q, U, g = host[c]
+            res = co.nuts_step(otgt, co.Metric(m[c], 2), rng[c], float(e[c]), q, U, g)
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), q[0], rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(info.state.potential_energy[c].item(), U[0], rtol=RTOL)
+            np.testing.assert_allclose(info.state.potential_energy_grad[c].cpu().numpy(), g[0], rtol=1e-7, atol=1e-6)
+            np.testing.assert_allclose(info.state.momentum[c].cpu().numpy(), res["momentum"][0], rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(info.acceptance_probability[c].item(), res["acceptance_probability"][0], rtol=1e-8)
+            assert info.n_leapfrog[c].item() == res["n_leapfrog"][0]
+            assert info.num_doublings[c].item() == res["num_doublings"][0]
+            assert bool(info.is_turning[c].item()) == bool(res["is_turning"][0])
+            assert bool(info.is_diverging[c].item()) == bool(res["is_diverging"][0])
+            assert np.array_equal(upd[srng][c].cpu().numpy().view(np.uint64).reshape(1, 4, 4), rng[c]), (t, c)
+            total += int(res["n_leapfrog"][0])
+    assert total >= 3 * len(picks) * 2  # real trees (2 or 5 leapfrogs after warm-up), not first-step divergences
+    acc = info.acceptance_probability.cpu().numpy()
+    assert 0.6 < acc.mean() < 0.95  # the adaptation's 0.8 target
+
+
+@pytest.mark.timeout(900)
+def test_config5_thousand_step_warmup_in_one_launch_equals_the_loop():
+    """The bench's 1000-step warm-up at 1e5 rows, five chains (one full workgroup and one with a single
+    chain): the single launch in which every chain adapts and goes on at its own pace against the
+    step-by-step loop (one launch per transition + k_adapt_update) -- state, step sizes, inverse mass
+    matrices, their square roots, the following transition and the generator states bit for bit."""
+    from aehmc_amd import window_adaptation
+    C = 5
+    outs = []
+    for fused in (True, False):
+        X, y, tgt, srng, kernel, state = _c5_problem(C)
+        state, (eps, imm), upd = window_adaptation.run(kernel, state, 1000, fused=fused)
+        info, upd = kernel(state, eps, imm)
+        outs.append((state.position.clone(), state.potential_energy.clone(), state.potential_energy_grad.clone(),
+                     eps.value.clone(), imm.value.clone(), imm.sqrt_mass.clone(), info.state.position.clone(),
+                     info.n_leapfrog.clone(), upd[srng].clone()))
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), k
+    e = outs[0][3].cpu().numpy()
+    assert np.isfinite(e).all() and (e > 0).all() and len(np.unique(e)) == C
