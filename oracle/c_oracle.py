@@ -40,7 +40,8 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = ct.CDLL(build())
+        # AEHMC_ORACLE_LIB: another build of the same source (the ASan / UBSan one of `make asan`)
+        _LIB = ct.CDLL(os.environ.get("AEHMC_ORACLE_LIB") or build())
         _LIB.ao_kinetic_energy.restype = ct.c_double
     return _LIB
 

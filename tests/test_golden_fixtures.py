@@ -45,7 +45,9 @@ def _oracle_run(case):
 @pytest.mark.parametrize("case", FIX["derived"], ids=lambda c: c["name"])
 def test_oracle_reproduces_fixtures(case):
     for q, U, res, st in _oracle_run(case):
-        assert np.array_equal(q, np.array(st["position"]))  # same machine code path: bit-exact
+        # the fixtures were written by this same restatement; another host's libm (exp / log in the acceptance
+        # arithmetic) or compiler may differ in the last bits, which is no defect of the product
+        np.testing.assert_allclose(q, np.array(st["position"]), rtol=1e-12, atol=1e-14)
         assert res["n_leapfrog"].tolist() == st["n_leapfrog"]
 
 
