@@ -118,8 +118,9 @@ def test_dual_averaging_around_an_hmc_kernel():
 
 def test_window_adaptation_of_an_hmc_kernel():
     """window_adaptation.run drives an HMC kernel when told its trajectory length: per-chain step sizes
-    and diagonal mass matrices come back, sampling with them accepts at about the 0.8 target, and the
-    adapted inverse mass matrix tracks the target's variances."""
+    and diagonal mass matrices come back, the warm-up's own acceptance sits at the 0.8 target (sampling with
+    the AVERAGED final step size, window_adaptation.py:184-190, accepts somewhat more), and the adapted
+    inverse mass matrix tracks the target's variances."""
     from aehmc_amd import RandomStream, hmc, targets, window_adaptation
     C, D = 256, 3
     sigma = np.array([0.5, 1.0, 3.0])
@@ -130,7 +131,9 @@ def test_window_adaptation_of_an_hmc_kernel():
         window_adaptation.run(kernel, state, 50)
     state, (eps, imm), _ = window_adaptation.run(kernel, state, 400, num_integration_steps=8)
     _, info, acc_hist, _ = kernel.sample(state, eps, imm, 8, 200)
-    assert 0.7 < acc_hist.mean().item() < 0.9
+    assert 0.75 < acc_hist.mean().item() < 0.99
+    e = eps.value.cpu().numpy()
+    assert np.isfinite(e).all() and (e > 0.05).all() and (e < 3).all()
     var = imm.value.mean(dim=0).cpu().numpy()
     np.testing.assert_allclose(var, sigma ** 2, rtol=0.35)
 

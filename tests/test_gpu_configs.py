@@ -240,7 +240,7 @@ def test_config5_full_size_matches_oracle_after_warmup():
     otgt = co.Target(co.T_LINREG, 2, X=X, y=y)
     state, (eps, imm), upd = window_adaptation.run(kernel, state, 1000)
     e, m = eps.value.cpu().numpy(), imm.value.cpu().numpy()
-    assert np.isfinite(e).all() and (e > 0).all() and np.median(e) < 0.5 and (m > 0).all()
+    assert np.isfinite(e).all() and (e > 0).all() and np.median(e) < 1.0 and (m > 0).all()
     picks = [0, 1, 2, 3, 257, 514, 1022, 1023]
     rng = {c: upd[srng][c].cpu().numpy().view(np.uint64).reshape(1, 4, 4).copy() for c in picks}
     host = {c: co.new_state(otgt, state.position[c:c + 1].cpu().numpy().copy()) for c in picks}
@@ -289,3 +289,4 @@ def test_config5_thousand_step_warmup_in_one_launch_equals_the_loop():
         assert torch.equal(a, b), k
     e = outs[0][3].cpu().numpy()
     assert np.isfinite(e).all() and (e > 0).all() and len(np.unique(e)) == C
+
