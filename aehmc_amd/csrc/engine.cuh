@@ -1131,10 +1131,11 @@ __global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C,
 // scalar / diagonal metric): zbuf[c, i] = sqrt_mass[i] * z_i.  The workgroup-per-chain resident
 // kernels run this as a pre-pass -- inside them a single wavefront per CU would walk the stream
 // while the other waves of the workgroup wait.
-// Rows of zbuf are `ld` >= D apart; [D, ld) is filled with zeros.
+// Rows of zbuf are `ld` >= D apart; [D, ld) is filled with zeros.  nt > 1: the momenta of nt consecutive
+// transitions (the stream of site #1 serves nothing else), transition tt in zbuf[tt][C][ld].
 __global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites, long long C, long long D,
                                                        const double *sqrt_mass, long long sm_cs, int met_ndim,
-                                                       double *zbuf, long long ld) {
+                                                       double *zbuf, long long ld, int nt) {
   __shared__ double ztab[ZIG_LDS_DOUBLES];
   const ZigTabLds tab = zig_tab_to_lds(ztab);
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1142,10 +1143,12 @@ __global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites
   uint64_t *gs = rng + (size_t)c * nsites * 4;
   Pcg64 g = pcg_load(gs);
   const double *sm = sqrt_mass + (size_t)c * sm_cs;
-  double *dst = zbuf + (size_t)c * ld;
   const bool scalar = met_ndim == 0;
-  wave_normals(g, D, [=](long long i, double z) { dst[i] = (scalar ? sm[0] : sm[i]) * z; }, tab);
-  for (long long i = D + (threadIdx.x & 63); i < ld; i += 64) dst[i] = 0.0;
+  for (int tt = 0; tt < nt; tt++) {
+    double *dst = zbuf + ((size_t)tt * C + c) * ld;
+    wave_normals(g, D, [=](long long i, double z) { dst[i] = (scalar ? sm[0] : sm[i]) * z; }, tab);
+    for (long long i = D + (threadIdx.x & 63); i < ld; i += 64) dst[i] = 0.0;
+  }
   if ((threadIdx.x & 63) == 0) pcg_store(gs, g);
 }
 __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long C, long long n,

@@ -822,7 +822,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     if (path == NUTS_PATH_WIDE) {  // one workgroup per chain (nuts_wide.cuh): momentum drawn at one wavefront per chain first
       a.ldw = nuts_wide_ld(a.D);
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, a.rng, a.nsites, (long long)C,
-                         (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf, a.ldw);
+                         (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf, a.ldw, 1);
       HIPCHK(hipGetLastError());
       HIPCHK(launch_nuts_wide(a, st));
     } else {  // teams of <= 64 lanes: any number of transitions in one launch
@@ -1056,20 +1056,30 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     f.eps_c = ctx->eps_c;
     f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
     f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
-    // one launch pair per transition: the momentum draw runs at one wavefront per chain
-    // (k_draw_momentum), the workgroup-per-chain kernel then integrates and accepts
-    f.T = 1;
+    // A launch pair per CHUNK of transitions: the momenta of the chunk are drawn first, at one wavefront per
+    // chain (k_draw_momentum), into [nt][C][D]; the workgroup-per-chain kernel then runs the nt transitions
+    // with the position on chip.  The chunk's normals live in the first work vectors of the workspace (cur_q
+    // ... zbuf are contiguous and unused on this path): as many transitions as fit, 22 with the HMC layout.
+    // (Drawing chunk k+1 on a side stream BESIDE the integration of chunk k was measured in round 3: the two
+    // kernels do share the CUs -- 4 x 96 + 96 of a SIMD's 512 registers -- but both are bound by VALU issue, and
+    // together they take what they take one after the other: profiles/r3/INDEX.md.)
+    const size_t vec = (size_t)((char *)a.cur_p - (char *)a.cur_q);
+    const size_t cap_bytes = (size_t)((char *)a.zbuf - (char *)a.cur_q) + vec;
+    const int64_t cap = (int64_t)(cap_bytes / ((size_t)C * D * sizeof(double)));
+    if (cap < 1) FAIL("internal: workspace holds no momentum row");
+    double *zall = a.cur_q;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    for (int64_t t = 0; t < T; t++) {
+    for (int64_t t0 = 0; t0 < T; t0 += cap) {
+      const int nt = (int)(T - t0 < cap ? T - t0 : cap);
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, rng, 2, (long long)C, (long long)D,
-                         f.sqrt_mass, f.imm_cs, f.met_ndim, a.zbuf, (long long)D);
+                         f.sqrt_mass, f.imm_cs, f.met_ndim, zall, (long long)D, nt);
       HIPCHK(hipGetLastError());
-      f.samples = samples ? samples + (size_t)t * C * D : nullptr;
-      f.acc_hist = acc_hist ? acc_hist + (size_t)t * C : nullptr;
-      f.div_hist = div_hist ? div_hist + (size_t)t * C : nullptr;
-      f.out.momentum = t == T - 1 ? out->momentum : nullptr;  // only the last transition's is observable
-      HIPCHK(launch_hmc_resident(f, a.zbuf, st));
+      f.samples = samples ? samples + (size_t)t0 * C * D : nullptr;
+      f.acc_hist = acc_hist ? acc_hist + (size_t)t0 * C : nullptr;
+      f.div_hist = div_hist ? div_hist + (size_t)t0 * C : nullptr;
+      f.out.momentum = t0 + nt == T ? out->momentum : nullptr;  // only the last transition's is observable
+      HIPCHK(launch_hmc_resident(f, zall, nt, st));
     }
     if (T > 1 && out->n_leapfrog)
       LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));

@@ -194,26 +194,38 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
 }
 
 // ---- large D: one workgroup of T threads per chain, state in VGPRs ----------------------
-// Thread t keeps elements t, t+T, ... of q, p (and dU/dq where it is not q itself) in
-// registers for all L leapfrogs of ONE transition; the momentum was drawn by k_draw_momentum
-// (one wavefront per chain) into `zbuf`.  HBM sees q, z (and dU/dq for the diagonal target)
-// once on the way in and q, dU/dq once on the way out of an accepted transition.  Cross-wave
-// sums take one LDS hop, so the summation order differs from the lock-step path (1e-13).
-// Slots past D replicate element D-1 (in bounds), are masked out of the sums and never stored.
+// Thread t keeps elements t, t+T, ... of q, p (and dU/dq where it is not q itself) in registers for
+// all L leapfrogs of `nt` CONSECUTIVE transitions (round 3; one per launch before): the chain's position
+// never leaves the chip between the transitions of a sample() call.  The momenta of the nt transitions
+// were drawn by k_draw_momentum (one wavefront per chain: the PCG64 stream of a chain is sequential) into
+// zbuf[nt][C][D].  Per transition HBM sees the D normals on the way in (loaded into the registers of the
+// dead momentum behind the last energy sum, i.e. under the accept arithmetic) and nothing on the way out
+// but the optional sample row; q, dU/dq, U go out once, at the end of the launch, if any transition was
+// accepted.  The position a rejection falls back to waits in LDS (each thread re-reads only what it wrote
+// itself: no barrier).  Cross-wave sums take one LDS hop, so the summation order differs from the lock-step
+// path (1e-13).  Slots past D replicate element D-1 (in bounds), are masked out of the sums, never stored.
 template <int T, int R, int TK>
-__global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zbuf) {
+__global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zbuf, int nt) {
   constexpr int NW = T / 64;
   constexpr bool DG = TK == AEHMC_T_DIAG_GAUSSIAN;  // otherwise dU/dq == q, no separate copy
   __shared__ double red[2][2 * NW];
+  extern __shared__ __attribute__((aligned(16))) double wide_save[];  // q [D] (+ dU/dq [D]) at the transition's start
   int flip = 0;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const long long c = blockIdx.x;
   const size_t row = (size_t)c * a.D;
   const size_t imo = (size_t)c * a.imm_cs;
+  const size_t tstride = (size_t)a.C * a.D;  // between the rows of one chain in [nt][C][D] arrays
   const unsigned last = (unsigned)a.D - 1;
-#define EI(r) (((unsigned)(t + T * (r)) < last) ? (unsigned)(t + T * (r)) : last)
-#define VALID(r) ((unsigned)(t + T * (r)) <= last)
+  // Element indices are derived from `tb`, a copy of the thread index behind an opaque barrier that is renewed at
+  // every phase of every transition: otherwise the ~60 addresses of the phases outside the leapfrog loop are
+  // hoisted out of the transition loop, stay live across the leapfrog loop next to the 80 registers of q, p, b q
+  // and imm, and spill (228 B/lane at <1024, 10>, the spill code inside the leapfrog loop).
+  unsigned tb = (unsigned)t;
+#define RENEW_TB() asm volatile("" : "+v"(tb))
+#define EI(r) (((tb + T * (r)) < last) ? (tb + T * (r)) : last)
+#define VALID(r) ((tb + T * (r)) <= last)
 #define MASK(r) (VALID(r) ? 1.0 : 0.0)
   auto sum2 = [&](double &x, double &y) {
     x = wave_sum(x);
@@ -250,119 +262,170 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
   Pcg64 g2 = pcg_load(a.rng + (size_t)c * 8 + 4);  // site #2: accept (hmc.py:194)
   const double eps = a.eps_c ? a.eps_c[c] : a.eps;
   const double b = 0.5 * eps, aa = 1 * eps;
-  double kd = 0.0, zero = 0.0;
+  double pa = 0.0;
+  int is_div = 0, acc = 0, any_acc = 0;
+  for (int tt = 0; tt < nt; tt++) {
+    const bool last_t = tt == nt - 1;
+    double kd = 0.0, zero = 0.0;
+    RENEW_TB();
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    kd += MASK(r) * ((im[r] * p[r]) * p[r]);
-    if (a.out.momentum && VALID(r)) (a.out.momentum + row)[EI(r)] = p[r];  // kept on rejection
-  }
-  sum2(kd, zero);
-  const double H0 = U + 0.5 * kd;  // hmc.py:187
-  if (DG) {
-    for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
+    for (int r = 0; r < R; r++) {
+      kd += MASK(r) * ((im[r] * p[r]) * p[r]);
+      wide_save[EI(r)] = q[r];
+      if (DG) wide_save[a.D + EI(r)] = g[DG ? r : 0];
+      // only the last transition's momentum is observable: the initial one is kept on rejection
+      if (last_t && a.out.momentum && VALID(r)) (a.out.momentum + row)[EI(r)] = p[r];
+    }
+    sum2(kd, zero);
+    const double H0 = U + 0.5 * kd;  // hmc.py:187
+    if (DG) {
+      for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
+        RENEW_TB();
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        double pp = p[r] - b * GR(r);
-        const double qq = q[r] + aa * (im[r] * pp);
-        const double gg = ((qq - a.mu[EI(r)]) / a.sigma[EI(r)]) / a.sigma[EI(r)];
-        pp = pp - b * gg;
-        q[r] = qq;
-        g[DG ? r : 0] = gg;
-        p[r] = pp;
+        for (int r = 0; r < R; r++) {
+          double pp = p[r] - b * GR(r);
+          const double qq = q[r] + aa * (im[r] * pp);
+          const double gg = ((qq - a.mu[EI(r)]) / a.sigma[EI(r)]) / a.sigma[EI(r)];
+          pp = pp - b * gg;
+          q[r] = qq;
+          g[DG ? r : 0] = gg;
+          p[r] = pp;
+        }
+      }
+    } else {  // dU/dq == q; b * q' ends one leapfrog and starts the next (same product, computed once)
+      double bq[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) bq[r] = b * q[r];
+      for (long long l = 0; l < a.L; l++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          p[r] = p[r] - bq[r];
+          q[r] = q[r] + aa * (im[r] * p[r]);
+          bq[r] = b * q[r];
+          p[r] = p[r] - bq[r];
+        }
       }
     }
-  } else {  // dU/dq == q; b * q' ends one leapfrog and starts the next (same product, computed once)
-    double bq[R];
+    double usum = 0.0;
+    kd = 0.0;
+    RENEW_TB();
 #pragma unroll
-    for (int r = 0; r < R; r++) bq[r] = b * q[r];
-    for (long long l = 0; l < a.L; l++) {
+    for (int r = 0; r < R; r++) {
+      const double qq = q[r];
+      double u;
+      if (TK == AEHMC_T_STD_NORMAL) u = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
+      else if (TK == AEHMC_T_ISO_GAUSSIAN) u = qq * qq;
+      else {
+        const double z = (qq - a.mu[EI(r)]) / a.sigma[EI(r)];
+        u = 0.5 * (z * z) + a.log_sigma[EI(r)] + AEHMC_LOG_SQRT_2PI;
+      }
+      usum += MASK(r) * u;
+      const double pf = -1.0 * p[r];  // hmc.py:185
+      kd += MASK(r) * ((im[r] * pf) * pf);
+    }
+    RENEW_TB();
+    if (!last_t) {  // the momentum is dead: its registers take the next transition's normals, which arrive
+      //               while the sums below are reduced and the accept decision is made
+      const double *zn = zrow + (size_t)(tt + 1) * tstride;
+#pragma unroll
+      for (int r = 0; r < R; r++) p[r] = zn[EI(r)];
+    }
+    sum2(usum, kd);
+    const double Unew = a.L > 0 ? (TK == AEHMC_T_ISO_GAUSSIAN ? 0.5 * usum : usum) : U;
+    double delta = H0 - (Unew + 0.5 * kd);
+    if (isnan(delta)) delta = -INFINITY;
+    is_div = fabs(delta) > a.thr;
+    pa = exp(delta);
+    if (pa > 1.0) pa = 1.0;
+    if (pa < 0.0) pa = 0.0;
+    acc = rng_bernoulli(g2, pa);  // hmc.py:193-195
+    RENEW_TB();
+    if (acc) {
+      U = Unew;
+      any_acc = 1;
+    } else {  // back to the transition's start
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        p[r] = p[r] - bq[r];
-        q[r] = q[r] + aa * (im[r] * p[r]);
-        bq[r] = b * q[r];
-        p[r] = p[r] - bq[r];
+        q[r] = wide_save[EI(r)];
+        if (DG) g[DG ? r : 0] = wide_save[a.D + EI(r)];
       }
     }
-  }
-  double usum = 0.0;
-  kd = 0.0;
+    if (a.samples) {
+      double *dst = a.samples + (size_t)tt * tstride + row;
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    const double qq = q[r];
-    double u;
-    if (TK == AEHMC_T_STD_NORMAL) u = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
-    else if (TK == AEHMC_T_ISO_GAUSSIAN) u = qq * qq;
-    else {
-      const double z = (qq - a.mu[EI(r)]) / a.sigma[EI(r)];
-      u = 0.5 * (z * z) + a.log_sigma[EI(r)] + AEHMC_LOG_SQRT_2PI;
+      for (int r = 0; r < R; r++)
+        if (VALID(r)) dst[EI(r)] = q[r];
     }
-    usum += MASK(r) * u;
-    const double pf = -1.0 * p[r];  // hmc.py:185
-    kd += MASK(r) * ((im[r] * pf) * pf);
+    if (t == 0) {
+      if (a.acc_hist) a.acc_hist[(size_t)tt * a.C + c] = pa;
+      if (a.div_hist) a.div_hist[(size_t)tt * a.C + c] = is_div;
+    }
   }
-  sum2(usum, kd);
-  const double Unew = a.L > 0 ? (TK == AEHMC_T_ISO_GAUSSIAN ? 0.5 * usum : usum) : U;
-  double delta = H0 - (Unew + 0.5 * kd);
-  if (isnan(delta)) delta = -INFINITY;
-  const int is_div = fabs(delta) > a.thr;
-  double pa = exp(delta);
-  if (pa > 1.0) pa = 1.0;
-  if (pa < 0.0) pa = 0.0;
-  const int acc = rng_bernoulli(g2, pa);  // hmc.py:193-195
-  if (acc) {  // commit; a rejected transition leaves the state in HBM untouched
+  RENEW_TB();
+  if (any_acc) {  // commit; a call without an accepted transition leaves the state in HBM untouched
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (!VALID(r)) continue;
       (a.q + row)[EI(r)] = q[r];
       (a.g + row)[EI(r)] = GR(r);
-      if (a.out.momentum) (a.out.momentum + row)[EI(r)] = -1.0 * p[r];
-      if (a.samples) (a.samples + row)[EI(r)] = q[r];
     }
-  } else if (a.samples) {
+  }
+  if (acc && a.out.momentum) {
 #pragma unroll
     for (int r = 0; r < R; r++)
-      if (VALID(r)) (a.samples + row)[EI(r)] = qrow[EI(r)];
+      if (VALID(r)) (a.out.momentum + row)[EI(r)] = -1.0 * p[r];
   }
   if (t == 0) {
     pcg_store(a.rng + (size_t)c * 8 + 4, g2);
-    if (acc) a.U[c] = Unew;
+    if (any_acc) a.U[c] = U;
     a.out.acceptance_probability[c] = pa;
     a.out.is_diverging[c] = is_div;
-    if (a.out.n_leapfrog) a.out.n_leapfrog[c] = a.L;
+    if (a.out.n_leapfrog) a.out.n_leapfrog[c] = a.L * nt;
     if (a.out.is_turning) a.out.is_turning[c] = acc;  // HMC: reused as the accept flag
-    if (a.acc_hist) a.acc_hist[c] = pa;
-    if (a.div_hist) a.div_hist[c] = is_div;
   }
 #undef GR
 #undef EI
 #undef VALID
 #undef MASK
+#undef RENEW_TB
 }
 
 inline bool hmc_resident_supported(int tkind, int met_ndim, long long D) {
-  return target_is_elem_host(tkind) && met_ndim < 2 && D > 1024 && D <= 10240;
+  // (the diagonal-Gaussian target parks q AND dU/dq in LDS between a transition's start and its accept
+  //  decision: 16 D bytes next to the reduction scratch in the CU's 160 KB)
+  return target_is_elem_host(tkind) && met_ndim < 2 && D > 1024 && D <= (tkind == AEHMC_T_DIAG_GAUSSIAN ? 10176 : 10240);
 }
 template <int T, int R>
-inline hipError_t launch_hmc_wide_r(const HmcFusedArgs &a, const double *zbuf, hipStream_t st) {
+inline hipError_t launch_hmc_wide_r(const HmcFusedArgs &a, const double *zbuf, int nt, hipStream_t st) {
+  const bool dg = a.tkind == AEHMC_T_DIAG_GAUSSIAN;
+  const size_t dyn = (size_t)a.D * sizeof(double) * (dg ? 2 : 1);
+#define AEHMC_WIDE_LAUNCH(TK)                                                                              \
+  do {                                                                                                     \
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_wide<T, R, TK>),             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);             \
+    if (e_ != hipSuccess) return e_;                                                                       \
+    hipLaunchKernelGGL((k_hmc_wide<T, R, TK>), dim3((unsigned)a.C), dim3(T), dyn, st, a, zbuf, nt);        \
+  } while (0)
   switch (a.tkind) {
     case AEHMC_T_STD_NORMAL:
-      hipLaunchKernelGGL((k_hmc_wide<T, R, AEHMC_T_STD_NORMAL>), dim3((unsigned)a.C), dim3(T), 0, st, a, zbuf);
+      AEHMC_WIDE_LAUNCH(AEHMC_T_STD_NORMAL);
       break;
     case AEHMC_T_ISO_GAUSSIAN:
-      hipLaunchKernelGGL((k_hmc_wide<T, R, AEHMC_T_ISO_GAUSSIAN>), dim3((unsigned)a.C), dim3(T), 0, st, a, zbuf);
+      AEHMC_WIDE_LAUNCH(AEHMC_T_ISO_GAUSSIAN);
       break;
     default:
-      hipLaunchKernelGGL((k_hmc_wide<T, R, AEHMC_T_DIAG_GAUSSIAN>), dim3((unsigned)a.C), dim3(T), 0, st, a, zbuf);
+      AEHMC_WIDE_LAUNCH(AEHMC_T_DIAG_GAUSSIAN);
   }
+#undef AEHMC_WIDE_LAUNCH
   return hipGetLastError();
 }
-// `samples`, `acc_hist`, `div_hist` point at THIS transition's slices (a.T is not used).
-inline hipError_t launch_hmc_resident(const HmcFusedArgs &a, const double *zbuf, hipStream_t st) {
-  if (a.D <= 2048) return launch_hmc_wide_r<256, 8>(a, zbuf, st);
-  if (a.D <= 4096) return launch_hmc_wide_r<512, 8>(a, zbuf, st);
-  if (a.D <= 8192) return launch_hmc_wide_r<1024, 8>(a, zbuf, st);
-  return launch_hmc_wide_r<1024, 10>(a, zbuf, st);
+// `nt` consecutive transitions; `samples`, `acc_hist`, `div_hist` point at the FIRST of them ([nt][C][..] slices);
+// zbuf [nt][C][D] holds their momenta.
+inline hipError_t launch_hmc_resident(const HmcFusedArgs &a, const double *zbuf, int nt, hipStream_t st) {
+  if (a.D <= 2048) return launch_hmc_wide_r<256, 8>(a, zbuf, nt, st);
+  if (a.D <= 4096) return launch_hmc_wide_r<512, 8>(a, zbuf, nt, st);
+  if (a.D <= 8192) return launch_hmc_wide_r<1024, 8>(a, zbuf, nt, st);
+  return launch_hmc_wide_r<1024, 10>(a, zbuf, nt, st);
 }
 
 template <int R>

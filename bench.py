@@ -87,6 +87,9 @@ def other_configs():
     return out
 
 
+HMC_PER_CALL = 20
+
+
 def diag_case(kind, D, C, device):
     """Secondary workloads (diagonal / scalar mass: HBM-bound): D-dim isotropic Gaussian,
     diagonal inverse mass matrix of ones, eps = 0.5 D^-1/4, C chains; `kind` nuts (default depth) or
@@ -101,8 +104,9 @@ def diag_case(kind, D, C, device):
     state = mod.new_state(q0, tgt)
     if kind == "nuts":
         return state, (lambda st: kernel(st, eps, imm))
-    # HMC: 10 transitions per engine call (kernel.sample, the user-level scan); n_leapfrog is the call's total
-    return state, (lambda st: (kernel.sample(st, eps, imm, 32, 10, keep_samples=False)[1], None))
+    # HMC: HMC_PER_CALL transitions per engine call (kernel.sample, the user-level scan): the position stays on chip
+    # for the transitions of a call; n_leapfrog is the call's total
+    return state, (lambda st: (kernel.sample(st, eps, imm, 32, HMC_PER_CALL, keep_samples=False)[1], None))
 
 
 def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
@@ -130,7 +134,7 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
         kern_ms, kern_n, _ = eng.profile_read()
         eng.profile_enable(False)
         nl = int(nl.item())
-        per_call = 10 if kind == "hmc" else 1  # transitions per engine call (= per HIP-event pair)
+        per_call = HMC_PER_CALL if kind == "hmc" else 1  # transitions per engine call (= per HIP-event pair)
         traffic = None
         if pmc and kind in pmc:
             traffic = pmc[kind]["hbm_bytes_per_transition"]
