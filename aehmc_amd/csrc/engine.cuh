@@ -1144,9 +1144,10 @@ __global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites
   Pcg64 g = pcg_load(gs);
   const double *sm = sqrt_mass + (size_t)c * sm_cs;
   const bool scalar = met_ndim == 0;
+  const PcgLaneJump jump = pcg_lane_jump(g);
   for (int tt = 0; tt < nt; tt++) {
     double *dst = zbuf + ((size_t)tt * C + c) * ld;
-    wave_normals(g, D, [=](long long i, double z) { dst[i] = (scalar ? sm[0] : sm[i]) * z; }, tab);
+    wave_normals(g, D, [=](long long i, double z) { dst[i] = (scalar ? sm[0] : sm[i]) * z; }, tab, jump);
     for (long long i = D + (threadIdx.x & 63); i < ld; i += 64) dst[i] = 0.0;
   }
   if ((threadIdx.x & 63) == 0) pcg_store(gs, g);

@@ -81,8 +81,9 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   double pa = 0.0;
   int is_div = 0, acc = 0;
 
+  const PcgLaneJump jump1 = pcg_lane_jump(g1);
   for (long long t = 0; t < a.T; t++) {
-    wave_normals(g1, a.D, [=](long long i, double z) { zrow[i] = z; }, tab);  // metrics.py:65-68
+    wave_normals(g1, a.D, [=](long long i, double z) { zrow[i] = z; }, tab, jump1);  // metrics.py:65-68
     __threadfence_block();
     double kd = 0.0;
 #pragma unroll

@@ -243,11 +243,28 @@ struct LaneSrc {  // raw outputs of lanes idx, idx+1, ... of the current round (
     return true;
   }
 };
+// the per-lane jump constants of a generator: A^(lane+1) and G_(lane+1) * inc (inc never changes)
+struct PcgLaneJump {
+  u128 Ak, GI;
+};
+__device__ __forceinline__ PcgLaneJump pcg_lane_jump(const Pcg64 &rng) {
+  const int lane = threadIdx.x & 63;
+  PcgLaneJump j;
+  j.Ak = mk128(c_pcg_jump[lane][0], c_pcg_jump[lane][1]);
+  j.GI = mul128(mk128(c_pcg_jump[lane][2], c_pcg_jump[lane][3]), rng.inc);
+  return j;
+}
+template <class Store, class Tab>
+__device__ inline void wave_normals(Pcg64 &rng, long long n, Store store, const Tab &tab, const PcgLaneJump &jump);
 template <class Store, class Tab = ZigTabConst>
 __device__ inline void wave_normals(Pcg64 &rng, long long n, Store store, const Tab &tab = Tab{}) {
+  wave_normals(rng, n, store, tab, pcg_lane_jump(rng));
+}
+// (`jump` = pcg_lane_jump(rng), computed once by kernels that call this in a loop)
+template <class Store, class Tab>
+__device__ inline void wave_normals(Pcg64 &rng, long long n, Store store, const Tab &tab, const PcgLaneJump &jump) {
   const int lane = threadIdx.x & 63;
-  const u128 Ak = mk128(c_pcg_jump[lane][0], c_pcg_jump[lane][1]);
-  const u128 GI = mul128(mk128(c_pcg_jump[lane][2], c_pcg_jump[lane][3]), rng.inc);
+  const u128 Ak = jump.Ak, GI = jump.GI;
   long long pos = 0;  // normals delivered so far
   while (pos < n) {
     const u128 sk = muladd128(Ak, rng.state, GI);  // state after lane+1 steps

@@ -112,7 +112,7 @@ def diag_case(kind, D, C, device):
 def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
     """Diagonal-mass NUTS and HMC at the headline shape.  `achieved` = HBM bytes per transition as
     COUNTED by rocprofv3 (FETCH_SIZE x 2 + WRITE_SIZE of the kernels of one transition, separate
-    --pmc passes of the same workload: profiles/r2/diag_pmc_summary.json) / the transition's kernel
+    --pmc passes of the same workload: the newest profiles/rN/diag_pmc_summary.json) / the transition's kernel
     time measured here with HIP events on the launch stream."""
     pmc, pmc_src = pmc_summary("diag_pmc_summary.json") if (D, C) == (10_000, 4096) else (None, None)
     out = []
@@ -140,14 +140,26 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
             traffic = pmc[kind]["hbm_bytes_per_transition"]
         avg_ms = kern_ms / max(kern_n, 1) / per_call
         alg = (48.0 if kind == "hmc" else 88.0) * D * nl / (steps * per_call)  # SURVEY 8d streaming figure, for reference only
-        roof = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "kernel": main_kernel + " (+ k_draw_momentum)",
-                "avg_launch_ms": avg_ms, "launches": kern_n * per_call, "traffic": traffic,
-                "traffic_source": pmc_src if traffic else None,
-                "achieved": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
-                "streaming_bytes_per_transition": alg,
-                "note": "achieved = counted HBM bytes per transition / kernel time; the chain state is on chip, so the "
-                        "counted bytes are far below the streaming figure (48 D / 88 D per leapfrog)"}
-        roof["frac"] = roof["achieved"] / PEAK_HBM_GBS if traffic else None
+        hbm = {"unit": "GB/s", "peak": PEAK_HBM_GBS, "traffic": traffic,
+               "achieved": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+               "streaming_bytes_per_transition": alg,
+               "note": "counted HBM bytes per transition / kernel time; the chain state is on chip, so the counted bytes are far "
+                       "below the streaming figure (48 D / 88 D per leapfrog)"}
+        hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS if traffic else None
+        if kind == "nuts":  # bound by HBM on its counted bytes (checkpoints, proposal copies, parked trajectory ends)
+            roof = dict(hbm, bound="hbm", kernel=main_kernel + " (+ k_draw_momentum)", avg_launch_ms=avg_ms,
+                        launches=kern_n * per_call, traffic_source=pmc_src if traffic else None)
+        else:
+            # the position stays in registers for the transitions of a call: HBM sees the normals in and little else, and
+            # the bound is fp64 VALU issue -- 6 UNFUSED operations per element and leapfrog (the reference rounds every
+            # product and sum), against 16 lanes x 4 SIMDs x 256 CUs x 2.4 GHz lane-operations per second
+            peak_ops = 256 * 4 * 16 * 2.4e9 / 1e12
+            ops = nl / dt * 6.0 * D / 1e12
+            roof = {"bound": "valu", "unit": "Tlane-op/s (fp64, unfused)", "achieved": ops, "peak": peak_ops, "frac": ops / peak_ops,
+                    "kernel": main_kernel + " (+ k_draw_momentum)", "avg_launch_ms": avg_ms, "launches": kern_n * per_call,
+                    "traffic": traffic, "traffic_source": pmc_src if traffic else None, "hbm": hbm,
+                    "note": "6 D fp64 operations per leapfrog in the integration; the momentum draw (PCG64 + ziggurat, one "
+                            "wavefront per chain) takes a third of a transition and is VALU-bound as well"}
         out.append({"config": f"diag-{kind}",
                     "workload": f"{D}-dim isotropic Gaussian, diagonal mass, {'NUTS depth 10' if kind == 'nuts' else 'HMC L=32'}, "
                                 f"{C} chains", "value": nl / dt, "unit": "leapfrog-steps/s", "ms_per_transition": dt / (steps * per_call) * 1e3,

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import diag_case
 
 what = sys.argv[1] if len(sys.argv) > 1 else "both"
-NT = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # engine calls (HMC: 10 transitions each)
+NT = int(sys.argv[2]) if len(sys.argv) > 2 else 2  # engine calls (HMC: bench.HMC_PER_CALL transitions each)
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000
 C = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 for kind in ("nuts", "hmc"):
