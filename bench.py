@@ -550,9 +550,12 @@ def cpu_baseline_c5(X, y, info, eps, imm):
             nl += int(co.nuts_step(otgt, metric, rng, e, q, U, g, nthreads=threads)["n_leapfrog"].sum())
         return nl, time.perf_counter() - t0
 
-    reps = 20
+    # bounded samples of a few seconds each: a leapfrog is one pass over the 1e5 rows (~1e6 flop), so 4 chains x 3000
+    # transitions (~5e4 leapfrogs) on one thread, and one chain per thread x 3000 transitions on at most 64 threads
+    # (more threads than that only measure the fork / join of the OpenMP team on this workload)
+    reps = 3000
     n1, dt1 = run(4, 1, reps)
-    used = min(cores, 256, pos.shape[0])
+    used = min(cores, 64, pos.shape[0])
     na, dta = run(used, used, reps)
     return {"value": na / dta, "unit": "leapfrog-steps/s", "cores": used, "kind": "port",
             "sample": f"{used} chains x {reps} NUTS transitions (median adapted step size / metric), OpenMP over "
@@ -608,16 +611,19 @@ def cpu_baseline(config, D, q0, target, imm, eps):
         otgt, metric = co.Target(co.T_ISO_GAUSSIAN, D), co.Metric(np.ones(D), D)
         # (one oracle call = one transition of all chains: ~1e8 flop, so the fork / join of a 256-thread
         #  team would dominate -- all chains of the config, at most 32 threads)
-        reps, n_all = 20, q0.shape[0]
+        reps, n_all = 2000, q0.shape[0]  # ~1e10 flop-ish per call: a few seconds on 32 threads
         cores = min(cores, 32)
         what = f"{reps} HMC transitions (L=32) per chain"
-    nl1, dt1 = run(8, 1)
+    n_one = 8
+    reps_all, reps = reps, max(reps // 10, 1)  # the single-thread leg: 8 chains, a tenth of the transitions
+    nl1, dt1 = run(n_one, 1)
+    reps = reps_all
     used = min(cores, n_all)  # threads that get a chain
     nla, dta = run(n_all, used)
     return {"value": nla / dta, "unit": "leapfrog-steps/s", "cores": used, "kind": "port",
             "sample": f"{n_all} chains x {what}, {used} OpenMP threads over chains ({nla} leapfrogs, {dta:.1f} s)",
             "single_thread": {"value": nl1 / dt1, "unit": "leapfrog-steps/s", "cores": 1,
-                              "sample": f"8 chains x {what} ({nl1} leapfrogs, {dt1:.1f} s)"},
+                              "sample": f"8 chains x {reps_all // 10} HMC transitions (L=32) per chain ({nl1} leapfrogs, {dt1:.1f} s)"},
             "host_cpu_count": cores,
             "note": "C restatement of aehmc semantics (oracle/c), not Aesara; reported, not optimised"}
 
