@@ -67,7 +67,8 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
   constexpr bool PAR_REG = R <= 8;          // per-element parameters live in VGPRs
   constexpr bool IM_LDS = !PAR_REG && !DG;  // imm in the LDS half that dU/dq does not need
   constexpr bool STREAM = !PAR_REG && DG;   // parameters streamed from L2 every pass
-  constexpr int BR = (R % 4 == 0) ? 4 : R;  // elements per streamed batch
+  constexpr int BR = STREAM ? 2 : ((R % 4 == 0) ? 4 : R);  // elements per batch (streamed parameters: two, so that
+  //                                                           the batch in use and the one on its way stay at 32 registers)
   constexpr int NB = R / BR;
   static_assert(R % BR == 0, "R must be a multiple of the batch size");
   static_assert(QGL || PAR_REG, "more than 8 elements per thread: q lives in LDS");
@@ -213,11 +214,7 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
   }
   const double eps = a.eps_c ? a.eps_c[c] : a.eps;
   int ck_last = -1;  // checkpoint index whose pair the registers held before this step (-1: none)
-  Par cur[BR], nxt[BR];  // streamed parameters: batch 0 of the next pass is fetched ahead
-  if (STREAM) {
-#pragma unroll
-    for (int u = 0; u < BR; u++) cur[u] = par_load(u);
-  }
+  Par cur[BR], nxt[BR];  // streamed parameters: the batch in use and the next one on its way
 
 #ifdef AEHMC_WIDE_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -263,6 +260,10 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     }
     auto pass = [&](auto fwd_tag) {
       constexpr bool FWD = decltype(fwd_tag)::value;
+      if (STREAM) {
+#pragma unroll
+        for (int u = 0; u < BR; u++) cur[u] = par_load(u);
+      }
 #pragma unroll
       for (int b0 = 0; b0 < NB; b0++) {
         if (STREAM && b0 + 1 < NB) {
@@ -328,13 +329,11 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     }
     if (even) ck_last = tmax;
     AEHMC_TICK(0);  // pass
-    // fetched ahead, behind the reduction and the per-chain scalar work below: the first
-    // parameter batch of the next pass, and the first checkpoint pair this step's U-turn check
-    // needs from memory (level tmax when it is not in registers, else level tmax - 1)
-    if (STREAM) {
-#pragma unroll
-      for (int u = 0; u < BR; u++) cur[u] = par_load(u);
-    }
+    // fetched ahead, behind the reduction and the per-chain scalar work below: the first checkpoint
+    // pair this step's U-turn check needs from memory (level tmax when it is not in registers, else
+    // level tmax - 1).  (The streamed variants used to fetch the first parameter batch of the NEXT pass
+    // here as well: its 16 registers, live across the scalar code next to the 4 R of the checkpoint
+    // pair, made them spill 96 / 224 B per lane; the batch is now loaded at the head of the pass.)
     const int pre_idx = fwd ? tmax - 1 : tmax;
     const bool pre_on = check && pre_idx >= tmin;
     double pre_kp[R], pre_ks[R];
