@@ -684,6 +684,43 @@ def test_hmc_wide_many_chains_equal_small_call(eng, D, tk):
     assert 0.3 < acc.mean().item() <= 1.0
 
 
+@pytest.mark.parametrize("D,tk", [(1500, "diag"), (9000, "iso"), (10000, "diag")])
+def test_hmc_wide_long_sample_with_rejections(eng, D, tk):
+    """The round-3 workgroup-per-chain HMC kernel keeps the position on chip for the transitions of a launch, parks
+    the state a rejection falls back to in LDS and takes the momenta of up to 22 transitions per launch pair:
+    50 transitions in one sample() call (three chunks) at a step size that rejects about every third proposal equal,
+    bit for bit, 50 single-transition calls on the same seeds -- positions after every transition, acceptance
+    history, final state, last momentum and the generator states -- and the oracle along the way (1e-9)."""
+    from aehmc_amd import RandomStream, hmc
+    r = np.random.default_rng(D + 7)
+    tgt, otgt, imm = make_case("diag", tk, D, r)
+    C, L, T = 3, 5, 50
+    seeds = [4100 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    eps = 1.35 / D ** 0.25
+    k1, s1 = hmc.new_kernel(RandomStream(seeds=seeds), tgt), RandomStream(seeds=seeds)
+    samples, info, acc, div = k1.sample(hmc.new_state(dev(q0), tgt), eps, imm, L, T)
+    k2 = hmc.new_kernel(s1, tgt)
+    state = hmc.new_state(dev(q0), tgt)
+    metric, rng = co.Metric(imm, D), co.site_states(seeds, 2)
+    q, U, g = co.new_state(otgt, q0.copy())
+    n_acc = 0
+    for t in range(T):
+        i2, upd = k2(state, eps, imm, L)
+        state = i2.state._replace(momentum=None)
+        assert torch.equal(samples[t], i2.state.position), t
+        assert torch.equal(acc[t], i2.acceptance_probability), t
+        res = co.hmc_step(otgt, metric, rng, eps, L, q, U, g)
+        np.testing.assert_allclose(samples[t].cpu().numpy(), q, rtol=RTOL, atol=1e-12)
+        n_acc += int(res["accepted"].sum())
+    assert torch.equal(info.state.position, i2.state.position)
+    assert torch.equal(info.state.potential_energy, i2.state.potential_energy)
+    assert torch.equal(info.state.potential_energy_grad, i2.state.potential_energy_grad)
+    assert torch.equal(info.state.momentum, i2.state.momentum)
+    assert torch.equal(k1._hmc["holder"]["rng"], upd[s1])
+    assert 0.1 * C * T < n_acc < 0.95 * C * T  # both branches of the accept decision, many times
+
+
 def test_hmc_fused_equals_lockstep_bitwise(eng):
     """The register-resident single-launch HMC kernel and the generic lock-step path run
     the same arithmetic in the same order."""
