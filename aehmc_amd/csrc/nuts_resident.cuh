@@ -49,12 +49,21 @@ __device__ __forceinline__ double subwave_sum(double x) {
   return x;
 }
 
-// sum of two values over the team; every thread of the team returns the same bits
+// sum of two values over the team; every thread of the team returns the same bits.
+// `single`: only thread 0 of the team holds a term (D == 1 on a whole wavefront -- the README example's single
+// chain): the butterfly would add 63 zeros to it, i.e. return lane 0's value + 0.0; reading that lane directly skips
+// ~50 dependent cross-lane instructions per call on the latency path of a lone chain (same bits: x + 0.0 also
+// turns a -0.0 into the +0.0 the butterfly produces).
 template <int T>
-__device__ __forceinline__ void team_sum2(double &x, double &y) {
+__device__ __forceinline__ void team_sum2(double &x, double &y, bool single = false) {
   if (Team<T>::SUB) {
     x = subwave_sum<T>(x);
     y = subwave_sum<T>(y);
+    return;
+  }
+  if (single) {
+    x = read_lane_f64(x, 0) + 0.0;
+    y = read_lane_f64(y, 0) + 0.0;
     return;
   }
   x = wave_sum(x);
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
   if (c >= a.C) return;  // a whole team leaves together
   const size_t row = (size_t)c * a.D;
   const bool lead = t == 0;
+  const bool single = T == 64 && a.D == 1;  // (wave-uniform: a kernel argument)
 
   double q[R], g[R], p[R], pb[R];  // moving end + sub-trajectory momentum sum
   bool ok[R];
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
       AT(a.psum, r) = p[r];
     }
   }
-  team_sum2<T>(kd, zero);
+  team_sum2<T>(kd, zero, single);
   {
     const double U = MULTI ? U_state : a.U[c];
     ct.H0 = U + 0.5 * kd;
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
         }
         R_FENCE();
       }
-      team_sum2<T>(usum, kd);
+      team_sum2<T>(usum, kd, single);
       ct.U_cur = target_finish(a, usum);
     }
 
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
             }
             R_FENCE();
           }
-          team_sum2<T>(d_l, d_r);
+          team_sum2<T>(d_l, d_r, single);
           crit = (d_l <= 0) | (d_r <= 0);
           bool reached = (idx - 1) < tmin;
           idx -= 1;
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
         }
         R_FENCE();
       }
-      team_sum2<T>(d_l, d_r);
+      team_sum2<T>(d_l, d_r, single);
       const bool turning = (d_l <= 0) | (d_r <= 0);
       put2(ct.U_end, dir, ct.U_cur);
       ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;
