@@ -69,6 +69,8 @@ struct aehmc_ctx {
   bool fuse_pre = false, pre_done = false;  // NUTS lock-step loop, dense-linear mode: see launch_leapfrog
   int *d_sched = nullptr;  // warm-up schedule on the device: stage [n], is_window_end [n]
   int64_t d_sched_n = 0;
+  double *pc_work = nullptr;  // scratch of aehmc_metric_sqrt_per_chain above D = 64 (kept, grown on demand)
+  size_t pc_work_bytes = 0;
 };
 
 #define HIPCHK(expr)                                                                     \
@@ -161,6 +163,7 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (ctx->sk_flags) (void)hipFree(ctx->sk_flags);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->d_sched) (void)hipFree(ctx->d_sched);
+  if (ctx->pc_work) (void)hipFree(ctx->pc_work);
   for (int i = 0; i < NRING; i++)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -324,16 +327,24 @@ extern "C" int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D,
   const bool in_lds = D <= AEHMC_PC_LDS_MAX_D;
   const size_t dyn = in_lds ? (size_t)2 * D * D * sizeof(double) : 0;
   double *work = nullptr;
-  if (!in_lds) HIPCHK(hipMalloc((void **)&work, (size_t)C * D * D * sizeof(double)));
+  if (!in_lds) {  // the factor is formed in a scratch copy: kept with the ctx, not allocated per call
+    const size_t need = (size_t)C * D * D * sizeof(double);
+    if (ctx->pc_work_bytes < need) {
+      if (ctx->pc_work) HIPCHK(hipFree(ctx->pc_work));
+      ctx->pc_work = nullptr;
+      ctx->pc_work_bytes = 0;
+      HIPCHK(hipMalloc((void **)&ctx->pc_work, need));
+      ctx->pc_work_bytes = need;
+    }
+    work = ctx->pc_work;
+  }
   if (dyn)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_inv_pc),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
   hipLaunchKernelGGL(k_chol_inv_pc, dim3((unsigned)C), dim3(64), dyn, (hipStream_t)stream, imm, sqrt_mass,
                      (long long)C, (int)D, ctx->d_err + 1, work);
-  const hipError_t le = hipGetLastError(), se = hipStreamSynchronize((hipStream_t)stream);
-  if (work) (void)hipFree(work);
-  HIPCHK(le);
-  HIPCHK(se);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   if (ctx->h_err[1]) {
     ctx->h_err[1] = 0;
     FAIL("inverse mass matrix of some chain is not positive definite");
