@@ -59,3 +59,43 @@ def test_random_stream_scheme_a():
     st2 = s.sites(2)
     g5 = np.random.default_rng(np.random.SeedSequence(0).spawn(6)[5]).bit_generator.state["state"]
     assert int(st2[0, 1, 1]) == g5["state"] & (2**64 - 1)
+
+
+def test_random_stream_from_state_round_trip():
+    """RandomStream.from_state hands the saved generator states to the NEXT kernel and keeps the spawn sequence
+    of the seeds where an unbroken session would be (README.md:49-51: the reference threads RNG state through
+    `updates`); without the seeds it can resume one kernel only."""
+    import numpy as np
+    from aehmc_amd import RandomStream
+    s = RandomStream(seed=0)
+    nuts_sites, hmc_sites = s.sites(4), s.sites(2)
+    r = RandomStream.from_state(nuts_sites.view(np.int64), seed=0)  # int64 bit patterns, as a device tensor holds them
+    assert not r.batched and r.num_chains == 1
+    assert np.array_equal(r.sites(4), nuts_sites) and np.array_equal(r.sites(2), hmc_sites)
+    many = RandomStream(seeds=[3, 4, 5])
+    st = many.sites(2)
+    lone = RandomStream.from_state(st)
+    assert lone.batched and lone.num_chains == 3 and np.array_equal(lone.sites(2), st)
+    with pytest.raises(ValueError, match="without its seeds"):
+        lone.sites(2)
+    with pytest.raises(ValueError, match="call sites"):
+        RandomStream.from_state(st, seeds=[3, 4, 5]).sites(4)
+    with pytest.raises(ValueError, match="saved chains"):
+        RandomStream.from_state(st, seeds=[3, 4])
+    with pytest.raises(ValueError, match=r"\[C, n_sites, 4\]"):
+        RandomStream.from_state(st[0])
+
+
+def test_window_adaptation_schedule_and_hmc_argument():
+    """build_schedule is the reference's (tests/test_adaptation.py:9-22 pins it in test_adaptation_oracle.py); an
+    HMC kernel without its trajectory length is refused before anything touches the GPU."""
+    from aehmc_amd import window_adaptation
+    sched = window_adaptation.build_schedule(1000)
+    assert len(sched) == 1000 and sched[0] == (0, False) and sched[75] == (1, False)
+    assert sum(1 for _, e in sched if e) == 5 and sched[-1] == (0, False)
+
+    def fake_hmc(state, eps, imm, L):
+        raise AssertionError("not reached")
+    fake_hmc._hmc = {}
+    with pytest.raises(ValueError, match="num_integration_steps"):
+        window_adaptation.run(fake_hmc, None, 10)
