@@ -49,7 +49,7 @@ def test_config3_depth10_both_dense_modes_match_oracle(c3_model, c3_oracle):
     """c3 with max_num_expansions = 10 (the benchmarked setting), 256 chains, two consecutive
     transitions in both dense-metric modes (`dense_linear` 1: v and w carried by recurrence, 2 GEMMs
     per leapfrog -- the default and what the bench times; 0: the literal 3 products of
-    metrics.py:71).  Four chains -- first, last, the deepest and the shallowest tree -- against
+    metrics.py:71).  32 of the 256 chains -- first, last, the deepest and the shallowest tree, 28 more -- against
     the C oracle: n_leapfrog, num_doublings, both flags and the RNG state after the transition
     identical, real outputs within 1e-9.  The two modes must agree with each other on every chain
     in every discrete output (a U-turn test is a `<= 0` on values that differ by rounding)."""
@@ -90,8 +90,10 @@ def test_config3_depth10_both_dense_modes_match_oracle(c3_model, c3_oracle):
     assert nd0.max() >= 5 and nl0.max() >= 33, (nd0.max(), nl0.max())  # trees do run deep
     assert len(np.unique(nl0)) >= 2                                    # ... and leave the launches at different steps
     sel = sorted({0, C - 1, int(nl0.argmax()), int(nl0.argmin())})
-    while len(sel) < 4:
-        sel = sorted(set(sel) | {len(sel) * 37 % C})
+    k = 1
+    while len(sel) < 32:  # (round 3: 32 of the 256 chains instead of four, one OpenMP thread each on the host; 64 pass too, in 215 s)
+        sel = sorted(set(sel) | {k * 37 % C})
+        k += 1
     rng = co.site_states([seeds[i] for i in sel], 4)
     q, U, g = co.new_state(otgt, q0[sel].copy())
     for t in range(2):
