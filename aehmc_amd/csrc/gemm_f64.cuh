@@ -210,19 +210,27 @@ struct GemmStreamK {
   int epoch;
 };
 
+// PW: column tiles per panel.  The concurrent tiles of an XCD are a run of consecutive tile numbers, i.e. a
+// (run / PW) x PW super-tile whose A and B panels its L2 shares.  128 x 128 tiles, 64 per XCD: 8 x 8.  128 x 256
+// tiles, 32 per XCD (one workgroup per CU): PW = 4 gives 8 x 4 tiles = 1024 + 1024 operand rows per (XCD, round)
+// where PW = 8 streamed 512 + 2048 (round 3; the order of the tiles does not change any result).
+#ifndef AEHMC_GEMM_PW_WIDE
+#define AEHMC_GEMM_PW_WIDE 4
+#endif
+template <int PW>
 __device__ __forceinline__ void gemm_tile_coords(int t, int Tm, int Tn, int &tm, int &tn) {
-  const int per_panel = Tm * GEMM_PANEL_W;
-  const int nfull = Tn / GEMM_PANEL_W;
+  const int per_panel = Tm * PW;
+  const int nfull = Tn / PW;
   const int panel = t / per_panel;
   if (panel < nfull) {
     const int rr = t - panel * per_panel;
-    tn = panel * GEMM_PANEL_W + rr % GEMM_PANEL_W;
-    tm = rr / GEMM_PANEL_W;
+    tn = panel * PW + rr % PW;
+    tm = rr / PW;
   } else {
-    int wlast = Tn - nfull * GEMM_PANEL_W;
+    int wlast = Tn - nfull * PW;
     if (wlast < 1) wlast = 1;
     const int rr = t - nfull * per_panel;
-    tn = nfull * GEMM_PANEL_W + rr % wlast;
+    tn = nfull * PW + rr % wlast;
     tm = rr / wlast;
   }
 }
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256, (PIPE ? 1 : 2)) void gemm_nt_f64_streamk_kerne
   // partial; 2 = tail: continue from the neighbour's partial -> C
   auto pass = [&](int t, int kb, int ke, int mode) {
     int tm, tn;
-    gemm_tile_coords(t, Tm, Tn, tm, tn);
+    gemm_tile_coords<(NJ == 8 ? AEHMC_GEMM_PW_WIDE : GEMM_PANEL_W)>(t, Tm, Tn, tm, tn);
     const int64_t m0 = (int64_t)tm * GEMM_BM, n0 = (int64_t)tn * BN;
     __syncthreads();  // previous pass is done with s_rows / LDS
     if (tid < GEMM_BM) {
