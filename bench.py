@@ -237,7 +237,8 @@ def launch_ranks(n, timeout_s=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: 5 (c1, c2: 20, c5: 100)")
+    ap.add_argument("--steps", type=int, default=None, help="default: 5 (c1, c2: 20; c5: 1000 transitions -- as many draws as "
+                                                            "warm-up steps -- in one launch)")
     ap.add_argument("--warmup", type=int, default=None, help="default: 1 (c1, c2: 5 -- their steps are < 1 ms each, and the "
                                                              "clocks of an idle GPU take longer than that to come up)")
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"],
@@ -249,7 +250,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the diagonal-mass secondary lines")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"c1": 20, "c2": 20, "c5": 100}.get(args.config, 5)
+        args.steps = {"c1": 20, "c2": 20, "c5": 1000}.get(args.config, 5)
     if args.warmup is None:
         args.warmup = {"c1": 5, "c2": 5, "c5": 1000}.get(args.config, 1)
     if args.chains is None:
