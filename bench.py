@@ -510,7 +510,7 @@ def bench_c5(args, rank, world, device):
         flops = 6.0 * N * total_rank / max(kern_n, 1)
         achieved = flops / avg_s / 1e12
         pj, src = pmc_summary("c5_pmc_summary.json")
-        if not (pj and C == 1024):
+        if not (pj and C == 1024 and pj.get("run", {}).get("transitions") == args.steps):  # counters of THIS launch shape only
             pj, src = None, None
         roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP64_VALU_TFLOPS, "kernel": "k_nuts_linreg", "avg_launch_ms": avg_s * 1e3,

@@ -1,11 +1,12 @@
 #!/bin/bash
-# Round-3 counters for config c5 (k_nuts_linreg: 1024 chains x 1e5 rows, sample(100) after a 1000-step warm-up):
+# Round-3 counters for config c5 (k_nuts_linreg: 1024 chains x 1e5 rows, sample(1000) after a 1000-step warm-up = the
+# bench's default launch):
 # kernel-trace stats, then SEPARATE --pmc passes (no trace domains mixed in), program directly after `--`.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r3_c5
 mkdir -p $O
-CMD="python3 $R/tools/c5_run.py 1024 1000 100"
+CMD="python3 $R/tools/c5_run.py 1024 1000 1000"
 $CMD > $O/run.json 2> $O/run.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c5 -- $CMD > $O/stats.log 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/run_r3_c5.sh -> c5_pmc_summary.json: counters of the LAST k_nuts_linreg dispatch of tools/c5_run.py (the
-sample(100) launch of 1024 chains x 1e5 rows after the warm-up launch) and the derived figures bench.py --config c5
+sample() launch of 1024 chains x 1e5 rows after the warm-up launch) and the derived figures bench.py --config c5
 reports.  FETCH_SIZE / WRITE_SIZE come in KB; FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B,
 MI355X_MICROARCH.md, HBM section); SQ_*CYCLES / SQ_WAIT* / SQ_ACTIVE* count quad-cycles."""
 import csv, glob, json, os, sys
@@ -55,8 +55,8 @@ if "TCC_REQ_sum" in k:
     d["l2_bytes_algorithmic"] = 16.0 * (N - 10176) * rounds_lb
 if "GRBM_GUI_ACTIVE" in k:
     d["clock_GHz_grbm"] = k["GRBM_GUI_ACTIVE"] / 8 / t / 1e9
-out = {"note": "rocprofv3, separate --pmc passes of `tools/c5_run.py 1024 1000 100` (profiles/run_r3_c5.sh); values of the LAST "
-               "k_nuts_linreg dispatch = sample(100) of 1024 chains x 1e5 rows after the 1000-step warm-up launch; FETCH_SIZE "
+out = {"note": "rocprofv3, separate --pmc passes of `tools/c5_run.py` (profiles/run_r3_c5.sh; chains, warm-up steps and transitions in `run`); values of the LAST "
+               "k_nuts_linreg dispatch = the sample() launch after the warm-up launch; FETCH_SIZE "
                "doubled; SQ cycle counters in quad-cycles",
        "run": run, "per_launch": k, "derived": d}
 json.dump(out, open(os.path.join(src, "c5_pmc_summary.json"), "w"), indent=1)
