@@ -102,3 +102,84 @@ def test_hip_matches_the_independent_derivation(case, linear):
             assert bool(info.is_diverging.item()) == e["is_diverging"]
     finally:
         eng.set_option("dense_linear", 1)
+
+
+def _independent():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_dense_pin", os.path.join(HERE, "golden", "make_dense_pin.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_restatements_match_the_independent_derivation_on_random_cases(block):
+    """Beyond the four committed cases: the independent derivation itself (tests/golden/make_dense_pin.py, imported
+    here) against the C and numpy restatements on 40 random dense problems -- D = 2 ... 6, random SPD precision and
+    inverse mass matrix, step sizes from tiny (deep trees, cut at max_num_expansions) to large (early U-turns, low
+    acceptance), both samplers: every discrete output identical, values to 1e-10."""
+    from oracle import c_oracle as co
+    from oracle import np_oracle as no
+    ind = _independent()
+    r = np.random.default_rng(900 + block)
+    depth_seen = set()
+    for k in range(10):
+        D = int(r.integers(2, 7))
+        A, B = r.normal(size=(D, D)), r.normal(size=(D, D))
+        P = A @ A.T / D + 0.5 * np.eye(D)
+        imm = B @ B.T / D + 0.5 * np.eye(D)
+        P, imm = 0.5 * (P + P.T), 0.5 * (imm + imm.T)
+        mu, q0 = r.normal(size=D), r.normal(size=D)
+        eps = float(np.exp(r.uniform(np.log(0.02), np.log(0.9))))
+        max_exp = int(r.choice([3, 6, 10]))
+        seed = int(r.integers(0, 2 ** 31))
+        e = ind.nuts_transition(seed, q0, mu, P, imm, eps, max_exp)
+        otgt = co.Target(co.T_DENSE_MVN, D, mu=mu, prec=P)
+        q, U, g = co.new_state(otgt, q0.copy())
+        res = co.nuts_step(otgt, co.Metric(imm, D), co.site_states([seed], 4), eps, q, U, g, max_exp=max_exp)
+        np.testing.assert_allclose(q[0], e["position"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(res["acceptance_probability"][0], e["acceptance_probability"], rtol=1e-10)
+        got = (int(res["n_leapfrog"][0]), int(res["num_doublings"][0]), bool(res["is_turning"][0]), bool(res["is_diverging"][0]))
+        assert got == (e["n_leapfrog"], e["num_doublings"], e["is_turning"], e["is_diverging"]), (block, k)
+        tgt = no.DenseMVN(mu, P)
+        info = no.nuts_kernel(no.RandomStream(seed), tgt, max_num_expansions=max_exp)(no.new_state(q0, tgt), eps, imm)
+        np.testing.assert_allclose(info.state.position, e["position"], rtol=1e-10, atol=1e-12)
+        assert info.n_leapfrog == e["n_leapfrog"]
+        depth_seen.add(e["num_doublings"])
+        h = ind.hmc_transition(seed, q0, mu, P, imm, eps, 7)
+        q, U, g = co.new_state(otgt, q0.copy())
+        hres = co.hmc_step(otgt, co.Metric(imm, D), co.site_states([seed], 2), eps, 7, q, U, g)
+        np.testing.assert_allclose(q[0], h["position"], rtol=1e-10, atol=1e-12)
+        assert bool(hres["accepted"][0]) == h["accepted"]
+    assert len(depth_seen) >= 3
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_independent_derivation_on_random_cases():
+    """The product's dense path against the independent derivation itself on 16 random dense problems (D = 2 ... 6,
+    single chains, trees from a few to dozens of leapfrogs) -- no oracle involved."""
+    import torch
+    from aehmc_amd import RandomStream, nuts, targets
+    ind = _independent()
+    r = np.random.default_rng(4242)
+    deep = 0
+    for k in range(16):
+        D = int(r.integers(2, 7))
+        A, B = r.normal(size=(D, D)), r.normal(size=(D, D))
+        P = A @ A.T / D + 0.5 * np.eye(D)
+        imm = B @ B.T / D + 0.5 * np.eye(D)
+        P, imm = 0.5 * (P + P.T), 0.5 * (imm + imm.T)
+        mu, q0 = r.normal(size=D), r.normal(size=D)
+        eps = float(np.exp(r.uniform(np.log(0.03), np.log(0.7))))
+        max_exp = int(r.choice([4, 10]))
+        seed = int(r.integers(0, 2 ** 31))
+        e = ind.nuts_transition(seed, q0, mu, P, imm, eps, max_exp)
+        tgt = targets.DenseMVN(mu, P)
+        kernel = nuts.new_kernel(RandomStream(seed=seed), tgt, max_num_expansions=max_exp)
+        info, _ = kernel(nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt), eps, imm)
+        np.testing.assert_allclose(info.state.position.cpu().numpy(), e["position"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(info.acceptance_probability.item(), e["acceptance_probability"], rtol=1e-9)
+        got = (info.n_leapfrog.item(), info.num_doublings.item(), bool(info.is_turning.item()), bool(info.is_diverging.item()))
+        assert got == (e["n_leapfrog"], e["num_doublings"], e["is_turning"], e["is_diverging"]), k
+        deep += e["n_leapfrog"] >= 10
+    assert deep >= 4
