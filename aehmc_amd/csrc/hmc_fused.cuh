@@ -203,14 +203,17 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
 // dead momentum behind the last energy sum, i.e. under the accept arithmetic) and nothing on the way out
 // but the optional sample row; q, dU/dq, U go out once, at the end of the launch, if any transition was
 // accepted.  The position a rejection falls back to waits in LDS (each thread re-reads only what it wrote
-// itself: no barrier).  Cross-wave sums take one LDS hop, so the summation order differs from the lock-step
+// itself: no barrier).  Diagonal-Gaussian target: the LDS holds sigma and mu instead (two divisions by sigma per
+// element and leapfrog: from L2 they cost the loop its registers -- 264 B/lane of scratch, 5.6 ms per transition
+// at D = 1e4), and the fall-back state is the caller's q / dU/dq, rewritten at every accepted transition.  Cross-wave sums take one LDS hop, so the summation order differs from the lock-step
 // path (1e-13).  Slots past D replicate element D-1 (in bounds), are masked out of the sums, never stored.
 template <int T, int R, int TK>
 __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zbuf, int nt) {
   constexpr int NW = T / 64;
   constexpr bool DG = TK == AEHMC_T_DIAG_GAUSSIAN;  // otherwise dU/dq == q, no separate copy
   __shared__ double red[2][2 * NW];
-  extern __shared__ __attribute__((aligned(16))) double wide_save[];  // q [D] (+ dU/dq [D]) at the transition's start
+  extern __shared__ __attribute__((aligned(16))) double wide_save[];  // q [D] at the transition's start; DG: sigma [D], mu [D]
+  double *const psig = wide_save, *const pmu = wide_save + a.D;       // (diagonal-Gaussian target only)
   int flip = 0;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -257,6 +260,10 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
     p[r] = zrow[EI(r)];
     if (DG) g[r] = grow[EI(r)];
     im[r] = a.imm[imo + (a.met_ndim == 0 ? 0 : EI(r))];
+    if (DG) {  // (a thread reads back only the entries it wrote: no barrier)
+      psig[EI(r)] = a.sigma[EI(r)];
+      pmu[EI(r)] = a.mu[EI(r)];
+    }
   }
 #define GR(r) (DG ? g[DG ? (r) : 0] : q[r])
   double U = a.U[c];
@@ -272,8 +279,7 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
 #pragma unroll
     for (int r = 0; r < R; r++) {
       kd += MASK(r) * ((im[r] * p[r]) * p[r]);
-      wide_save[EI(r)] = q[r];
-      if (DG) wide_save[a.D + EI(r)] = g[DG ? r : 0];
+      if (!DG) wide_save[EI(r)] = q[r];
       // only the last transition's momentum is observable: the initial one is kept on rejection
       if (last_t && a.out.momentum && VALID(r)) (a.out.momentum + row)[EI(r)] = p[r];
     }
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
         for (int r = 0; r < R; r++) {
           double pp = p[r] - b * GR(r);
           const double qq = q[r] + aa * (im[r] * pp);
-          const double gg = ((qq - a.mu[EI(r)]) / a.sigma[EI(r)]) / a.sigma[EI(r)];
+          const double sd = psig[EI(r)];
+          const double gg = ((qq - pmu[EI(r)]) / sd) / sd;
           pp = pp - b * gg;
           q[r] = qq;
           g[DG ? r : 0] = gg;
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
       if (TK == AEHMC_T_STD_NORMAL) u = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
       else if (TK == AEHMC_T_ISO_GAUSSIAN) u = qq * qq;
       else {
-        const double z = (qq - a.mu[EI(r)]) / a.sigma[EI(r)];
+        const double z = (qq - pmu[EI(r)]) / psig[EI(r)];
         u = 0.5 * (z * z) + a.log_sigma[EI(r)] + AEHMC_LOG_SQRT_2PI;
       }
       usum += MASK(r) * u;
@@ -344,11 +351,23 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
     if (acc) {
       U = Unew;
       any_acc = 1;
+      if (DG) {  // the caller's arrays are this target's fall-back state: they follow every accepted transition
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          if (!VALID(r)) continue;
+          (a.q + row)[EI(r)] = q[r];
+          (a.g + row)[EI(r)] = g[DG ? r : 0];
+        }
+      }
     } else {  // back to the transition's start
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        q[r] = wide_save[EI(r)];
-        if (DG) g[DG ? r : 0] = wide_save[a.D + EI(r)];
+        if (DG) {
+          q[r] = qrow[EI(r)];
+          g[DG ? r : 0] = grow[EI(r)];
+        } else {
+          q[r] = wide_save[EI(r)];
+        }
       }
     }
     if (a.samples) {
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
     }
   }
   RENEW_TB();
-  if (any_acc) {  // commit; a call without an accepted transition leaves the state in HBM untouched
+  if (any_acc && !DG) {  // commit; a call without an accepted transition leaves the state in HBM untouched
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (!VALID(r)) continue;
