@@ -785,8 +785,11 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   const int tkind = ctx->tgt.kind, nd = ctx->met.ndim;
   const int64_t D = ctx->tgt.D;
   if (ctx->opt_resident_nuts && nuts_linreg_supported(tkind, nd, D, max_num_expansions)) return NUTS_PATH_LINREG;
-  const bool want_resident =
-      ctx->opt_resident_nuts == 1 || (ctx->opt_resident_nuts == 2 && (D > 256 || C >= 16384 || C <= 2048));
+  // auto (2) == always where a single-launch kernel exists (round 3): measured again with round 2's resident
+  // kernels, they beat the lock-step path at EVERY chain count -- 1.6x to 3x between 2048 and 16384 chains, where
+  // the old rule still picked lock-step (tools/debug/resident_vs_lockstep.py, profiles/r3/INDEX.md)
+  const bool want_resident = ctx->opt_resident_nuts != 0;
+  (void)C;
   if (want_resident && nuts_resident_supported(tkind, nd, D)) return NUTS_PATH_TEAMS;  // D <= 512
   if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
   return NUTS_PATH_LOCKSTEP;
@@ -806,14 +809,9 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   a.eps = step_size; a.thr = divergence_threshold;
   a.rng = rng; a.nsites = 4;
   a.q = q; a.U = U; a.g = g; a.out = *out;
-  // auto (measured crossovers, tools/nuts_diag_bench.py): the resident kernel wins when the state
-  // no longer fits the lock-step kernels' on-chip reuse (D > 256), when there are enough chains
-  // to fill the GPU with sub-wavefront teams (C >= 16384), and in the latency regime -- up to
-  // 2048 chains (down to the single chain of the README example) all teams are resident at once
-  // and one launch replaces one launch per leapfrog;
-  // a few thousand chains of small D run faster in lock step.  The regression target always
-  // takes its workgroup-cooperative resident kernel (nuts_linreg.cuh), which also runs any number
-  // of consecutive transitions in one launch.
+  // The single-launch kernels (teams of <= 64 lanes up to D = 512, a workgroup per chain above, the
+  // workgroup-cooperative regression kernel) are taken wherever they exist; the lock-step engine below serves
+  // dense metrics, dense targets, and `resident_nuts` = 0.
   if (nuts_path(ctx, C, max_num_expansions) == NUTS_PATH_LINREG) {
     NutsSampleArgs m{};
     m.T = 1;

@@ -117,12 +117,11 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *  "fused_hmc" 1    register-resident single-launch HMC when the metric is diagonal and the
  *                   target coordinate-wise; 0 forces the lock-step path
  *  "resident_nuts" 2 register-resident single-launch NUTS (a team of 1..64 lanes, or a
- *                   256/1024-thread workgroup for large D, keeps the chain's moving state in
- *                   VGPRs for the whole tree) for diagonal/scalar metrics, coordinate-wise
+ *                   256/512-thread workgroup for large D, keeps the chain's moving state on chip
+ *                   for the whole tree) for diagonal/scalar metrics, coordinate-wise
  *                   targets, D <= 10176, and the regression target (four chains per workgroup
- *                   share each pass over the data rows).  2 = auto (used when D > 256,
- *                   C >= 16384 or C <= 2048, where it beats the lock-step path, and always
- *                   for the regression target), 1 = always, 0 = never
+ *                   share each pass over the data rows).  2 (auto) = 1 = wherever such a kernel exists
+ *                   (round 3: it beats the lock-step path at every chain count), 0 = never
  *  "resident_min_team" 0  1: always give a chain the smallest team of lanes that holds it
  *                   (64/T chains per wavefront) instead of widening teams while the GPU would
  *                   otherwise run fewer than ~4096 wavefronts
