@@ -803,6 +803,79 @@ __global__ __launch_bounds__(256) void k_nuts_fused(EngineArgs a) {
   }
   rng_store(a, c, lane, rng, 0, 3);
 }
+// ---- small dense problems: the whole transition of a chain in ONE launch, mat-vecs inside the wavefront ----------
+// Dense inverse mass matrix and / or dense-precision target with D <= 64 -- the classic full-mass-matrix use.  On the
+// lock-step path a leapfrog of such a problem is four launches around two D x D "GEMMs" and costs ~70 us whatever
+// the chain count (tools/debug/small_dense.py: 1.5 ms per transition at D = 50, 4096 chains).  Here the wavefront
+// that owns the chain loops stages, products and bookkeeping by itself, as k_nuts_fused does for diagonal metrics:
+// the (shared) matrices sit TRANSPOSED in LDS, lane i forms row i of a product with the operand's elements
+// broadcast from registers (v_readlane), k ascending from 0.0 -- the order of the reference's dot products
+// (the restatement's too), one rounding per product and per sum.  Literal dense mode (metrics.py:71: imm p_half and
+// imm p' are formed, 3 products per leapfrog); the chain's vectors are rows of the work arrays (L1 / L2 resident at
+// this size).  Same stage and bookkeeping functions as every other path.
+constexpr int FUSED_DENSE_MAX_D = 64;
+constexpr int FUSED_DENSE_BLOCK = 512;  // eight chains per workgroup share the matrices
+// y[i] = sum_k M[i][k] x[k] for i < D; MT = M transposed in LDS (MT[k * D + i] = M[i][k]); x, y rows in global memory,
+// element i read and written by lane i only
+__device__ __forceinline__ void wave_matvec_lds(const double *MT, const double *x, double *y, int D, int lane) {
+  const bool on = lane < D;
+  const double xl = on ? x[lane] : 0.0;
+  double acc = 0.0;
+  for (int k = 0; k < D; k++) {
+    const double xk = read_lane_f64(xl, k);
+    if (on) acc += MT[k * D + lane] * xk;
+  }
+  if (on) y[lane] = acc;
+}
+template <bool MD, bool TD>
+__global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_nuts_fused_dense(EngineArgs a, const double *prec) {
+  extern __shared__ __attribute__((aligned(16))) double fd_lds[];
+  const int D = (int)a.D, DD = D * D;
+  double *const immT = fd_lds;                          // MD: imm (symmetric up to rounding: transposed literally)
+  double *const smT = fd_lds + (MD ? DD : 0);           // MD: sqrt_mass = L^-T
+  double *const PT = fd_lds + (MD ? 2 * DD : 0);        // TD: the target's precision
+  for (int e = threadIdx.x; e < DD; e += FUSED_DENSE_BLOCK) {
+    const int i = e / D, k = e % D;
+    if (MD) {
+      immT[k * D + i] = a.imm[e];
+      smT[k * D + i] = a.sqrt_mass[e];
+    }
+    if (TD) PT[k * D + i] = prec[e];
+  }
+  __syncthreads();
+  AEHMC_CHAIN_OF_WAVE();
+  const size_t row = (size_t)c * a.D;
+  ChainRng rng = rng_load(a, c);
+  ChainCtl ct;
+  draw_momentum<MD>(a, c, lane, rng.g[0]);  // MD: z -> zbuf; otherwise sqrt(1/imm) o z -> cur_p
+  if (MD) {
+    wave_matvec_lds(smT, a.zbuf + row, a.cur_p + row, D, lane);    // p = L^-T z (metrics.py:66-67)
+    wave_matvec_lds(immT, a.cur_p + row, a.cur_v + row, D, lane);  // v = imm p
+  }
+  nuts_init_chain<MD>(a, c, lane, ct, rng);
+  while (!ct.done) {
+    double U_new = 0.0;
+    if (MD) {
+      leap_stages<true, false, false, true>(a, c, lane, ct.dir, U_new);            // p_half
+      wave_matvec_lds(immT, a.cur_p + row, a.vhalf + row, D, lane);                // imm p_half
+      if (TD) {
+        leap_stages<false, true, false, true>(a, c, lane, ct.dir, U_new);          // q', r = q' - mu
+        wave_matvec_lds(PT, a.rbuf + row, a.cur_g + row, D, lane);                 // dU/dq = P r
+        if (leap_stages<false, false, true, true>(a, c, lane, ct.dir, U_new)) ct.U_cur = U_new;  // U, p'
+      } else {
+        if (leap_stages<false, true, true, true>(a, c, lane, ct.dir, U_new)) ct.U_cur = U_new;   // q', target, p'
+      }
+      wave_matvec_lds(immT, a.cur_p + row, a.cur_v + row, D, lane);                // imm p'
+    } else {  // diagonal / scalar metric, dense target
+      leap_stages<true, true, false, false>(a, c, lane, ct.dir, U_new);
+      wave_matvec_lds(PT, a.rbuf + row, a.cur_g + row, D, lane);
+      if (leap_stages<false, false, true, false>(a, c, lane, ct.dir, U_new)) ct.U_cur = U_new;
+    }
+    nuts_book<MD>(a, c, lane, ct, rng);
+  }
+  rng_store(a, c, lane, rng, 0, 3);
+}
+
 // MODE: stage set; BOOK: run the NUTS bookkeeping afterwards
 template <bool DO1, bool DO2, bool DO3, bool MET_DENSE, bool BOOK>
 __global__ __launch_bounds__(256) void k_step(EngineArgs a) {

@@ -780,7 +780,7 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
 
 // which kernel family a NUTS call takes (one place: aehmc_nuts_warmup asks before it commits to a
 // single-launch warm-up)
-enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE };
+enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE, NUTS_PATH_FUSED_DENSE };
 static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions) {
   const int tkind = ctx->tgt.kind, nd = ctx->met.ndim;
   const int64_t D = ctx->tgt.D;
@@ -792,6 +792,11 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   (void)C;
   if (want_resident && nuts_resident_supported(tkind, nd, D)) return NUTS_PATH_TEAMS;  // D <= 512
   if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
+  // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
+  // inside the wavefront (k_nuts_fused_dense)
+  if (want_resident && D <= FUSED_DENSE_MAX_D && !ctx->met.per_chain && (nd == 2 || tkind == AEHMC_T_DENSE_MVN) &&
+      (target_is_elem_host(tkind) || tkind == AEHMC_T_DENSE_MVN))
+    return NUTS_PATH_FUSED_DENSE;
   return NUTS_PATH_LOCKSTEP;
 }
 
@@ -843,6 +848,26 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       }
       HIPCHK(launch_nuts_resident(a, m, st, ctx->opt_resident_min_team));
     }
+    return prof_end(ctx, st, p);
+  }
+  if (path == NUTS_PATH_FUSED_DENSE) {
+    const bool md = a.met_ndim == 2, td = a.tkind == AEHMC_T_DENSE_MVN;
+    a.linear = 0;  // literal products (metrics.py:71)
+    const size_t dyn = (size_t)((md ? 2 : 0) + (td ? 1 : 0)) * a.D * a.D * sizeof(double);
+    const dim3 grid((unsigned)((C + FUSED_DENSE_BLOCK / 64 - 1) / (FUSED_DENSE_BLOCK / 64))), block(FUSED_DENSE_BLOCK);
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+#define AEHMC_FD_LAUNCH(MDV, TDV)                                                                              \
+  do {                                                                                                         \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_fused_dense<MDV, TDV>),                   \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                         \
+    hipLaunchKernelGGL((k_nuts_fused_dense<MDV, TDV>), grid, block, dyn, st, a, ctx->tgt.prec);                 \
+  } while (0)
+    if (md && td) AEHMC_FD_LAUNCH(true, true);
+    else if (md) AEHMC_FD_LAUNCH(true, false);
+    else AEHMC_FD_LAUNCH(false, true);
+#undef AEHMC_FD_LAUNCH
+    HIPCHK(hipGetLastError());
     return prof_end(ctx, st, p);
   }
   if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
