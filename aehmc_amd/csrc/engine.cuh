@@ -974,7 +974,7 @@ __global__ void k_count_active(const ChainCtl *ctl, long long C, int *out) {
 
 // ---- HMC (hmc.py:77-124, 157-204; trajectory.py:31-107) ---------------------------
 template <bool MET_DENSE>
-__device__ inline void hmc_init_chain(const EngineArgs &a, long long c, int lane) {
+__device__ inline ChainCtl hmc_init_chain(const EngineArgs &a, long long c, int lane) {
   const size_t row = (size_t)c * a.D;
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
@@ -991,6 +991,7 @@ __device__ inline void hmc_init_chain(const EngineArgs &a, long long c, int lane
   ct.H0 = ct.U_cur + 0.5 * kd;  // hmc.py:187
   ct.dir = 1;
   if (lane == 0) a.ctl[c] = ct;
+  return ct;
 }
 template <bool MET_DENSE>
 __global__ __launch_bounds__(256) void k_hmc_init(EngineArgs a) {
@@ -1004,11 +1005,10 @@ __global__ __launch_bounds__(256) void k_hmc_begin_diag(EngineArgs a) {
   rng_store(a, c, lane, rng, 0, 0);
   hmc_init_chain<false>(a, c, lane);
 }
+// hmc.py:185-204 after the L leapfrogs: flip, energy difference, accept / reject, outputs
 template <bool MET_DENSE>
-__global__ __launch_bounds__(256) void k_hmc_end(EngineArgs a, long long L) {
-  AEHMC_CHAIN_OF_WAVE();
+__device__ inline void hmc_end_chain(const EngineArgs &a, long long c, int lane, const ChainCtl &ct, long long L) {
   const size_t row = (size_t)c * a.D;
-  ChainCtl ct = a.ctl[c];
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
     double p = -1.0 * a.cur_p[row + i];  // hmc.py:185 momentum flip
@@ -1042,6 +1042,61 @@ __global__ __launch_bounds__(256) void k_hmc_end(EngineArgs a, long long L) {
     if (a.out.n_leapfrog) a.out.n_leapfrog[c] = L;
     if (a.out.is_turning) a.out.is_turning[c] = acc;  // HMC: reused as the accept flag
   }
+}
+template <bool MET_DENSE>
+__global__ __launch_bounds__(256) void k_hmc_end(EngineArgs a, long long L) {
+  AEHMC_CHAIN_OF_WAVE();
+  const ChainCtl ct = a.ctl[c];
+  hmc_end_chain<MET_DENSE>(a, c, lane, ct, L);
+}
+// The HMC transition of a small dense problem in one launch (see k_nuts_fused_dense: same matrices in LDS, same
+// in-wavefront products, literal dense mode); the chain's scalars stay in registers between the stages.
+template <bool MD, bool TD>
+__global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArgs a, const double *prec, long long L) {
+  extern __shared__ __attribute__((aligned(16))) double fd_lds[];
+  const int D = (int)a.D, DD = D * D;
+  double *const immT = fd_lds, *const smT = fd_lds + (MD ? DD : 0), *const PT = fd_lds + (MD ? 2 * DD : 0);
+  for (int e = threadIdx.x; e < DD; e += FUSED_DENSE_BLOCK) {
+    const int i = e / D, k = e % D;
+    if (MD) {
+      immT[k * D + i] = a.imm[e];
+      smT[k * D + i] = a.sqrt_mass[e];
+    }
+    if (TD) PT[k * D + i] = prec[e];
+  }
+  __syncthreads();
+  AEHMC_CHAIN_OF_WAVE();
+  const size_t row = (size_t)c * a.D;
+  {
+    Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4);
+    draw_momentum<MD>(a, c, lane, g1);
+    if (lane == 0) pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
+  }
+  if (MD) {
+    wave_matvec_lds(smT, a.zbuf + row, a.cur_p + row, D, lane);
+    wave_matvec_lds(immT, a.cur_p + row, a.cur_v + row, D, lane);
+  }
+  ChainCtl ct = hmc_init_chain<MD>(a, c, lane);
+  for (long long l = 0; l < L; l++) {  // trajectory.py:86-95
+    double U_new = 0.0;
+    if (MD) {
+      leap_stages<true, false, false, true>(a, c, lane, 1, U_new);
+      wave_matvec_lds(immT, a.cur_p + row, a.vhalf + row, D, lane);
+      if (TD) {
+        leap_stages<false, true, false, true>(a, c, lane, 1, U_new);
+        wave_matvec_lds(PT, a.rbuf + row, a.cur_g + row, D, lane);
+        if (leap_stages<false, false, true, true>(a, c, lane, 1, U_new)) ct.U_cur = U_new;
+      } else {
+        if (leap_stages<false, true, true, true>(a, c, lane, 1, U_new)) ct.U_cur = U_new;
+      }
+      if (l == L - 1) wave_matvec_lds(immT, a.cur_p + row, a.cur_v + row, D, lane);  // for the final kinetic energy
+    } else {
+      leap_stages<true, true, false, false>(a, c, lane, 1, U_new);
+      wave_matvec_lds(PT, a.rbuf + row, a.cur_g + row, D, lane);
+      if (leap_stages<false, false, true, false>(a, c, lane, 1, U_new)) ct.U_cur = U_new;
+    }
+  }
+  hmc_end_chain<MD>(a, c, lane, ct, L);
 }
 
 // ---- new_state / stand-alone building blocks --------------------------------------

@@ -1122,12 +1122,36 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   a.eps = step_size; a.thr = divergence_threshold;
   a.rng = rng; a.nsites = 2;
   a.q = q; a.U = U; a.g = g; a.out = *out;
+  // small dense problems (shared dense metric and / or dense-precision target, D <= 64): the transition in one
+  // launch with the products inside the wavefront (k_hmc_fused_dense), as for NUTS
+  const bool fused_dense = ctx->opt_fused_hmc && D <= FUSED_DENSE_MAX_D && !ctx->met.per_chain &&
+                           (a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN) &&
+                           (target_is_elem_host(a.tkind) || a.tkind == AEHMC_T_DENSE_MVN);
   for (int64_t t = 0; t < T; t++) {
+    if (fused_dense) {
+      const bool md = a.met_ndim == 2, td = a.tkind == AEHMC_T_DENSE_MVN;
+      EngineArgs b = a;
+      b.linear = 0;  // literal products (metrics.py:71)
+      const size_t dyn = (size_t)((md ? 2 : 0) + (td ? 1 : 0)) * D * D * sizeof(double);
+      const dim3 grid((unsigned)((C + FUSED_DENSE_BLOCK / 64 - 1) / (FUSED_DENSE_BLOCK / 64))), block(FUSED_DENSE_BLOCK);
+#define AEHMC_FD_LAUNCH(MDV, TDV)                                                                              \
+  do {                                                                                                         \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_fused_dense<MDV, TDV>),                    \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                         \
+    hipLaunchKernelGGL((k_hmc_fused_dense<MDV, TDV>), grid, block, dyn, st, b, ctx->tgt.prec, (long long)L);    \
+  } while (0)
+      if (md && td) AEHMC_FD_LAUNCH(true, true);
+      else if (md) AEHMC_FD_LAUNCH(true, false);
+      else AEHMC_FD_LAUNCH(false, true);
+#undef AEHMC_FD_LAUNCH
+      HIPCHK(hipGetLastError());
+    } else {
     if (int rc = launch_begin(ctx, a, false, st)) return rc;
     for (int64_t l = 0; l < L; l++)
       if (int rc = launch_leapfrog(ctx, a, false, l == L - 1, st)) return rc;
     if (a.met_ndim == 2) LAUNCH(k_hmc_end<true>, C, st, a, (long long)L);
     else LAUNCH(k_hmc_end<false>, C, st, a, (long long)L);
+    }
     if (samples)
       HIPCHK(hipMemcpyAsync(samples + (size_t)t * C * D, q, (size_t)C * D * sizeof(double),
                             hipMemcpyDeviceToDevice, st));
