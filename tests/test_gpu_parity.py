@@ -721,6 +721,51 @@ def test_hmc_wide_long_sample_with_rejections(eng, D, tk):
     assert 0.1 * C * T < n_acc < 0.95 * C * T  # both branches of the accept decision, many times
 
 
+@pytest.mark.parametrize("sampler", ["nuts", "hmc"])
+@pytest.mark.parametrize("kind,tkind", [("dense", "dense"), ("dense", "diag"), ("dense", "iso"), ("diag", "dense"), ("scalar", "dense")])
+@pytest.mark.parametrize("D", [1, 7, 64])
+def test_small_dense_single_launch_kernels(eng, sampler, kind, tkind, D):
+    """k_nuts_fused_dense / k_hmc_fused_dense (round 3: dense metric and / or dense target, D <= 64, the whole
+    transition in one launch with the products inside the wavefront), one case per compiled variant and sampler at
+    D = 1, 7 and the maximum 64 (three matrices = 96 KB of LDS), 13 chains (a partial workgroup), three
+    transitions: against the oracle (values 1e-9, every discrete output and the generator states exact) and
+    against the lock-step path with its MFMA GEMMs (1e-11: another summation order, same arithmetic otherwise)."""
+    from aehmc_amd import RandomStream, hmc, nuts
+    r = np.random.default_rng(1000 * D + len(kind) * 7 + len(tkind))
+    tgt, otgt, imm = make_case(kind, tkind, D, r)
+    C = 13
+    seeds = [77 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    eps = 0.35 / D ** 0.25
+    mod = nuts if sampler == "nuts" else hmc
+    extra = () if sampler == "nuts" else (9,)
+    metric, rng = co.Metric(imm, D), co.site_states(seeds, 4 if sampler == "nuts" else 2)
+    q, U, g = co.new_state(otgt, q0.copy())
+    finals = []
+    for fused in (1, 0):
+        eng.set_option("resident_nuts", 2 if fused else 0)
+        eng.set_option("fused_hmc", fused)
+        try:
+            srng = RandomStream(seeds=seeds)
+            kernel = mod.new_kernel(srng, tgt) if sampler == "hmc" else mod.new_kernel(srng, tgt, max_num_expansions=7)
+            state = mod.new_state(dev(q0), tgt)
+            for t in range(3):
+                info, upd = kernel(state, eps, imm, *extra)
+                state = info.state._replace(momentum=None)
+                if fused:
+                    res = (co.nuts_step(otgt, metric, rng, eps, q, U, g, max_exp=7) if sampler == "nuts"
+                           else co.hmc_step(otgt, metric, rng, eps, 9, q, U, g))
+                    check_state(info, q, U, g, res, nuts=sampler == "nuts")
+            if fused:
+                assert np.array_equal(upd[srng].cpu().numpy().view(np.uint64).reshape(rng.shape), rng)
+            finals.append((info.state.position.clone(), info.n_leapfrog.clone(), upd[srng].clone()))
+        finally:
+            eng.set_option("resident_nuts", 2)
+            eng.set_option("fused_hmc", 1)
+    np.testing.assert_allclose(finals[0][0].cpu().numpy(), finals[1][0].cpu().numpy(), rtol=1e-11, atol=1e-13)
+    assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+
+
 def test_hmc_fused_equals_lockstep_bitwise(eng):
     """The register-resident single-launch HMC kernel and the generic lock-step path run
     the same arithmetic in the same order."""
