@@ -93,6 +93,9 @@ struct NutsSampleArgs {
   const int *stage, *window_end;  // device arrays [T] (window_adaptation.py:230-327)
   double target, gamma, t0, kappa;
   aehmc_adapt_state ad;
+  // small dense problems (k_nuts_resident's DENSE instantiations)
+  const double *prec;  // the dense target's precision [D, D]
+  double *imm_ws;      // per-chain dense metrics: [C, D, D] workspace for the transposed matrices
 };
 
 // two-entry arrays are picked with a select, never indexed dynamically (a dynamic index
@@ -804,78 +807,100 @@ __global__ __launch_bounds__(256) void k_nuts_fused(EngineArgs a) {
   rng_store(a, c, lane, rng, 0, 3);
 }
 // ---- small dense problems: the whole transition of a chain in ONE launch, mat-vecs inside the wavefront ----------
-// Dense inverse mass matrix and / or dense-precision target with D <= 64 -- the classic full-mass-matrix use.  On the
-// lock-step path a leapfrog of such a problem is four launches around two D x D "GEMMs" and costs ~70 us whatever
-// the chain count (tools/debug/small_dense.py: 1.5 ms per transition at D = 50, 4096 chains).  Here the wavefront
-// that owns the chain loops stages, products and bookkeeping by itself, as k_nuts_fused does for diagonal metrics:
-// the (shared) matrices sit TRANSPOSED in LDS, lane i forms row i of a product with the operand's elements
-// broadcast from registers (v_readlane), k ascending from 0.0 -- the order of the reference's dot products
-// (the restatement's too), one rounding per product and per sum.  Literal dense mode (metrics.py:71: imm p_half and
-// imm p' are formed, 3 products per leapfrog); the chain's vectors are rows of the work arrays (L1 / L2 resident at
-// this size).  Same stage and bookkeeping functions as every other path.
+// Dense inverse mass matrix (shared or per chain) and / or dense-precision target with D <= 64 -- the classic
+// full-mass-matrix use.  On the lock-step path a leapfrog of such a problem is four launches around two D x D "GEMMs"
+// and costs ~70 us whatever the chain count (tools/debug/small_dense.py: 1.5 ms per transition at D = 50, 4096
+// chains).  Here the wavefront that owns the chain keeps position, momentum, gradient and velocity in registers,
+// element i in lane i (NUTS: k_nuts_resident's DENSE instantiations, nuts_resident.cuh; HMC: k_hmc_fused_dense
+// below): the matrices sit TRANSPOSED in LDS, lane i forms row i of a product with the operand's elements broadcast
+// from registers (v_readlane), k ascending from 0.0 -- the order of the reference's dot products (the restatement's
+// too), one rounding per product and per sum.  Literal dense mode (metrics.py:71: imm p_half and imm p' are formed,
+// 3 products per leapfrog).
 constexpr int FUSED_DENSE_MAX_D = 64;
 constexpr int FUSED_DENSE_BLOCK = 512;  // eight chains per workgroup share the matrices
 // y[i] = sum_k M[i][k] x[k] for i < D; MT = M transposed in LDS (MT[k * D + i] = M[i][k]); x, y rows in global memory,
 // element i read and written by lane i only
+// (eight matrix elements are fetched ahead of the eight FMAs that use them: a few wavefronts per SIMD cannot hide a
+// load per dependent FMA; the sum still runs k = 0, 1, 2, ... from 0.0)
+// operand and result in registers: lane k < D holds x[k] (other lanes are never read), lane i < D returns y[i]
+__device__ __forceinline__ double wave_matvec_reg(const double *MT, double xl, int D, int lane) {
+  const double *col = MT + (lane < D ? lane : 0);
+  double acc = 0.0;
+  int k = 0;
+  for (; k + 8 <= D; k += 8) {
+    double m[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) m[u] = col[(k + u) * D];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += m[u] * read_lane_f64(xl, k + u);
+  }
+  for (; k < D; k++) acc += col[k * D] * read_lane_f64(xl, k);
+  return acc;
+}
 __device__ __forceinline__ void wave_matvec_lds(const double *MT, const double *x, double *y, int D, int lane) {
   const bool on = lane < D;
-  const double xl = on ? x[lane] : 0.0;
-  double acc = 0.0;
-  for (int k = 0; k < D; k++) {
-    const double xk = read_lane_f64(xl, k);
-    if (on) acc += MT[k * D + lane] * xk;
-  }
+  const double acc = wave_matvec_reg(MT, on ? x[lane] : 0.0, D, lane);
   if (on) y[lane] = acc;
 }
+// One leapfrog (integrators.py:63-100 with metrics.py:71's literal products) of a D <= 64 chain whose position,
+// momentum and gradient sit in registers, element i in lane i: the arithmetic of leap_stages<1,1,1> with the
+// products above in between, no trip through the work arrays between the stages (a dependent L2 round trip each).
+// Returns the new potential energy; lanes >= D carry don't-care values (never read by the products, masked out
+// of the energy sum).
 template <bool MD, bool TD>
-__global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_nuts_fused_dense(EngineArgs a, const double *prec) {
-  extern __shared__ __attribute__((aligned(16))) double fd_lds[];
-  const int D = (int)a.D, DD = D * D;
-  double *const immT = fd_lds;                          // MD: imm (symmetric up to rounding: transposed literally)
-  double *const smT = fd_lds + (MD ? DD : 0);           // MD: sqrt_mass = L^-T
-  double *const PT = fd_lds + (MD ? 2 * DD : 0);        // TD: the target's precision
-  for (int e = threadIdx.x; e < DD; e += FUSED_DENSE_BLOCK) {
-    const int i = e / D, k = e % D;
-    if (MD) {
-      immT[k * D + i] = a.imm[e];
-      smT[k * D + i] = a.sqrt_mass[e];
-    }
-    if (TD) PT[k * D + i] = prec[e];
+__device__ __forceinline__ double leap_small_dense(const EngineArgs &a, long long c, int lane, int dir,
+                                                   const double *immW, const double *PT, int D, double &q, double &p,
+                                                   double &g) {
+  const double step_size = (dir ? 1.0 : -1.0) * (a.eps_c ? a.eps_c[c] : a.eps);
+  const double b = 0.5 * step_size, aa = 1 * step_size;
+  const bool on = lane < D;
+  const long long il = on ? lane : 0;
+  p = p - b * g;
+  const double v = MD ? wave_matvec_reg(immW, p, D, lane) : vel_diag(a, c, il, p);
+  q = q + aa * v;
+  double u;
+  if (TD) {
+    const double r = q - a.mu[il];
+    g = wave_matvec_reg(PT, r, D, lane);  // dU/dq = P r
+    u = r * g;
+  } else {
+    target_elem(a, il, q, u, g);
   }
-  __syncthreads();
-  AEHMC_CHAIN_OF_WAVE();
-  const size_t row = (size_t)c * a.D;
-  ChainRng rng = rng_load(a, c);
-  ChainCtl ct;
-  draw_momentum<MD>(a, c, lane, rng.g[0]);  // MD: z -> zbuf; otherwise sqrt(1/imm) o z -> cur_p
-  if (MD) {
-    wave_matvec_lds(smT, a.zbuf + row, a.cur_p + row, D, lane);    // p = L^-T z (metrics.py:66-67)
-    wave_matvec_lds(immT, a.cur_p + row, a.cur_v + row, D, lane);  // v = imm p
-  }
-  nuts_init_chain<MD>(a, c, lane, ct, rng);
-  while (!ct.done) {
-    double U_new = 0.0;
-    if (MD) {
-      leap_stages<true, false, false, true>(a, c, lane, ct.dir, U_new);            // p_half
-      wave_matvec_lds(immT, a.cur_p + row, a.vhalf + row, D, lane);                // imm p_half
-      if (TD) {
-        leap_stages<false, true, false, true>(a, c, lane, ct.dir, U_new);          // q', r = q' - mu
-        wave_matvec_lds(PT, a.rbuf + row, a.cur_g + row, D, lane);                 // dU/dq = P r
-        if (leap_stages<false, false, true, true>(a, c, lane, ct.dir, U_new)) ct.U_cur = U_new;  // U, p'
-      } else {
-        if (leap_stages<false, true, true, true>(a, c, lane, ct.dir, U_new)) ct.U_cur = U_new;   // q', target, p'
-      }
-      wave_matvec_lds(immT, a.cur_p + row, a.cur_v + row, D, lane);                // imm p'
-    } else {  // diagonal / scalar metric, dense target
-      leap_stages<true, true, false, false>(a, c, lane, ct.dir, U_new);
-      wave_matvec_lds(PT, a.rbuf + row, a.cur_g + row, D, lane);
-      if (leap_stages<false, false, true, false>(a, c, lane, ct.dir, U_new)) ct.U_cur = U_new;
-    }
-    nuts_book<MD>(a, c, lane, ct, rng);
-  }
-  rng_store(a, c, lane, rng, 0, 3);
+  p = p - b * g;
+  return target_finish(a, wave_sum(on ? u : 0.0));
 }
-
+// the same product with the chain's OWN row-major matrix in global memory (per-chain dense metrics, what
+// is_mass_matrix_full adaptation produces): lane i walks row i, a 8 D byte stride between lanes -- used once per
+// transition (the momentum draw's L^-T z); the two products per leapfrog read a transposed copy instead
+__device__ __forceinline__ double wave_matvec_rows_reg(const double *M, double xl, int D, int lane) {
+  const double *mrow = M + (size_t)(lane < D ? lane : 0) * D;
+  double acc = 0.0;
+  int k = 0;
+  for (; k + 8 <= D; k += 8) {
+    double m[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) m[u] = mrow[k + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += m[u] * read_lane_f64(xl, k + u);
+  }
+  for (; k < D; k++) acc += mrow[k] * read_lane_f64(xl, k);
+  return acc;
+}
+__device__ __forceinline__ void wave_matvec_rows(const double *M, const double *x, double *y, int D, int lane) {
+  const bool on = lane < D;
+  const double acc = wave_matvec_rows_reg(M, on ? x[lane] : 0.0, D, lane);
+  if (on) y[lane] = acc;
+}
+// per-chain metric: the wavefront writes the literal transpose of its chain's inverse mass matrix to workspace
+// once per transition, so that the 2 products per leapfrog read D contiguous doubles per k (same values, same
+// k-ascending sums as the rows; the strided walk above costs 16x the cache lines)
+__device__ __forceinline__ void wave_transpose_to(const double *M, double *MT, int D, int lane) {
+  for (int e = lane; e < D * D; e += 64) {
+    const int i = e / D, k = e % D;
+    MT[k * D + i] = M[e];
+  }
+  __threadfence();  // other lanes of this wavefront read what this lane wrote
+}
 // MODE: stage set; BOOK: run the NUTS bookkeeping afterwards
 template <bool DO1, bool DO2, bool DO3, bool MET_DENSE, bool BOOK>
 __global__ __launch_bounds__(256) void k_step(EngineArgs a) {
@@ -1049,16 +1074,17 @@ __global__ __launch_bounds__(256) void k_hmc_end(EngineArgs a, long long L) {
   const ChainCtl ct = a.ctl[c];
   hmc_end_chain<MET_DENSE>(a, c, lane, ct, L);
 }
-// The HMC transition of a small dense problem in one launch (see k_nuts_fused_dense: same matrices in LDS, same
+// The HMC transition of a small dense problem in one launch (see above: same matrices in LDS, same
 // in-wavefront products, literal dense mode); the chain's scalars stay in registers between the stages.
-template <bool MD, bool TD>
-__global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArgs a, const double *prec, long long L) {
+template <bool MD, bool TD, bool PC = false>
+__global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArgs a, const double *prec, double *imm_ws, long long L) {
   extern __shared__ __attribute__((aligned(16))) double fd_lds[];
   const int D = (int)a.D, DD = D * D;
-  double *const immT = fd_lds, *const smT = fd_lds + (MD ? DD : 0), *const PT = fd_lds + (MD ? 2 * DD : 0);
+  constexpr bool MLDS = MD && !PC;
+  double *const immT = fd_lds, *const smT = fd_lds + (MLDS ? DD : 0), *const PT = fd_lds + (MLDS ? 2 * DD : 0);
   for (int e = threadIdx.x; e < DD; e += FUSED_DENSE_BLOCK) {
     const int i = e / D, k = e % D;
-    if (MD) {
+    if (MLDS) {
       immT[k * D + i] = a.imm[e];
       smT[k * D + i] = a.sqrt_mass[e];
     }
@@ -1067,34 +1093,32 @@ __global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArg
   __syncthreads();
   AEHMC_CHAIN_OF_WAVE();
   const size_t row = (size_t)c * a.D;
+  const double *const immW = PC ? imm_ws + (size_t)c * DD : immT;  // PC: this chain's transposed copy (global)
+  if (PC) wave_transpose_to(a.imm + (size_t)c * DD, imm_ws + (size_t)c * DD, D, lane);
   {
     Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4);
     draw_momentum<MD>(a, c, lane, g1);
     if (lane == 0) pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
   }
   if (MD) {
-    wave_matvec_lds(smT, a.zbuf + row, a.cur_p + row, D, lane);
-    wave_matvec_lds(immT, a.cur_p + row, a.cur_v + row, D, lane);
+    if (PC) wave_matvec_rows(a.sqrt_mass + (size_t)c * DD, a.zbuf + row, a.cur_p + row, D, lane);
+    else wave_matvec_lds(smT, a.zbuf + row, a.cur_p + row, D, lane);
+    wave_matvec_lds(immW, a.cur_p + row, a.cur_v + row, D, lane);
   }
   ChainCtl ct = hmc_init_chain<MD>(a, c, lane);
-  for (long long l = 0; l < L; l++) {  // trajectory.py:86-95
-    double U_new = 0.0;
-    if (MD) {
-      leap_stages<true, false, false, true>(a, c, lane, 1, U_new);
-      wave_matvec_lds(immT, a.cur_p + row, a.vhalf + row, D, lane);
-      if (TD) {
-        leap_stages<false, true, false, true>(a, c, lane, 1, U_new);
-        wave_matvec_lds(PT, a.rbuf + row, a.cur_g + row, D, lane);
-        if (leap_stages<false, false, true, true>(a, c, lane, 1, U_new)) ct.U_cur = U_new;
-      } else {
-        if (leap_stages<false, true, true, true>(a, c, lane, 1, U_new)) ct.U_cur = U_new;
-      }
-      if (l == L - 1) wave_matvec_lds(immT, a.cur_p + row, a.cur_v + row, D, lane);  // for the final kinetic energy
-    } else {
-      leap_stages<true, true, false, false>(a, c, lane, 1, U_new);
-      wave_matvec_lds(PT, a.rbuf + row, a.cur_g + row, D, lane);
-      if (leap_stages<false, false, true, false>(a, c, lane, 1, U_new)) ct.U_cur = U_new;
-    }
+  const bool on = lane < D;
+  const size_t el = row + (on ? lane : 0);
+  double q = a.cur_q[el], p = a.cur_p[el], g = a.cur_g[el];
+  for (long long l = 0; l < L; l++)  // trajectory.py:86-95: the whole trajectory in registers
+    ct.U_cur = leap_small_dense<MD, TD>(a, c, lane, 1, immW, PT, D, q, p, g);
+  if (on) {
+    a.cur_q[el] = q;
+    a.cur_p[el] = p;
+    a.cur_g[el] = g;
+  }
+  if (MD && L > 0) {
+    const double v = wave_matvec_reg(immW, p, D, lane);  // for the final kinetic energy
+    if (on) a.cur_v[el] = v;
   }
   hmc_end_chain<MD>(a, c, lane, ct, L);
 }

@@ -71,6 +71,8 @@ struct aehmc_ctx {
   int64_t d_sched_n = 0;
   double *pc_work = nullptr;  // scratch of aehmc_metric_sqrt_per_chain above D = 64 (kept, grown on demand)
   size_t pc_work_bytes = 0;
+  double *fd_ws = nullptr;  // small-dense kernels, per-chain metrics: the chains' transposed matrices (kept, grown)
+  size_t fd_ws_bytes = 0;
 };
 
 #define HIPCHK(expr)                                                                     \
@@ -164,6 +166,7 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->d_sched) (void)hipFree(ctx->d_sched);
   if (ctx->pc_work) (void)hipFree(ctx->pc_work);
+  if (ctx->fd_ws) (void)hipFree(ctx->fd_ws);
   for (int i = 0; i < NRING; i++)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -781,6 +784,18 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
 // which kernel family a NUTS call takes (one place: aehmc_nuts_warmup asks before it commits to a
 // single-launch warm-up)
 enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE, NUTS_PATH_FUSED_DENSE };
+// workspace of the small-dense kernels with per-chain metrics (hipFree waits for earlier launches that use it)
+static int fused_dense_workspace(aehmc_ctx *ctx, size_t need, double **out) {
+  if (ctx->fd_ws_bytes < need) {
+    if (ctx->fd_ws) HIPCHK(hipFree(ctx->fd_ws));
+    ctx->fd_ws = nullptr;
+    ctx->fd_ws_bytes = 0;
+    HIPCHK(hipMalloc((void **)&ctx->fd_ws, need));
+    ctx->fd_ws_bytes = need;
+  }
+  *out = ctx->fd_ws;
+  return 0;
+}
 static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions) {
   const int tkind = ctx->tgt.kind, nd = ctx->met.ndim;
   const int64_t D = ctx->tgt.D;
@@ -793,10 +808,10 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   if (want_resident && nuts_resident_supported(tkind, nd, D)) return NUTS_PATH_TEAMS;  // D <= 512
   if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
-  // inside the wavefront (k_nuts_fused_dense)
-  if (want_resident && D <= FUSED_DENSE_MAX_D && !ctx->met.per_chain && (nd == 2 || tkind == AEHMC_T_DENSE_MVN) &&
+  // inside the wavefront (k_nuts_resident's DENSE instantiations)
+  if (want_resident && D <= FUSED_DENSE_MAX_D && (nd == 2 || tkind == AEHMC_T_DENSE_MVN) &&
       (target_is_elem_host(tkind) || tkind == AEHMC_T_DENSE_MVN))
-    return NUTS_PATH_FUSED_DENSE;
+    return NUTS_PATH_FUSED_DENSE;  // (per-chain dense metrics included: each wavefront reads its own matrices)
   return NUTS_PATH_LOCKSTEP;
 }
 
@@ -850,24 +865,21 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     }
     return prof_end(ctx, st, p);
   }
-  if (path == NUTS_PATH_FUSED_DENSE) {
-    const bool md = a.met_ndim == 2, td = a.tkind == AEHMC_T_DENSE_MVN;
+  if (path == NUTS_PATH_FUSED_DENSE) {  // small dense problems: k_nuts_resident's DENSE instantiations
+    const bool md = a.met_ndim == 2, td = a.tkind == AEHMC_T_DENSE_MVN, pc = md && ctx->met.per_chain;
     a.linear = 0;  // literal products (metrics.py:71)
-    const size_t dyn = (size_t)((md ? 2 : 0) + (td ? 1 : 0)) * a.D * a.D * sizeof(double);
-    const dim3 grid((unsigned)((C + FUSED_DENSE_BLOCK / 64 - 1) / (FUSED_DENSE_BLOCK / 64))), block(FUSED_DENSE_BLOCK);
+    NutsSampleArgs m{};
+    m.T = 1;
+    if (multi && multi_done && !multi->adapt) {
+      m = *multi;
+      *multi_done = true;
+    }
+    m.prec = ctx->tgt.prec;
+    if (pc)
+      if (int rc = fused_dense_workspace(ctx, (size_t)C * a.D * a.D * sizeof(double), &m.imm_ws)) return rc;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-#define AEHMC_FD_LAUNCH(MDV, TDV)                                                                              \
-  do {                                                                                                         \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_fused_dense<MDV, TDV>),                   \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                         \
-    hipLaunchKernelGGL((k_nuts_fused_dense<MDV, TDV>), grid, block, dyn, st, a, ctx->tgt.prec);                 \
-  } while (0)
-    if (md && td) AEHMC_FD_LAUNCH(true, true);
-    else if (md) AEHMC_FD_LAUNCH(true, false);
-    else AEHMC_FD_LAUNCH(false, true);
-#undef AEHMC_FD_LAUNCH
-    HIPCHK(hipGetLastError());
+    HIPCHK(launch_nuts_resident_dense(a, m, st, md, td, pc));
     return prof_end(ctx, st, p);
   }
   if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
@@ -1124,25 +1136,30 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   a.q = q; a.U = U; a.g = g; a.out = *out;
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): the transition in one
   // launch with the products inside the wavefront (k_hmc_fused_dense), as for NUTS
-  const bool fused_dense = ctx->opt_fused_hmc && D <= FUSED_DENSE_MAX_D && !ctx->met.per_chain &&
+  const bool fused_dense = ctx->opt_fused_hmc && D <= FUSED_DENSE_MAX_D &&
                            (a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN) &&
                            (target_is_elem_host(a.tkind) || a.tkind == AEHMC_T_DENSE_MVN);
   for (int64_t t = 0; t < T; t++) {
     if (fused_dense) {
-      const bool md = a.met_ndim == 2, td = a.tkind == AEHMC_T_DENSE_MVN;
+      const bool md = a.met_ndim == 2, td = a.tkind == AEHMC_T_DENSE_MVN, pc = md && ctx->met.per_chain;
       EngineArgs b = a;
       b.linear = 0;  // literal products (metrics.py:71)
-      const size_t dyn = (size_t)((md ? 2 : 0) + (td ? 1 : 0)) * D * D * sizeof(double);
+      const size_t dyn = (size_t)((md && !pc ? 2 : 0) + (td ? 1 : 0)) * D * D * sizeof(double);
+      double *imm_ws = nullptr;
+      if (pc)
+        if (int rc = fused_dense_workspace(ctx, (size_t)C * D * D * sizeof(double), &imm_ws)) return rc;
       const dim3 grid((unsigned)((C + FUSED_DENSE_BLOCK / 64 - 1) / (FUSED_DENSE_BLOCK / 64))), block(FUSED_DENSE_BLOCK);
-#define AEHMC_FD_LAUNCH(MDV, TDV)                                                                              \
+#define AEHMC_FD_LAUNCH(MDV, TDV, PCV)                                                                         \
   do {                                                                                                         \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_fused_dense<MDV, TDV>),                    \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_fused_dense<MDV, TDV, PCV>),               \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                         \
-    hipLaunchKernelGGL((k_hmc_fused_dense<MDV, TDV>), grid, block, dyn, st, b, ctx->tgt.prec, (long long)L);    \
+    hipLaunchKernelGGL((k_hmc_fused_dense<MDV, TDV, PCV>), grid, block, dyn, st, b, ctx->tgt.prec, imm_ws, (long long)L); \
   } while (0)
-      if (md && td) AEHMC_FD_LAUNCH(true, true);
-      else if (md) AEHMC_FD_LAUNCH(true, false);
-      else AEHMC_FD_LAUNCH(false, true);
+      if (md && td && pc) AEHMC_FD_LAUNCH(true, true, true);
+      else if (md && td) AEHMC_FD_LAUNCH(true, true, false);
+      else if (md && pc) AEHMC_FD_LAUNCH(true, false, true);
+      else if (md) AEHMC_FD_LAUNCH(true, false, false);
+      else AEHMC_FD_LAUNCH(false, true, false);
 #undef AEHMC_FD_LAUNCH
       HIPCHK(hipGetLastError());
     } else {

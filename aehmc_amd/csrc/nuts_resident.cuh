@@ -20,6 +20,11 @@
 //
 // Diagonal / scalar metric (shared or per chain), coordinate-wise targets.  Arithmetic and
 // its order are those of the lock-step path in engine.cuh (for T = 64 bit for bit, tested);
+// DENSE instantiations (T = 64, one element per lane, D <= 64: "small dense problems", the classic full-mass-matrix
+// use) add a dense inverse mass matrix (shared, or one per chain) and / or the dense-precision target: the D x D
+// products of metrics.py:66-71 run inside the wavefront (wave_matvec_reg: matrix transposed in LDS -- or, per
+// chain, in a workspace written once per transition -- operand broadcast from registers), the velocity imm p
+// lives in a register beside p and is checkpointed with it as the lock-step path does (ckv / end_v);
 // reference: nuts.py:56-153, trajectory.py:154-374,428-714, termination.py:85-235,
 // proposals.py:19-174, integrators.py:54-73, metrics.py:44-104.
 #pragma once
@@ -37,6 +42,9 @@ struct Team {
   static constexpr bool WAVE = (T == 64);  // one wavefront per chain
   static constexpr int BLOCK = 256;
 };
+// DENSE bits of k_nuts_resident
+constexpr int RES_DENSE_METRIC = 1, RES_DENSE_TARGET = 2, RES_DENSE_PER_CHAIN = 4;
+constexpr int RES_DENSE_BLOCK = 512;  // eight chains share the matrices in LDS (up to 96 KB at D = 64)
 
 // butterfly sum over the T (< 64) consecutive lanes of a sub-wavefront team
 template <int T>
@@ -73,14 +81,39 @@ __device__ __forceinline__ void team_sum2(double &x, double &y, bool single = fa
 // MULTI: the launch runs m.T > 1 transitions (the RNG state, the leapfrog total ... stay live across
 // the tree loop, which costs ~35 VGPRs and a wavefront per SIMD: single transitions keep their own
 // instantiation).
-template <int T, int R, bool MULTI>
-__global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, NutsSampleArgs m) {
+template <int T, int R, bool MULTI, int DENSE = 0>
+__global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK) void k_nuts_resident(EngineArgs a,
+                                                                                            NutsSampleArgs m) {
   using TM = Team<T>;
+  static_assert(DENSE == 0 || (T == 64 && R == 1), "dense products: one wavefront per chain, one element per lane");
+  constexpr bool MD = (DENSE & RES_DENSE_METRIC) != 0, TD = (DENSE & RES_DENSE_TARGET) != 0;
+  constexpr bool PC = (DENSE & RES_DENSE_PER_CHAIN) != 0, MLDS = MD && !PC;
+  constexpr int BLOCK = DENSE ? RES_DENSE_BLOCK : TM::BLOCK;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long c = TM::SUB ? ((long long)blockIdx.x * 256 + threadIdx.x) / T : (long long)blockIdx.x * 4 + wave;
+  const long long c = TM::SUB ? ((long long)blockIdx.x * 256 + threadIdx.x) / T : (long long)blockIdx.x * (BLOCK / 64) + wave;
   const int t = TM::SUB ? (int)(threadIdx.x % T) : lane;
+  // DENSE: the shared matrices, transposed, in LDS (immT: the inverse mass matrix, smT: L^-T, PT: the precision)
+  extern __shared__ __attribute__((aligned(16))) double res_lds[];
+  const int Dd = (int)a.D, DD = Dd * Dd;
+  const double *immW = res_lds, *const smT = res_lds + (MLDS ? DD : 0), *const PT = res_lds + (MLDS ? 2 * DD : 0);
+  if (DENSE) {
+    for (int e = threadIdx.x; e < DD; e += BLOCK) {
+      const int i = e / Dd, k = e % Dd;
+      if (MLDS) {
+        res_lds[k * Dd + i] = a.imm[e];
+        res_lds[DD + k * Dd + i] = a.sqrt_mass[e];
+      }
+      if (TD) res_lds[(MLDS ? 2 * DD : 0) + k * Dd + i] = m.prec[e];
+    }
+    __syncthreads();
+  }
   if (c >= a.C) return;  // a whole team leaves together
+  if (PC) {  // this chain's transposed inverse mass matrix (workspace; rewritten when the metric may have changed)
+    wave_transpose_to(a.imm + (size_t)c * DD, m.imm_ws + (size_t)c * DD, Dd, lane);
+    immW = m.imm_ws + (size_t)c * DD;
+  }
+  double v0 = 0.0;  // MD: the moving end's velocity imm p (element `lane`)
   const size_t row = (size_t)c * a.D;
   const bool lead = t == 0;
   const bool single = T == 64 && a.D == 1;  // (wave-uniform: a kernel argument)
@@ -111,7 +144,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
   for (int r = 0; r < R; r++) {
     const long long i = (long long)t + (long long)T * r;
     ok[r] = i < a.D;
-    if (IM_REG) imr[r] = ok[r] ? a.imm[imo + (a.met_ndim == 0 ? 0 : i)] : 1.0;
+    if (IM_REG) imr[r] = (ok[r] && !MD) ? a.imm[imo + (a.met_ndim == 0 ? 0 : i)] : 1.0;
   }
   rng = rng_load(a, c);
   double U_state = MULTI ? a.U[c] : 0.0;  // the chain's potential energy between transitions
@@ -161,7 +194,8 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
       const double *sm = a.sqrt_mass + imo;
       const bool scalar = a.met_ndim == 0;
       double *dst = a.zbuf;
-      wave_normals(rng.g[0], a.D, [=](long long i, double z) { dst[row + i] = (scalar ? sm[0] : sm[i]) * z; });
+      if (MD) wave_normals(rng.g[0], a.D, [=](long long i, double z) { dst[row + i] = z; });  // p = L^-T z below
+      else wave_normals(rng.g[0], a.D, [=](long long i, double z) { dst[row + i] = (scalar ? sm[0] : sm[i]) * z; });
       if (!MULTI && lead) pcg_store(a.rng + (size_t)c * a.nsites * 4, rng.g[0]);
     }
     __threadfence_block();
@@ -169,17 +203,24 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
 
   // ---- nuts.py:113-125 ----------------------------------------------------------------
   kd = 0.0;
+  if (MD) {  // metrics.py:66-67 and :71
+    const double z = ok[0] ? AT(a.zbuf, 0) : 0.0;
+    p[0] = PC ? wave_matvec_rows_reg(a.sqrt_mass + (size_t)c * DD, z, Dd, lane) : wave_matvec_reg(smT, z, Dd, lane);
+    if (!ok[0]) p[0] = 0.0;
+    v0 = wave_matvec_reg(immW, p[0], Dd, lane);
+  }
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    if (!TM::SUB) p[r] = ok[r] ? AT(a.zbuf, r) : 0.0;
+    if (!TM::SUB && !MD) p[r] = ok[r] ? AT(a.zbuf, r) : 0.0;
     pb[r] = 0.0;
     if (ok[r]) {
-      kd += (IMM(r) * p[r]) * p[r];
+      kd += MD ? v0 * p[r] : (IMM(r) * p[r]) * p[r];
 #pragma unroll
       for (int e = 0; e < 2; e++) {
         AT(a.end_q[e], r) = QGET(r);
         AT(a.end_p[e], r) = p[r];
         AT(a.end_g[e], r) = GGET(r);
+        if (MD) AT(a.end_v[e], r) = v0;
       }
       AT(a.slot_q[0], r) = QGET(r);
       AT(a.slot_p[0], r) = p[r];
@@ -216,7 +257,15 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
     const double b = 0.5 * step_size, aa = 1 * step_size;
     double usum = 0.0;
     kd = 0.0;
-    {
+    if (DENSE) {  // products between the stages: engine.cuh's leap_small_dense
+      double qq = QGET(0), gg = GGET(0);
+      ct.U_cur = leap_small_dense<MD, TD>(a, c, lane, ct.dir, immW, PT, Dd, qq, p[0], gg);
+      QSET(0, qq);
+      GSET(0, gg);
+      if (MD) v0 = wave_matvec_reg(immW, p[0], Dd, lane);  // imm p'
+      kd = ok[0] ? (MD ? v0 * p[0] : (IMM(0) * p[0]) * p[0]) : 0.0;
+      kd = wave_sum(kd);
+    } else {
       // (global operands -- imm when it is not in registers -- are fetched BR elements at a
       // time: one round trip per batch instead of one per element)
 #pragma unroll
@@ -270,6 +319,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
           if (even) {
             ckp[EI(r)] = p[r];
             cks[EI(r)] = pb[r];
+            if (MD) (a.ckv + ((size_t)tmax * a.C + c) * a.D)[EI(r)] = v0;
           }
         }
         R_FENCE();
@@ -314,6 +364,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
         for (;;) {
           const double *kp = a.ckp + ((size_t)idx * a.C + c) * a.D;
           const double *ks = a.cks + ((size_t)idx * a.C + c) * a.D;
+          const double *kv = a.ckv + ((size_t)idx * a.C + c) * a.D;  // (MD)
           double d_l = 0.0, d_r = 0.0;
 #pragma unroll
           for (int r0 = 0; r0 < R; r0 += BR) {
@@ -324,14 +375,14 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
               const bool on = r0 + u < R && ok[r];
               kpv[u] = on ? kp[EI(r)] : 0.0;
               ksv[u] = on ? ks[EI(r)] : 0.0;
-              imv[u] = on ? IMM(r) : 0.0;
+              imv[u] = on ? (MD ? kv[EI(r)] : IMM(r)) : 0.0;  // MD: the checkpoint's velocity itself
             }
 #pragma unroll
             for (int u = 0; u < BR; u++) {
               const int r = r0 + u < R ? r0 + u : 0;
               if (r0 + u < R && ok[r]) {
                 double pl = kpv[u], pr = p[r];
-                double vl = imv[u] * pl, vr = imv[u] * pr;
+                double vl = MD ? imv[u] : imv[u] * pl, vr = MD ? v0 : imv[u] * pr;
                 double sub = pb[r] - ksv[u] + pl;
                 double rho = sub - (pr + pl) / 2;
                 d_l += vl * rho;
@@ -390,14 +441,14 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
           const bool on = r0 + u < R && ok[r];
           pov[u] = on ? AT(pick2(a.end_p, oth), r) : 0.0;
           psv[u] = on ? AT(a.psum, r) : 0.0;
-          imv[u] = on ? IMM(r) : 0.0;
+          imv[u] = on ? (MD ? AT(pick2(a.end_v, oth), r) : IMM(r)) : 0.0;  // MD: the other end's velocity
         }
 #pragma unroll
         for (int u = 0; u < BR; u++) {
         const int r = r0 + u < R ? r0 + u : 0;
         if (r0 + u < R && ok[r]) {
           double pc = p[r], po = pov[u];
-          double vc = imv[u] * pc, vo = imv[u] * po;
+          double vc = MD ? v0 : imv[u] * pc, vo = MD ? imv[u] : imv[u] * po;
           double s = psv[u] + pb[r];
           AT(a.psum, r) = s;
           double pl = dir ? po : pc, pr = dir ? pc : po;
@@ -408,6 +459,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
           AT(pick2(a.end_q, dir), r) = QGET(r);
           AT(pick2(a.end_p, dir), r) = pc;
           AT(pick2(a.end_g, dir), r) = GGET(r);
+          if (MD) AT(pick2(a.end_v, dir), r) = vc;
         }
         }
         R_FENCE();
@@ -470,6 +522,7 @@ __global__ __launch_bounds__(Team<T>::BLOCK) void k_nuts_resident(EngineArgs a, 
               QSET(r, AT(pick2(a.end_q, go_right), r));
               p[r] = AT(pick2(a.end_p, go_right), r);
               GSET(r, AT(pick2(a.end_g, go_right), r));
+              if (MD) v0 = AT(pick2(a.end_v, go_right), r);
             }
           }
           ct.U_cur = pick2(ct.U_end, go_right);
@@ -553,6 +606,41 @@ inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
   // teams of 1 .. 64 lanes up to D = 512; larger chains take one workgroup each (nuts_wide.cuh)
   return (tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN) &&
          met_ndim < 2 && D <= 512;
+}
+
+inline bool nuts_resident_dense_supported(int tkind, int met_ndim, long long D) {
+  const bool elem = tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN;
+  return D <= 64 && (met_ndim == 2 || tkind == AEHMC_T_DENSE_MVN) && (elem || tkind == AEHMC_T_DENSE_MVN);
+}
+template <int DENSE>
+inline hipError_t launch_nuts_resident_dense_v(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
+  constexpr int nmat = ((DENSE & RES_DENSE_METRIC) && !(DENSE & RES_DENSE_PER_CHAIN) ? 2 : 0) +
+                       ((DENSE & RES_DENSE_TARGET) ? 1 : 0);
+  const size_t dyn = (size_t)nmat * a.D * a.D * sizeof(double);
+  const unsigned grid = (unsigned)((a.C + RES_DENSE_BLOCK / 64 - 1) / (RES_DENSE_BLOCK / 64));
+  const bool multi = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total;
+  if (m.adapt) return hipErrorInvalidValue;  // (the in-launch adaptation is the diagonal one)
+#define AEHMC_RD(MULTI)                                                                                      \
+  do {                                                                                                       \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<64, 1, MULTI, DENSE>), \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                \
+    if (e != hipSuccess) return e;                                                                           \
+    hipLaunchKernelGGL((k_nuts_resident<64, 1, MULTI, DENSE>), dim3(grid), dim3(RES_DENSE_BLOCK), dyn, st, a, m); \
+  } while (0)
+  if (multi) AEHMC_RD(true);
+  else AEHMC_RD(false);
+#undef AEHMC_RD
+  return hipGetLastError();
+}
+// md / td: dense metric / dense-precision target; pc: one dense metric per chain (m.imm_ws: [C, D, D] workspace)
+inline hipError_t launch_nuts_resident_dense(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st, bool md,
+                                             bool td, bool pc) {
+  if (md && td && pc) return launch_nuts_resident_dense_v<7>(a, m, st);
+  if (md && td) return launch_nuts_resident_dense_v<3>(a, m, st);
+  if (md && pc) return launch_nuts_resident_dense_v<5>(a, m, st);
+  if (md) return launch_nuts_resident_dense_v<1>(a, m, st);
+  if (td) return launch_nuts_resident_dense_v<2>(a, m, st);
+  return hipErrorInvalidValue;
 }
 
 template <int T, int R>

@@ -172,10 +172,16 @@ def test_metric_sqrt_per_chain_matches_numpy():
 
 
 @pytest.mark.parametrize("kind", ["nuts", "hmc"])
-@pytest.mark.parametrize("linear,D", [(1, 5), (0, 5), (1, 64), (1, 65), (0, 150)])
-def test_per_chain_dense_metric_matches_oracle(kind, linear, D):
+@pytest.mark.parametrize("linear,D,tk,mk", [(1, 5, "diag", "dense"), (0, 5, "diag", "dense"), (1, 64, "diag", "dense"),
+                                            (1, 65, "diag", "dense"), (0, 150, "diag", "dense"),
+                                            (1, 9, "dense", "dense"), (1, 64, "dense", "dense"),
+                                            (1, 9, "dense", "diag"), (1, 70, "dense", "dense")])
+def test_per_chain_dense_metric_matches_oracle(kind, linear, D, tk, mk):
     """Every chain with its own dense inverse mass matrix (per-chain mat-vecs instead of the
-    chain-batched GEMM): chain c equals the oracle run with matrix c."""
+    chain-batched GEMM): chain c equals the oracle run with matrix c.  D <= 64 runs in the small-dense
+    single-launch kernels (each wavefront reads its chain's matrices, round 3), above that lock-step; the
+    dense-target rows cover the kernels' <metric, target, per-chain> variants and per-chain DIAGONAL metrics
+    on a dense target."""
     from aehmc_amd import PerChain, RandomStream, hmc, nuts, targets
     from aehmc_amd.engine import get_engine
     eng = get_engine()
@@ -184,10 +190,19 @@ def test_per_chain_dense_metric_matches_oracle(kind, linear, D):
         r = np.random.default_rng(21)
         C = 6
         mu, sigma = r.normal(size=D), 0.5 + r.random(D)
-        tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
-        A = r.normal(size=(C, D, D))
-        imm = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D)
-        imm = 0.5 * (imm + imm.transpose(0, 2, 1))
+        if tk == "dense":
+            B = r.normal(size=(D, D))
+            prec = np.linalg.inv(B @ B.T / D + np.eye(D))
+            prec = 0.5 * (prec + prec.T)
+            tgt, otgt = targets.DenseMVN(mu, prec), co.Target(co.T_DENSE_MVN, D, mu=mu, prec=prec)
+        else:
+            tgt, otgt = targets.DiagGaussian(mu, sigma), co.Target(co.T_DIAG_GAUSSIAN, D, mu=mu, sigma=sigma)
+        if mk == "dense":
+            A = r.normal(size=(C, D, D))
+            imm = A @ A.transpose(0, 2, 1) / D + 0.3 * np.eye(D)
+            imm = 0.5 * (imm + imm.transpose(0, 2, 1))
+        else:
+            imm = 0.5 + r.random((C, D))
         eps = 0.3 * (0.5 + r.random(C)) * (5 / D) ** 0.25
         seeds = [70 + c for c in range(C)]
         q0 = r.normal(size=(C, D))

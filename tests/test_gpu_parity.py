@@ -725,7 +725,7 @@ def test_hmc_wide_long_sample_with_rejections(eng, D, tk):
 @pytest.mark.parametrize("kind,tkind", [("dense", "dense"), ("dense", "diag"), ("dense", "iso"), ("diag", "dense"), ("scalar", "dense")])
 @pytest.mark.parametrize("D", [1, 7, 64])
 def test_small_dense_single_launch_kernels(eng, sampler, kind, tkind, D):
-    """k_nuts_fused_dense / k_hmc_fused_dense (round 3: dense metric and / or dense target, D <= 64, the whole
+    """k_nuts_resident<64,1,.,DENSE> / k_hmc_fused_dense (round 3: dense metric and / or dense target, D <= 64, the whole
     transition in one launch with the products inside the wavefront), one case per compiled variant and sampler at
     D = 1, 7 and the maximum 64 (three matrices = 96 KB of LDS), 13 chains (a partial workgroup), three
     transitions: against the oracle (values 1e-9, every discrete output and the generator states exact) and
@@ -764,6 +764,50 @@ def test_small_dense_single_launch_kernels(eng, sampler, kind, tkind, D):
             eng.set_option("fused_hmc", 1)
     np.testing.assert_allclose(finals[0][0].cpu().numpy(), finals[1][0].cpu().numpy(), rtol=1e-11, atol=1e-13)
     assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+
+
+@pytest.mark.parametrize("sampler", ["nuts", "hmc"])
+@pytest.mark.parametrize("per_chain", [False, True])
+@pytest.mark.parametrize("tkind,D", [("dense", 11), ("diag", 64), ("dense", 64)])
+def test_small_dense_sample_equals_single_calls(eng, sampler, per_chain, tkind, D):
+    """kernel.sample(T) of a small dense problem (NUTS: all T transitions inside one launch of the MULTI instantiation,
+    generator states in registers in between) returns bit for bit what T single calls return -- positions, histories,
+    the last transition's diagnostics and the generator states; shared and per-chain dense matrices."""
+    from aehmc_amd import PerChain, RandomStream, hmc, nuts
+    r = np.random.default_rng(31 * D + len(tkind))
+    tgt, _, imm = make_case("dense", tkind, D, r)
+    C, T = 11, 6
+    if per_chain:
+        A = r.normal(size=(C, D, D))
+        imm = A @ A.transpose(0, 2, 1) / D + 0.5 * np.eye(D)
+        imm = PerChain(dev(0.5 * (imm + imm.transpose(0, 2, 1))))
+        eps = PerChain(dev(0.4 / D ** 0.25 * (0.5 + r.random(C))))
+    else:
+        eps = 0.4 / D ** 0.25
+    seeds = [900 + c for c in range(C)]
+    q0 = r.normal(size=(C, D))
+    mod = nuts if sampler == "nuts" else hmc
+    extra = () if sampler == "nuts" else (5,)
+    s1, s2 = RandomStream(seeds=seeds), RandomStream(seeds=seeds)
+    k1, k2 = mod.new_kernel(s1, tgt), mod.new_kernel(s2, tgt)
+    samples, info, acc, div = k1.sample(mod.new_state(dev(q0), tgt), eps, imm, *extra, T)
+    state = mod.new_state(dev(q0), tgt)
+    nleap = 0
+    for t in range(T):
+        i2, upd = k2(state, eps, imm, *extra)
+        state = i2.state._replace(momentum=None)
+        nleap = nleap + i2.n_leapfrog
+        assert torch.equal(samples[t], i2.state.position), t
+        assert torch.equal(acc[t], i2.acceptance_probability), t
+        assert torch.equal(div[t].bool(), i2.is_diverging.bool()), t
+    assert torch.equal(info.state.potential_energy, i2.state.potential_energy)
+    assert torch.equal(info.state.potential_energy_grad, i2.state.potential_energy_grad)
+    assert torch.equal(info.state.momentum, i2.state.momentum)
+    if sampler == "nuts":
+        assert torch.equal(info.n_leapfrog, nleap)  # sample(): the total over the T transitions
+        assert torch.equal(info.num_doublings, i2.num_doublings)
+    holder = k1._nuts["holder"] if sampler == "nuts" else k1._hmc["holder"]
+    assert torch.equal(holder["rng"], upd[s2])
 
 
 def test_hmc_fused_equals_lockstep_bitwise(eng):
