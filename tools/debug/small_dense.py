@@ -29,5 +29,6 @@ for mode in MODES:
     samples, info = kernel.sample(state, 0.3 * D ** -0.25, imm, *extra, 100)[:2]
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     nl = float(HMC_L) if HMC_L else float(info.n_leapfrog.double().mean()) / 100
-    print(f"{"hmc" if HMC_L else "nuts"} single_launch={int(bool(mode))} D={D} C={C}: {dt/100*1e3:.3f} ms/transition, {nl:.1f} leapfrogs/transition/chain, "
+    name = "hmc" if HMC_L else "nuts"
+    print(f"{name} single_launch={int(bool(mode))} D={D} C={C}: {dt/100*1e3:.3f} ms/transition, {nl:.1f} leapfrogs/transition/chain, "
           f"{C*nl*100/dt:.3e} leapfrog/s", flush=True)
