@@ -56,6 +56,7 @@ struct aehmc_ctx {
   int64_t prof_n = 0;
   unsigned long long *d_flops = nullptr;  // algorithmic flops of the profiled launches
   // stream-K GEMM: persistent grid, partial-accumulator hand-off buffers
+  int opt_gemm_small = 1;  // mid-size products on small tiles: 1 auto, 0 off, 2 / 3 / 4: force 64x64 / 64x128 / 32x64
   int opt_streamk = 2;  // 0 off, 1 = 128x128 tiles (2 workgroups/CU), 2 = 128x256 tiles, software-pipelined (1 workgroup/CU)
   int sk_grid = 0, sk_grid_wide = 0;
   int64_t rows_hint = 0;  // > 0: upper bound on the live-row count of compacted GEMMs (from the last poll)
@@ -449,6 +450,10 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
     ctx->opt_dense_linear = value != 0;
     return 0;
   }
+  if (!strcmp(name, "gemm_small_tiles")) {
+    ctx->opt_gemm_small = (int)value;
+    return 0;
+  }
   if (!strcmp(name, "streamk")) {
     ctx->opt_streamk = (int)value;
     return 0;
@@ -607,7 +612,7 @@ static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A
   if (n_rows && ctx->rows_hint > 0 && ctx->rows_hint < M) M = ctx->rows_hint;
   HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st, row_idx, n_rows,
                             p ? ctx->d_flops : nullptr, (use_sk && mode == 0) ? &sk : nullptr, ctx->sk_grid,
-                            mode, ctx->opt_streamk == 2 ? ctx->sk_grid_wide : 0));
+                            mode, ctx->opt_streamk == 2 ? ctx->sk_grid_wide : 0, ctx->opt_gemm_small));
   return prof_end(ctx, st, p);
 }
 

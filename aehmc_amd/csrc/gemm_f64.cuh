@@ -627,13 +627,122 @@ __global__ __launch_bounds__(256) void gemm_nt_f64_tail_kernel(
     }
 }
 
+// ---- small tiles for mid-size problems --------------------------------------------------------
+// Chain-batched products of a mid-size problem (D = 65 .. ~1000: N = K = D, M = a few thousand chains) are only a
+// few dozen 128 x 128 tiles -- D = 200 with 4096 chains: 64 workgroups on 256 CUs, 32 us per product.  Here a
+// workgroup (4 waves, 2 x 2) computes a (32 I) x (32 J) tile, each wave I x J MFMA tiles: 32 x 64 or 64 x 64 tiles
+// give every CU two or more workgroups.  An fp64 MFMA (16x16x4: 32 cycles) is slow against the LDS reads that feed it,
+// so the small tile's lower operand reuse costs little; the operands are L2-resident at this size.  Same K-tile
+// (16), same per-element summation order as every other variant (bitwise the same result), rows compacted the same
+// way; K may end inside a K-tile (zeros).
+template <int I, int J, bool VEC>
+__global__ __launch_bounds__(256) void gemm_nt_f64_small_kernel(
+    int64_t M, int64_t N, int64_t K, const double *__restrict__ A, int64_t lda,
+    const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc,
+    const int *__restrict__ row_idx, const int *__restrict__ n_rows,
+    unsigned long long *__restrict__ flop_counter) {
+  constexpr int BM = 32 * I, BN = 32 * J;
+  __shared__ __attribute__((aligned(16))) double la[2][BM][GEMM_LDS];
+  __shared__ __attribute__((aligned(16))) double lb[2][BN][GEMM_LDS];
+  __shared__ int s_rows[BM];
+  if (n_rows) M = *n_rows;
+  if (flop_counter && blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(flop_counter, (unsigned long long)(2 * M * N * K));
+  const int Tn = (int)((N + BN - 1) / BN);
+  const int64_t m0 = (int64_t)(blockIdx.x / Tn) * BM, n0 = (int64_t)(blockIdx.x % Tn) * BN;
+  if (m0 >= M) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  if (tid < BM) {
+    const int64_t r = m0 + tid;
+    s_rows[tid] = r < M ? (row_idx ? row_idx[r] : (int)r) : -1;
+  }
+  __syncthreads();
+  // staging role: rows tid / 8 + 32 l, doubles 2 (tid % 8), +1 of the K-tile
+  const int srow = tid >> 3, scol = (tid & 7) * 2;
+  const double *pa[I], *pb[J];
+#pragma unroll
+  for (int l = 0; l < I; l++) {
+    const int r = s_rows[srow + 32 * l];
+    pa[l] = r >= 0 ? A + (int64_t)r * lda + scol : nullptr;
+  }
+#pragma unroll
+  for (int l = 0; l < J; l++) {
+    const int64_t r = n0 + srow + 32 * l;
+    pb[l] = r < N ? B + r * ldb + scol : nullptr;
+  }
+  auto fetch = [&](const double *ptr, int64_t k0) -> d2_t {
+    const int64_t k = k0 + scol;
+    if (!ptr || k >= K) return (d2_t){0.0, 0.0};
+    if (VEC && k + 2 <= K) return *reinterpret_cast<const d2_t *>(ptr + k0);
+    return (d2_t){ptr[k0], k + 1 < K ? ptr[k0 + 1] : 0.0};
+  };
+  d4_t acc[I][J];
+#pragma unroll
+  for (int i = 0; i < I; i++)
+#pragma unroll
+    for (int j = 0; j < J; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  d2_t ra[I], rb[J];
+  const int nk = (int)((K + GEMM_BK - 1) / GEMM_BK);
+#pragma unroll
+  for (int l = 0; l < I; l++) ra[l] = fetch(pa[l], 0);
+#pragma unroll
+  for (int l = 0; l < J; l++) rb[l] = fetch(pb[l], 0);
+#pragma unroll
+  for (int l = 0; l < I; l++) *reinterpret_cast<d2_t *>(&la[0][srow + 32 * l][scol]) = ra[l];
+#pragma unroll
+  for (int l = 0; l < J; l++) *reinterpret_cast<d2_t *>(&lb[0][srow + 32 * l][scol]) = rb[l];
+  __syncthreads();
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int kt = 0; kt < nk; kt++) {
+    const int st = kt & 1;
+    if (kt + 1 < nk) {
+      const int64_t k0 = (int64_t)(kt + 1) * GEMM_BK;
+#pragma unroll
+      for (int l = 0; l < I; l++) ra[l] = fetch(pa[l], k0);
+#pragma unroll
+      for (int l = 0; l < J; l++) rb[l] = fetch(pb[l], k0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < GEMM_BK / 4; kk++) {
+      double a[I], b[J];
+#pragma unroll
+      for (int i = 0; i < I; i++) a[i] = la[st][wm * 16 * I + i * 16 + fr][kk * 4 + fk];
+#pragma unroll
+      for (int j = 0; j < J; j++) b[j] = lb[st][wn * 16 * J + j * 16 + fr][kk * 4 + fk];
+#pragma unroll
+      for (int i = 0; i < I; i++)
+#pragma unroll
+        for (int j = 0; j < J; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int l = 0; l < I; l++) *reinterpret_cast<d2_t *>(&la[st ^ 1][srow + 32 * l][scol]) = ra[l];
+#pragma unroll
+      for (int l = 0; l < J; l++) *reinterpret_cast<d2_t *>(&lb[st ^ 1][srow + 32 * l][scol]) = rb[l];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < I; i++)
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+      const int64_t col = n0 + wn * 16 * J + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = s_rows[wm * 16 * I + i * 16 + fk + 4 * r];
+        if (row >= 0 && col < N) Cm[(int64_t)row * ldc + col] = acc[i][j][r];
+      }
+    }
+}
+
 inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const double *A,
                                      int64_t lda, const double *B, int64_t ldb, double *Cm,
                                      int64_t ldc, hipStream_t stream,
                                      const int *row_idx = nullptr, const int *n_rows = nullptr,
                                      unsigned long long *flop_counter = nullptr,
                                      const GemmStreamK *sk = nullptr, int sk_grid = 0, int mode = 0,
-                                     int sk_grid_wide = 0) {
+                                     int sk_grid_wide = 0, int small_tiles = 1) {
   if (M <= 0 || N <= 0) return hipSuccess;
   const int Tm = (int)((M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((N + GEMM_BN - 1) / GEMM_BN);
   const int total = Tm * Tn;
@@ -655,6 +764,25 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
       hipLaunchKernelGGL((gemm_nt_f64_tail_kernel<8, 2>), tg, dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc,
                          row_idx, n_rows, flop_counter);
     return hipGetLastError();
+  }
+  if (mode == 0 && small_tiles && M > 128 && N <= 2048 && total < 256) {
+    // mid-size problem, the 128 x 128 tiles would leave CUs idle: the largest small tile that still gives every CU two
+    // workgroups, else the smallest
+    const auto count = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+#define AEHMC_GEMM_SMALL(II, JJ)                                                                                  \
+  do {                                                                                                            \
+    if (vec)                                                                                                      \
+      hipLaunchKernelGGL((gemm_nt_f64_small_kernel<II, JJ, true>), dim3((unsigned)count(32 * II, 32 * JJ)),        \
+                         dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);  \
+    else                                                                                                          \
+      hipLaunchKernelGGL((gemm_nt_f64_small_kernel<II, JJ, false>), dim3((unsigned)count(32 * II, 32 * JJ)),       \
+                         dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);  \
+    return hipGetLastError();                                                                                     \
+  } while (0)
+    if (small_tiles == 3 || (small_tiles == 1 && count(64, 128) >= 512)) AEHMC_GEMM_SMALL(2, 4);
+    if (small_tiles == 2 || (small_tiles == 1 && count(64, 64) >= 512)) AEHMC_GEMM_SMALL(2, 2);
+    AEHMC_GEMM_SMALL(1, 2);
+#undef AEHMC_GEMM_SMALL
   }
   if (mode == 1) {
     hipLaunchKernelGGL((gemm_nt_f64_kernel<false, 1>), dim3(grid), dim3(256), 0, stream, M, N, K, A, lda,

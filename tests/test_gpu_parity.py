@@ -139,6 +139,30 @@ def test_gemm_few_row_tiles_every_tile_written(eng, M, N, K):
     assert torch.equal(outs[2], outs[0]) and torch.equal(outs[1], outs[0])
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 200, 200), (700, 300, 300), (129, 65, 65), (1000, 201, 201), (333, 1000, 77),
+                                   (1500, 1100, 130), (130, 2048, 33), (2000, 96, 1000)])
+def test_gemm_small_tiles_bitwise_equals_tiled(eng, M, N, K):
+    """Mid-size products (fewer than 256 tiles of 128 x 128, N <= 2048) take (32 I) x (32 J) tiles so that every CU
+    has work (round 3: D = 200, 4096 chains 37 -> 17 us): 64 x 128, 64 x 64 and 32 x 64, chosen by tile count or
+    forced with the option; every variant gives the bits of the 128 x 128 kernel (same K-tiles, same k order), writes
+    every element (poisoned output), odd leading dimensions (scalar loads) and K ending inside a K-tile included."""
+    r = np.random.default_rng(M + N + K)
+    A, B = dev(r.normal(size=(M, K))), dev(r.normal(size=(N, K)))
+    outs = {}
+    try:
+        for mode in (0, 1, 2, 3, 4):
+            eng.set_option("gemm_small_tiles", mode)
+            poison = torch.full((M, N), float("nan"), dtype=torch.float64, device="cuda")
+            eng.lib.aehmc_gemm_nt(eng.ctx, M, N, K, A.data_ptr(), K, B.data_ptr(), K, poison.data_ptr(), N, eng.stream)
+            torch.cuda.synchronize()
+            outs[mode] = poison
+    finally:
+        eng.set_option("gemm_small_tiles", 1)
+    assert torch.allclose(outs[0], A @ B.T, rtol=1e-12, atol=1e-12 * np.sqrt(K))
+    for mode in (1, 2, 3, 4):
+        assert torch.equal(outs[mode], outs[0]), mode
+
+
 # ------------------------------------------------------------------ G1 on the GPU
 def test_g1_readme_bit_exact_on_gpu():
     """README.md:22-54 through the drop-in API: position after one NUTS transition."""
