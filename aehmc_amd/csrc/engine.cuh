@@ -960,29 +960,46 @@ __global__ __launch_bounds__(256) void k_step_linear(EngineArgs a) {
   }
 }
 
-// ascending list of live chains + count (one 1024-thread block; deterministic order)
+// ascending list of live chains + count (one 1024-thread block; deterministic order).  Runs after every lock-step
+// of a dense problem: thread t owns a contiguous run of chains, reads their flags ONCE (loads in flight together,
+// kept as a bit mask), ranks itself with a shuffle scan inside its wavefront and the 16 wavefront totals.
 __global__ __launch_bounds__(1024) void k_compact(const ChainCtl *ctl, long long C, int *row_idx,
                                                   int *n_rows, int *host_slot) {
-  __shared__ int cnt[1024];
-  const int t = threadIdx.x;
+  __shared__ int wsum[16];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const long long per = (C + 1023) / 1024;
   const long long lo = t * per, hi = (lo + per < C) ? lo + per : C;
+  unsigned long long mask = 0;  // flags of the first 64 chains of the run (every chain up to C = 65536)
   int n = 0;
-  for (long long c = lo; c < hi; c++) n += ctl[c].done ? 0 : 1;
-  cnt[t] = n;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
-    int v = t >= off ? cnt[t - off] : 0;
-    __syncthreads();
-    cnt[t] += v;
-    __syncthreads();
+#pragma unroll 8
+  for (long long c = lo; c < hi; c++) {
+    const int live = ctl[c].done ? 0 : 1;
+    n += live;
+    if (c - lo < 64) mask |= (unsigned long long)live << (c - lo);
   }
-  int pos = cnt[t] - n;
-  for (long long c = lo; c < hi; c++)
-    if (!ctl[c].done) row_idx[pos++] = (int)c;
-  if (t == 1023) {
-    *n_rows = cnt[1023];
-    if (host_slot) *host_slot = cnt[1023];
+  int incl = n;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int sw = wsum[i];
+    base += i < w ? sw : 0;
+    total += sw;
+  }
+  int pos = base + incl - n;
+  for (long long c = lo; c < hi; c++) {
+    const bool live = (c - lo < 64) ? ((mask >> (c - lo)) & 1) != 0 : !ctl[c].done;
+    if (live) row_idx[pos++] = (int)c;
+  }
+  if (t == 0) {
+    *n_rows = total;
+    if (host_slot) *host_slot = total;
   }
 }
 

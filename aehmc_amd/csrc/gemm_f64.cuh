@@ -660,68 +660,80 @@ __global__ __launch_bounds__(256) void gemm_nt_f64_small_kernel(
   __syncthreads();
   // staging role: rows tid / 8 + 32 l, doubles 2 (tid % 8), +1 of the K-tile
   const int srow = tid >> 3, scol = (tid & 7) * 2;
+  // (rows beyond M / N read a valid row instead: their products land in output elements that are never stored)
   const double *pa[I], *pb[J];
 #pragma unroll
   for (int l = 0; l < I; l++) {
     const int r = s_rows[srow + 32 * l];
-    pa[l] = r >= 0 ? A + (int64_t)r * lda + scol : nullptr;
+    pa[l] = A + (int64_t)(r >= 0 ? r : s_rows[0]) * lda + scol;
   }
 #pragma unroll
   for (int l = 0; l < J; l++) {
     const int64_t r = n0 + srow + 32 * l;
-    pb[l] = r < N ? B + r * ldb + scol : nullptr;
+    pb[l] = B + (r < N ? r : n0) * ldb + scol;
   }
+  // branch-free: every load is issued (address clamped into the row), elements at k >= K are zeroed afterwards
   auto fetch = [&](const double *ptr, int64_t k0) -> d2_t {
     const int64_t k = k0 + scol;
-    if (!ptr || k >= K) return (d2_t){0.0, 0.0};
-    if (VEC && k + 2 <= K) return *reinterpret_cast<const d2_t *>(ptr + k0);
-    return (d2_t){ptr[k0], k + 1 < K ? ptr[k0 + 1] : 0.0};
+    if (VEC) {  // K even: a pair is inside or outside as a whole
+      const d2_t v = *reinterpret_cast<const d2_t *>(ptr + (k < K ? k0 : -(int64_t)scol));
+      return k < K ? v : (d2_t){0.0, 0.0};
+    }
+    const double x0 = ptr[k < K ? k0 : -(int64_t)scol], x1 = ptr[k + 1 < K ? k0 + 1 : -(int64_t)scol];
+    return (d2_t){k < K ? x0 : 0.0, k + 1 < K ? x1 : 0.0};
   };
   d4_t acc[I][J];
 #pragma unroll
   for (int i = 0; i < I; i++)
 #pragma unroll
     for (int j = 0; j < J; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
-  d2_t ra[I], rb[J];
+  // operands are fetched P K-tiles ahead into a ring of register stages (the K loop of a small tile is far shorter
+  // than a global-memory round trip: 8 MFMAs per wave and K-tile at I x J = 1 x 2)
+  constexpr int P = 4;
+  d2_t ra[P][I], rb[P][J];
   const int nk = (int)((K + GEMM_BK - 1) / GEMM_BK);
 #pragma unroll
-  for (int l = 0; l < I; l++) ra[l] = fetch(pa[l], 0);
+  for (int s = 0; s < P; s++) {
 #pragma unroll
-  for (int l = 0; l < J; l++) rb[l] = fetch(pb[l], 0);
+    for (int l = 0; l < I; l++) ra[s][l] = fetch(pa[l], (int64_t)s * GEMM_BK);
 #pragma unroll
-  for (int l = 0; l < I; l++) *reinterpret_cast<d2_t *>(&la[0][srow + 32 * l][scol]) = ra[l];
-#pragma unroll
-  for (int l = 0; l < J; l++) *reinterpret_cast<d2_t *>(&lb[0][srow + 32 * l][scol]) = rb[l];
-  __syncthreads();
+    for (int l = 0; l < J; l++) rb[s][l] = fetch(pb[l], (int64_t)s * GEMM_BK);
+  }
   const int fr = lane & 15, fk = lane >> 4;
-  for (int kt = 0; kt < nk; kt++) {
-    const int st = kt & 1;
-    if (kt + 1 < nk) {
-      const int64_t k0 = (int64_t)(kt + 1) * GEMM_BK;
+  for (int kt0 = 0; kt0 < nk; kt0 += P) {
 #pragma unroll
-      for (int l = 0; l < I; l++) ra[l] = fetch(pa[l], k0);
+    for (int s = 0; s < P; s++) {
+      const int kt = kt0 + s;
+      if (kt < nk) {  // workgroup-uniform
+        const int st = s & 1;  // (kt0 is a multiple of the even P)
+        // LDS stage st was last read in iteration kt - 2; every wave has passed iteration kt - 1's barrier since
 #pragma unroll
-      for (int l = 0; l < J; l++) rb[l] = fetch(pb[l], k0);
+        for (int l = 0; l < I; l++) *reinterpret_cast<d2_t *>(&la[st][srow + 32 * l][scol]) = ra[s][l];
+#pragma unroll
+        for (int l = 0; l < J; l++) *reinterpret_cast<d2_t *>(&lb[st][srow + 32 * l][scol]) = rb[s][l];
+        {
+          const int64_t k0 = (int64_t)(kt + P) * GEMM_BK;  // (past K: zeros, no access)
+#pragma unroll
+          for (int l = 0; l < I; l++) ra[s][l] = fetch(pa[l], k0);
+#pragma unroll
+          for (int l = 0; l < J; l++) rb[s][l] = fetch(pb[l], k0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 4; kk++) {
+          double a[I], b[J];
+#pragma unroll
+          for (int i = 0; i < I; i++) a[i] = la[st][wm * 16 * I + i * 16 + fr][kk * 4 + fk];
+#pragma unroll
+          for (int j = 0; j < J; j++) b[j] = lb[st][wn * 16 * J + j * 16 + fr][kk * 4 + fk];
+#pragma unroll
+          for (int i = 0; i < I; i++)
+#pragma unroll
+            for (int j = 0; j < J; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+      }
     }
-#pragma unroll
-    for (int kk = 0; kk < GEMM_BK / 4; kk++) {
-      double a[I], b[J];
-#pragma unroll
-      for (int i = 0; i < I; i++) a[i] = la[st][wm * 16 * I + i * 16 + fr][kk * 4 + fk];
-#pragma unroll
-      for (int j = 0; j < J; j++) b[j] = lb[st][wn * 16 * J + j * 16 + fr][kk * 4 + fk];
-#pragma unroll
-      for (int i = 0; i < I; i++)
-#pragma unroll
-        for (int j = 0; j < J; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int l = 0; l < I; l++) *reinterpret_cast<d2_t *>(&la[st ^ 1][srow + 32 * l][scol]) = ra[l];
-#pragma unroll
-      for (int l = 0; l < J; l++) *reinterpret_cast<d2_t *>(&lb[st ^ 1][srow + 32 * l][scol]) = rb[l];
-    }
-    __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < I; i++)
@@ -765,13 +777,13 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
                          row_idx, n_rows, flop_counter);
     return hipGetLastError();
   }
-  if (mode == 0 && small_tiles && M > 128 && N <= 2048 && total < 256) {
+  if (mode == 0 && small_tiles && M > 128 && N <= 2048 && K >= 2 && total < 256) {
     // mid-size problem, the 128 x 128 tiles would leave CUs idle: the largest small tile that still gives every CU two
     // workgroups, else the smallest
     const auto count = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
 #define AEHMC_GEMM_SMALL(II, JJ)                                                                                  \
   do {                                                                                                            \
-    if (vec)                                                                                                      \
+    if (vec && K % 2 == 0)                                                                                        \
       hipLaunchKernelGGL((gemm_nt_f64_small_kernel<II, JJ, true>), dim3((unsigned)count(32 * II, 32 * JJ)),        \
                          dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);  \
     else                                                                                                          \
