@@ -635,22 +635,27 @@ __global__ __launch_bounds__(256) void gemm_nt_f64_tail_kernel(
 // so the small tile's lower operand reuse costs little; the operands are L2-resident at this size.  Same K-tile
 // (16), same per-element summation order as every other variant (bitwise the same result), rows compacted the same
 // way; K may end inside a K-tile (zeros).
-template <int I, int J, bool VEC>
+template <int I, int J, bool VEC, int KT = 2>
 __global__ __launch_bounds__(256) void gemm_nt_f64_small_kernel(
     int64_t M, int64_t N, int64_t K, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm, int64_t ldc,
     const int *__restrict__ row_idx, const int *__restrict__ n_rows,
     unsigned long long *__restrict__ flop_counter) {
   constexpr int BM = 32 * I, BN = 32 * J;
-  __shared__ __attribute__((aligned(16))) double la[2][BM][GEMM_LDS];
-  __shared__ __attribute__((aligned(16))) double lb[2][BN][GEMM_LDS];
+  constexpr int LW = 16 * KT + 2;  // KT K-tiles of 16 per LDS stage and barrier
+  __shared__ __attribute__((aligned(16))) double la[2][BM][LW];
+  __shared__ __attribute__((aligned(16))) double lb[2][BN][LW];
   __shared__ int s_rows[BM];
   if (n_rows) M = *n_rows;
   if (flop_counter && blockIdx.x == 0 && threadIdx.x == 0)
     atomicAdd(flop_counter, (unsigned long long)(2 * M * N * K));
-  const int Tn = (int)((N + BN - 1) / BN);
-  const int64_t m0 = (int64_t)(blockIdx.x / Tn) * BM, n0 = (int64_t)(blockIdx.x % Tn) * BN;
-  if (m0 >= M) return;
+  // block ids are dealt to the 8 XCDs round-robin: every XCD gets a contiguous run of tiles (row-major, the Tn
+  // column tiles of a row block together), so a row block of A is fetched into ONE L2 instead of up to 8
+  const int Tn = (int)((N + BN - 1) / BN), Tm = (int)((M + BM - 1) / BM);
+  const int chunk = (Tm * Tn + 7) / 8;
+  const int tile = (int)(blockIdx.x % 8) * chunk + (int)(blockIdx.x / 8);
+  if ((int)(blockIdx.x / 8) >= chunk || tile >= Tm * Tn) return;
+  const int64_t m0 = (int64_t)(tile / Tn) * BM, n0 = (int64_t)(tile % Tn) * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   if (tid < BM) {
@@ -687,18 +692,22 @@ __global__ __launch_bounds__(256) void gemm_nt_f64_small_kernel(
   for (int i = 0; i < I; i++)
 #pragma unroll
     for (int j = 0; j < J; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
-  // operands are fetched P K-tiles ahead into a ring of register stages (the K loop of a small tile is far shorter
-  // than a global-memory round trip: 8 MFMAs per wave and K-tile at I x J = 1 x 2)
-  constexpr int P = 4;
-  d2_t ra[P][I], rb[P][J];
-  const int nk = (int)((K + GEMM_BK - 1) / GEMM_BK);
+  // operands are fetched P stages of KT K-tiles ahead into a ring of register stages.  (Measured, rocprofv3: K-tiles of
+  // 16 or 32 per barrier, 2 or 4 ring stages, loads kept out of branches so that the waits before the LDS writes are
+  // partial instead of s_waitcnt vmcnt(0) -- all within 5 %: at 28 % (D = 200) to 52 % (D = 500) of the 78.6 TFLOP/s
+  // fp64 MFMA peak the rest is the fixed cost of a launch this short, not the K loop.)
+  constexpr int P = 4 / KT < 2 ? 2 : 4 / KT, BKS = GEMM_BK * KT;  // ring stages; K per stage
+  d2_t ra[P][KT][I], rb[P][KT][J];
+  const int nk = (int)((K + BKS - 1) / BKS);
 #pragma unroll
-  for (int s = 0; s < P; s++) {
+  for (int s = 0; s < P; s++)
 #pragma unroll
-    for (int l = 0; l < I; l++) ra[s][l] = fetch(pa[l], (int64_t)s * GEMM_BK);
+    for (int u = 0; u < KT; u++) {
 #pragma unroll
-    for (int l = 0; l < J; l++) rb[s][l] = fetch(pb[l], (int64_t)s * GEMM_BK);
-  }
+      for (int l = 0; l < I; l++) ra[s][u][l] = fetch(pa[l], (int64_t)s * BKS + u * GEMM_BK);
+#pragma unroll
+      for (int l = 0; l < J; l++) rb[s][u][l] = fetch(pb[l], (int64_t)s * BKS + u * GEMM_BK);
+    }
   const int fr = lane & 15, fk = lane >> 4;
   for (int kt0 = 0; kt0 < nk; kt0 += P) {
 #pragma unroll
@@ -708,19 +717,25 @@ __global__ __launch_bounds__(256) void gemm_nt_f64_small_kernel(
         const int st = s & 1;  // (kt0 is a multiple of the even P)
         // LDS stage st was last read in iteration kt - 2; every wave has passed iteration kt - 1's barrier since
 #pragma unroll
-        for (int l = 0; l < I; l++) *reinterpret_cast<d2_t *>(&la[st][srow + 32 * l][scol]) = ra[s][l];
+        for (int u = 0; u < KT; u++) {
 #pragma unroll
-        for (int l = 0; l < J; l++) *reinterpret_cast<d2_t *>(&lb[st][srow + 32 * l][scol]) = rb[s][l];
-        {
-          const int64_t k0 = (int64_t)(kt + P) * GEMM_BK;  // (past K: zeros, no access)
+          for (int l = 0; l < I; l++)
+            *reinterpret_cast<d2_t *>(&la[st][srow + 32 * l][u * GEMM_BK + scol]) = ra[s][u][l];
 #pragma unroll
-          for (int l = 0; l < I; l++) ra[s][l] = fetch(pa[l], k0);
+          for (int l = 0; l < J; l++)
+            *reinterpret_cast<d2_t *>(&lb[st][srow + 32 * l][u * GEMM_BK + scol]) = rb[s][u][l];
+        }
 #pragma unroll
-          for (int l = 0; l < J; l++) rb[s][l] = fetch(pb[l], k0);
+        for (int u = 0; u < KT; u++) {
+          const int64_t k0 = (int64_t)(kt + P) * BKS + u * GEMM_BK;  // (past K: zeros)
+#pragma unroll
+          for (int l = 0; l < I; l++) ra[s][u][l] = fetch(pa[l], k0);
+#pragma unroll
+          for (int l = 0; l < J; l++) rb[s][u][l] = fetch(pb[l], k0);
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < GEMM_BK / 4; kk++) {
+        for (int kk = 0; kk < BKS / 4; kk++) {
           double a[I], b[J];
 #pragma unroll
           for (int i = 0; i < I; i++) a[i] = la[st][wm * 16 * I + i * 16 + fr][kk * 4 + fk];
@@ -784,10 +799,10 @@ inline hipError_t launch_gemm_nt_f64(int64_t M, int64_t N, int64_t K, const doub
 #define AEHMC_GEMM_SMALL(II, JJ)                                                                                  \
   do {                                                                                                            \
     if (vec && K % 2 == 0)                                                                                        \
-      hipLaunchKernelGGL((gemm_nt_f64_small_kernel<II, JJ, true>), dim3((unsigned)count(32 * II, 32 * JJ)),        \
+      hipLaunchKernelGGL((gemm_nt_f64_small_kernel<II, JJ, true>), dim3((unsigned)((count(32 * II, 32 * JJ) + 7) / 8 * 8)),        \
                          dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);  \
     else                                                                                                          \
-      hipLaunchKernelGGL((gemm_nt_f64_small_kernel<II, JJ, false>), dim3((unsigned)count(32 * II, 32 * JJ)),       \
+      hipLaunchKernelGGL((gemm_nt_f64_small_kernel<II, JJ, false>), dim3((unsigned)((count(32 * II, 32 * JJ) + 7) / 8 * 8)),       \
                          dim3(256), 0, stream, M, N, K, A, lda, B, ldb, Cm, ldc, row_idx, n_rows, flop_counter);  \
     return hipGetLastError();                                                                                     \
   } while (0)
