@@ -75,14 +75,15 @@ def new_state(q, logprob_fn, num_chains=None) -> IntegratorState:
 def diagnostics(layout: Layout, q, U, g, out, tree: bool) -> Diagnostics:
     """trajectory.py:379-384 record from the engine's [C, ...] outputs (``tree``: NUTS fields;
     HMC returns None for them as hmc.py:199-204 does)."""
+    flags = out["flags"].bool()  # [2, C]: is_turning (HMC: the accept flag), is_diverging
     return Diagnostics(
         state=IntegratorState(position=layout.vec(q), momentum=layout.vec(out["momentum"]),
                               potential_energy=layout.per_chain(U),
                               potential_energy_grad=layout.vec(g)),
         acceptance_probability=layout.per_chain(out["acceptance_probability"]),
         num_doublings=layout.per_chain(out["num_doublings"]) if tree else None,
-        is_turning=layout.per_chain(out["is_turning"].bool()) if tree else None,
-        is_diverging=layout.per_chain(out["is_diverging"].bool()),
+        is_turning=layout.per_chain(flags[0]) if tree else None,
+        is_diverging=layout.per_chain(flags[1]),
         n_leapfrog=layout.per_chain(out["n_leapfrog"]))
 
 

@@ -81,11 +81,16 @@ __device__ __forceinline__ void team_sum2(double &x, double &y, bool single = fa
 // MULTI: the launch runs m.T > 1 transitions (the RNG state, the leapfrog total ... stay live across
 // the tree loop, which costs ~35 VGPRs and a wavefront per SIMD: single transitions keep their own
 // instantiation).
-template <int T, int R, bool MULTI, int DENSE = 0>
+// CKL: the U-turn checkpoints of the chain (momentum and momentum sum per tree level, termination.py:12-16) live
+// in LDS instead of global memory -- [wave][level][2][64] doubles, element i written and read by lane i only.  For a
+// few chains (one wavefront per SIMD or less: the README example's single chain) the checkpoint reads are dependent
+// L2 round trips on the serial path of every leapfrog; with many chains the 40 KB per workgroup would cost occupancy.
+template <int T, int R, bool MULTI, int DENSE = 0, bool CKL = false>
 __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK) void k_nuts_resident(EngineArgs a,
                                                                                             NutsSampleArgs m) {
   using TM = Team<T>;
   static_assert(DENSE == 0 || (T == 64 && R == 1), "dense products: one wavefront per chain, one element per lane");
+  static_assert(!CKL || (DENSE == 0 && T == 64 && R == 1), "LDS checkpoints: one wavefront per chain, one element per lane");
   constexpr bool MD = (DENSE & RES_DENSE_METRIC) != 0, TD = (DENSE & RES_DENSE_TARGET) != 0;
   constexpr bool PC = (DENSE & RES_DENSE_PER_CHAIN) != 0, MLDS = MD && !PC;
   constexpr int BLOCK = DENSE ? RES_DENSE_BLOCK : TM::BLOCK;
@@ -310,8 +315,8 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK) void k_nu
     }
     const bool even = (step & 1) == 0;
     {
-      double *ckp = a.ckp + ((size_t)tmax * a.C + c) * a.D;
-      double *cks = a.cks + ((size_t)tmax * a.C + c) * a.D;
+      double *ckp = CKL ? res_lds + ((size_t)(wave * a.max_exp + tmax) * 2) * 64 : a.ckp + ((size_t)tmax * a.C + c) * a.D;
+      double *cks = CKL ? res_lds + ((size_t)(wave * a.max_exp + tmax) * 2 + 1) * 64 : a.cks + ((size_t)tmax * a.C + c) * a.D;
 #pragma unroll
       for (int r = 0; r < R; r++) {
         if (ok[r]) {
@@ -362,8 +367,8 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK) void k_nu
         int idx = tmax;
         bool crit = false;
         for (;;) {
-          const double *kp = a.ckp + ((size_t)idx * a.C + c) * a.D;
-          const double *ks = a.cks + ((size_t)idx * a.C + c) * a.D;
+          const double *kp = CKL ? res_lds + ((size_t)(wave * a.max_exp + idx) * 2) * 64 : a.ckp + ((size_t)idx * a.C + c) * a.D;
+          const double *ks = CKL ? res_lds + ((size_t)(wave * a.max_exp + idx) * 2 + 1) * 64 : a.cks + ((size_t)idx * a.C + c) * a.D;
           const double *kv = a.ckv + ((size_t)idx * a.C + c) * a.D;  // (MD)
           double d_l = 0.0, d_r = 0.0;
 #pragma unroll
@@ -647,6 +652,15 @@ template <int T, int R>
 inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
   const unsigned grid = Team<T>::SUB ? (unsigned)((a.C * T + 255) / 256) : (unsigned)((a.C + 3) / 4);
   const bool multi = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total || m.adapt;
+  if constexpr (T == 64 && R == 1) {
+    // a few chains (at most two wavefronts per SIMD): checkpoints in LDS, 4 waves x max_exp levels x 1 KB <= 64 KB
+    if (a.C <= 2048 && a.max_exp <= 16) {
+      const size_t dyn = (size_t)4 * a.max_exp * 2 * 64 * sizeof(double);
+      if (multi) hipLaunchKernelGGL((k_nuts_resident<T, R, true, 0, true>), dim3(grid), dim3(Team<T>::BLOCK), dyn, st, a, m);
+      else hipLaunchKernelGGL((k_nuts_resident<T, R, false, 0, true>), dim3(grid), dim3(Team<T>::BLOCK), dyn, st, a, m);
+      return hipGetLastError();
+    }
+  }
   if (multi) hipLaunchKernelGGL((k_nuts_resident<T, R, true>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a, m);
   else hipLaunchKernelGGL((k_nuts_resident<T, R, false>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a, m);
   return hipGetLastError();

@@ -285,6 +285,7 @@ class Engine:
             acceptance_probability=torch.empty(C, dtype=torch.float64, device=dev),
             num_doublings=i64[0], is_turning=i32[0], is_diverging=i32[1], n_leapfrog=i64[1])
         c = _lib.CDiagnostics(**{k: v.data_ptr() for k, v in out.items()})
+        out["flags"] = i32  # (is_turning, is_diverging) as one array: one conversion to bool for both
         return out, c
 
     def hmc_step(self, rng, eps, L, thr, q, U, g):

@@ -3,6 +3,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Tuple
 
+import torch
+
 from ._common import Layout, diagnostics, histories, new_state as _new_state, state_rows
 from .engine import get_engine, rng_to_device
 from .integrators import IntegratorState
@@ -20,6 +22,8 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
     from ``srng`` here, in that order."""
     rng_host = srng.sites(2)
     holder = {}
+    if torch.cuda.is_available():  # the generator states go to the device with the kernel, not with its first call
+        holder["rng"] = rng_to_device(rng_host, get_engine().device)
 
     def step(state: IntegratorState, step_size, inverse_mass_matrix,
              num_integration_steps: int) -> Tuple[Diagnostics, Dict]:
@@ -27,8 +31,8 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
         eng = get_engine()
         shape = tuple(state.position.shape)
         layout = Layout(shape, srng.batched, srng.num_chains)
-        if "rng" not in holder:
-            holder["rng"] = rng_to_device(rng_host, eng.device)
+        if "rng" not in holder or holder["rng"].device != eng.device:  # (uploaded at construction when a GPU is there)
+            holder["rng"] = holder["rng"].to(eng.device) if "rng" in holder else rng_to_device(rng_host, eng.device)
         q, U, g = state_rows(state, layout, eng.device)
         eng.set_target(logprob_fn, layout.D)
         eng.set_metric(inverse_mass_matrix, layout.D)
@@ -45,8 +49,8 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
         transition, acceptance history [N, ...], divergence history [N, ...])``."""
         eng = get_engine()
         layout = Layout(tuple(state.position.shape), srng.batched, srng.num_chains)
-        if "rng" not in holder:
-            holder["rng"] = rng_to_device(rng_host, eng.device)
+        if "rng" not in holder or holder["rng"].device != eng.device:  # (uploaded at construction when a GPU is there)
+            holder["rng"] = holder["rng"].to(eng.device) if "rng" in holder else rng_to_device(rng_host, eng.device)
         q, U, g = state_rows(state, layout, eng.device)
         eng.set_target(logprob_fn, layout.D)
         eng.set_metric(inverse_mass_matrix, layout.D)

@@ -3,6 +3,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Tuple
 
+import torch
+
 from ._common import Layout, diagnostics, histories, new_state as _new_state, state_rows
 from .engine import get_engine, rng_to_device
 from .integrators import IntegratorState
@@ -21,14 +23,16 @@ def new_kernel(srng: RandomStream, logprob_fn, max_num_expansions: int = 10,
     progressive sampling (proposals.py:131)."""
     rng_host = srng.sites(4)
     holder = {}
+    if torch.cuda.is_available():  # the generator states go to the device with the kernel, not with its first call
+        holder["rng"] = rng_to_device(rng_host, get_engine().device)
 
     def step(state: IntegratorState, step_size, inverse_mass_matrix) -> Tuple[Diagnostics, Dict]:
         """One NUTS transition for every chain (reference: aehmc/nuts.py:56-153)."""
         eng = get_engine()
         shape = tuple(state.position.shape)
         layout = Layout(shape, srng.batched, srng.num_chains)
-        if "rng" not in holder:
-            holder["rng"] = rng_to_device(rng_host, eng.device)
+        if "rng" not in holder or holder["rng"].device != eng.device:  # (uploaded at construction when a GPU is there)
+            holder["rng"] = holder["rng"].to(eng.device) if "rng" in holder else rng_to_device(rng_host, eng.device)
         q, U, g = state_rows(state, layout, eng.device)
         eng.set_target(logprob_fn, layout.D)
         eng.set_metric(inverse_mass_matrix, layout.D)
@@ -45,8 +49,8 @@ def new_kernel(srng: RandomStream, logprob_fn, max_num_expansions: int = 10,
         TOTAL in n_leapfrog, acceptance history, divergence history)``."""
         eng = get_engine()
         layout = Layout(tuple(state.position.shape), srng.batched, srng.num_chains)
-        if "rng" not in holder:
-            holder["rng"] = rng_to_device(rng_host, eng.device)
+        if "rng" not in holder or holder["rng"].device != eng.device:  # (uploaded at construction when a GPU is there)
+            holder["rng"] = holder["rng"].to(eng.device) if "rng" in holder else rng_to_device(rng_host, eng.device)
         q, U, g = state_rows(state, layout, eng.device)
         eng.set_target(logprob_fn, layout.D)
         eng.set_metric(inverse_mass_matrix, layout.D)
