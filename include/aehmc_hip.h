@@ -115,12 +115,15 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
 
 /* engine options (name, default):
  *  "fused_hmc" 1    register-resident single-launch HMC when the metric is diagonal and the
- *                   target coordinate-wise; 0 forces the lock-step path
+ *                   target coordinate-wise, or the problem small and dense (D <= 64, see
+ *                   "resident_nuts"); 0 forces the lock-step path
  *  "resident_nuts" 2 register-resident single-launch NUTS (a team of 1..64 lanes, or a
  *                   256/512-thread workgroup for large D, keeps the chain's moving state on chip
  *                   for the whole tree) for diagonal/scalar metrics, coordinate-wise
  *                   targets, D <= 10176, and the regression target (four chains per workgroup
- *                   share each pass over the data rows).  2 (auto) = 1 = wherever such a kernel exists
+ *                   share each pass over the data rows), and for small dense problems (D <= 64: a
+ *                   dense inverse mass matrix -- shared or one per chain -- and / or the dense-precision
+ *                   target, products inside the wavefront).  2 (auto) = 1 = wherever such a kernel exists
  *                   (round 3: it beats the lock-step path at every chain count), 0 = never
  *  "resident_min_team" 0  1: always give a chain the smallest team of lanes that holds it
  *                   (64/T chains per wavefront) instead of widening teams while the GPU would
@@ -133,6 +136,10 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *  "dense_linear" 1 dense metric: carry w = imm g with the state so that
  *                   v_half = v - (eps/2) w, v' = v_half - (eps/2) w' (one metric GEMM per
  *                   leapfrog); 0 forms imm p_half and imm p' directly as metrics.py:71 does
+ *  "gemm_small_tiles" 1  fp64 GEMM of a mid-size problem (fewer than 256 tiles of 128 x 128, N <= 2048):
+ *                   1 = 64 x 128, 64 x 64 or 32 x 64 tiles, the largest that gives every CU two
+ *                   workgroups (bitwise the results of the 128 x 128 kernel); 2 / 3 / 4 force
+ *                   64 x 64 / 64 x 128 / 32 x 64; 0 = off
  *  "streamk" 2      fp64 GEMM: persistent grid; whole tiles for all but the last 1..2 rounds, the
  *                   rest of the (tile, k) space split evenly; a tile cut between two workgroups is
  *                   accumulated in k order (bitwise equal to 0).  2: 128 x 256 tiles, one
