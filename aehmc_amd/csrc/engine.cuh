@@ -1094,7 +1094,9 @@ __global__ __launch_bounds__(256) void k_hmc_end(EngineArgs a, long long L) {
 // The HMC transition of a small dense problem in one launch (see above: same matrices in LDS, same
 // in-wavefront products, literal dense mode); the chain's scalars stay in registers between the stages.
 template <bool MD, bool TD, bool PC = false>
-__global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArgs a, const double *prec, double *imm_ws, long long L) {
+__global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArgs a, const double *prec, double *imm_ws, long long L,
+                                                                         long long nt, double *samples, double *acc_hist,
+                                                                         int *div_hist) {
   extern __shared__ __attribute__((aligned(16))) double fd_lds[];
   const int D = (int)a.D, DD = D * D;
   constexpr bool MLDS = MD && !PC;
@@ -1112,6 +1114,8 @@ __global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArg
   const size_t row = (size_t)c * a.D;
   const double *const immW = PC ? imm_ws + (size_t)c * DD : immT;  // PC: this chain's transposed copy (global)
   if (PC) wave_transpose_to(a.imm + (size_t)c * DD, imm_ws + (size_t)c * DD, D, lane);
+  // nt consecutive transitions of the chain in this launch (kernel.sample(nt)); per-transition records optional
+  for (long long tt = 0; tt < nt; tt++) {
   {
     Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4);
     draw_momentum<MD>(a, c, lane, g1);
@@ -1138,6 +1142,13 @@ __global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArg
     if (on) a.cur_v[el] = v;
   }
   hmc_end_chain<MD>(a, c, lane, ct, L);
+  if (samples && on) samples[((size_t)tt * a.C + c) * a.D + lane] = a.q[el];  // (what this lane holds now)
+  if (lane == 0) {
+    if (acc_hist) acc_hist[(size_t)tt * a.C + c] = a.out.acceptance_probability[c];
+    if (div_hist) div_hist[(size_t)tt * a.C + c] = a.out.is_diverging[c];
+  }
+  __threadfence_block();  // the next transition's lanes read the energy lane 0 has just written
+  }
 }
 
 // ---- new_state / stand-alone building blocks --------------------------------------

@@ -1144,36 +1144,41 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   const bool fused_dense = ctx->opt_fused_hmc && D <= FUSED_DENSE_MAX_D &&
                            (a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN) &&
                            (target_is_elem_host(a.tkind) || a.tkind == AEHMC_T_DENSE_MVN);
-  for (int64_t t = 0; t < T; t++) {
-    if (fused_dense) {
-      const bool md = a.met_ndim == 2, td = a.tkind == AEHMC_T_DENSE_MVN, pc = md && ctx->met.per_chain;
-      EngineArgs b = a;
-      b.linear = 0;  // literal products (metrics.py:71)
-      const size_t dyn = (size_t)((md && !pc ? 2 : 0) + (td ? 1 : 0)) * D * D * sizeof(double);
-      double *imm_ws = nullptr;
-      if (pc)
-        if (int rc = fused_dense_workspace(ctx, (size_t)C * D * D * sizeof(double), &imm_ws)) return rc;
-      const dim3 grid((unsigned)((C + FUSED_DENSE_BLOCK / 64 - 1) / (FUSED_DENSE_BLOCK / 64))), block(FUSED_DENSE_BLOCK);
+  if (fused_dense) {  // all T transitions in one launch
+    const bool md = a.met_ndim == 2, td = a.tkind == AEHMC_T_DENSE_MVN, pc = md && ctx->met.per_chain;
+    EngineArgs b = a;
+    b.linear = 0;  // literal products (metrics.py:71)
+    const size_t dyn = (size_t)((md && !pc ? 2 : 0) + (td ? 1 : 0)) * D * D * sizeof(double);
+    double *imm_ws = nullptr;
+    if (pc)
+      if (int rc = fused_dense_workspace(ctx, (size_t)C * D * D * sizeof(double), &imm_ws)) return rc;
+    const dim3 grid((unsigned)((C + FUSED_DENSE_BLOCK / 64 - 1) / (FUSED_DENSE_BLOCK / 64))), block(FUSED_DENSE_BLOCK);
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
 #define AEHMC_FD_LAUNCH(MDV, TDV, PCV)                                                                         \
   do {                                                                                                         \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_fused_dense<MDV, TDV, PCV>),               \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                         \
-    hipLaunchKernelGGL((k_hmc_fused_dense<MDV, TDV, PCV>), grid, block, dyn, st, b, ctx->tgt.prec, imm_ws, (long long)L); \
+    hipLaunchKernelGGL((k_hmc_fused_dense<MDV, TDV, PCV>), grid, block, dyn, st, b, ctx->tgt.prec, imm_ws,      \
+                       (long long)L, (long long)T, samples, acc_hist, (int *)div_hist);                        \
   } while (0)
-      if (md && td && pc) AEHMC_FD_LAUNCH(true, true, true);
-      else if (md && td) AEHMC_FD_LAUNCH(true, true, false);
-      else if (md && pc) AEHMC_FD_LAUNCH(true, false, true);
-      else if (md) AEHMC_FD_LAUNCH(true, false, false);
-      else AEHMC_FD_LAUNCH(false, true, false);
+    if (md && td && pc) AEHMC_FD_LAUNCH(true, true, true);
+    else if (md && td) AEHMC_FD_LAUNCH(true, true, false);
+    else if (md && pc) AEHMC_FD_LAUNCH(true, false, true);
+    else if (md) AEHMC_FD_LAUNCH(true, false, false);
+    else AEHMC_FD_LAUNCH(false, true, false);
 #undef AEHMC_FD_LAUNCH
-      HIPCHK(hipGetLastError());
-    } else {
+    HIPCHK(hipGetLastError());
+    if (int rc = prof_end(ctx, st, p)) return rc;
+    if (T > 1 && out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
+    return 0;
+  }
+  for (int64_t t = 0; t < T; t++) {
     if (int rc = launch_begin(ctx, a, false, st)) return rc;
     for (int64_t l = 0; l < L; l++)
       if (int rc = launch_leapfrog(ctx, a, false, l == L - 1, st)) return rc;
     if (a.met_ndim == 2) LAUNCH(k_hmc_end<true>, C, st, a, (long long)L);
     else LAUNCH(k_hmc_end<false>, C, st, a, (long long)L);
-    }
     if (samples)
       HIPCHK(hipMemcpyAsync(samples + (size_t)t * C * D, q, (size_t)C * D * sizeof(double),
                             hipMemcpyDeviceToDevice, st));
