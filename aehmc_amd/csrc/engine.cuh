@@ -848,10 +848,9 @@ __device__ __forceinline__ void wave_matvec_lds(const double *MT, const double *
 // Returns the new potential energy; lanes >= D carry don't-care values (never read by the products, masked out
 // of the energy sum).
 template <bool MD, bool TD>
-__device__ __forceinline__ double leap_small_dense(const EngineArgs &a, long long c, int lane, int dir,
+__device__ __forceinline__ double leap_small_dense(const EngineArgs &a, long long c, int lane, double step_size,
                                                    const double *immW, const double *PT, int D, double &q, double &p,
-                                                   double &g) {
-  const double step_size = (dir ? 1.0 : -1.0) * (a.eps_c ? a.eps_c[c] : a.eps);
+                                                   double &g) {  // step_size: signed (direction * eps)
   const double b = 0.5 * step_size, aa = 1 * step_size;
   const bool on = lane < D;
   const long long il = on ? lane : 0;
@@ -1130,8 +1129,9 @@ __global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArg
   const bool on = lane < D;
   const size_t el = row + (on ? lane : 0);
   double q = a.cur_q[el], p = a.cur_p[el], g = a.cur_g[el];
+  const double eps_c = 1.0 * (a.eps_c ? a.eps_c[c] : a.eps);
   for (long long l = 0; l < L; l++)  // trajectory.py:86-95: the whole trajectory in registers
-    ct.U_cur = leap_small_dense<MD, TD>(a, c, lane, 1, immW, PT, D, q, p, g);
+    ct.U_cur = leap_small_dense<MD, TD>(a, c, lane, eps_c, immW, PT, D, q, p, g);
   if (on) {
     a.cur_q[el] = q;
     a.cur_p[el] = p;

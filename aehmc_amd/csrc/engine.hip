@@ -875,7 +875,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     a.linear = 0;  // literal products (metrics.py:71)
     NutsSampleArgs m{};
     m.T = 1;
-    if (multi && multi_done && !multi->adapt) {
+    if (multi && multi_done && (!multi->adapt || (pc && multi->ad.full))) {  // (adaptation in the launch: per-chain dense)
       m = *multi;
       *multi_done = true;
     }
@@ -970,9 +970,11 @@ extern "C" int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64
   // in ONE launch, the chains adapting and moving on at their own pace (nuts_linreg.cuh: every chain;
   // nuts_resident.cuh: every wavefront) -- the same arithmetic as the loop below
   const int path = ctx->has_met ? nuts_path(ctx, C, max_num_expansions) : NUTS_PATH_LOCKSTEP;
-  if (num_steps > 0 && (path == NUTS_PATH_LINREG || path == NUTS_PATH_TEAMS) && !state->full &&
-      (ctx->met.ndim == 1 || (ctx->met.ndim == 0 && D == 1 && path == NUTS_PATH_TEAMS)) &&
-      ctx->met.per_chain) {
+  const bool one_launch_diag = (path == NUTS_PATH_LINREG || path == NUTS_PATH_TEAMS) && !state->full &&
+                               (ctx->met.ndim == 1 || (ctx->met.ndim == 0 && D == 1 && path == NUTS_PATH_TEAMS));
+  // is_mass_matrix_full with D <= 64: the small-dense kernel adapts its chain's matrix itself
+  const bool one_launch_full = path == NUTS_PATH_FUSED_DENSE && state->full && ctx->met.ndim == 2;
+  if (num_steps > 0 && (one_launch_diag || one_launch_full) && ctx->met.per_chain) {
     hipStream_t st = (hipStream_t)stream;
     AdaptArgs aa;
     if (int rc = adapt_args(ctx, C, D, state, aa)) return rc;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK) void k_nu
     kd = 0.0;
     if (DENSE) {  // products between the stages: engine.cuh's leap_small_dense
       double qq = QGET(0), gg = GGET(0);
-      ct.U_cur = leap_small_dense<MD, TD>(a, c, lane, ct.dir, immW, PT, Dd, qq, p[0], gg);
+      ct.U_cur = leap_small_dense<MD, TD>(a, c, lane, step_size, immW, PT, Dd, qq, p[0], gg);
       QSET(0, qq);
       GSET(0, gg);
       if (MD) v0 = wave_matvec_reg(immW, p[0], Dd, lane);  // imm p'
@@ -549,6 +549,46 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK) void k_nu
   if (MULTI && m.adapt) {  // the update of k_adapt_update, same order: step size, Welford, window end, last
     const int stage = m.stage[t_idx], wend = m.window_end[t_idx];
     double step_size = adapt_da_update(da, m.target, ct.acc_prob, m.gamma, m.t0, m.kappa);
+    if (MD && PC) {
+      // is_mass_matrix_full: the arithmetic of k_adapt_update's full branch (algorithms.py:187-197 with np.outer,
+      // mass_matrix.py:83-118), element i of the position in lane i, the D x D Welford sum row by row in memory
+      double *const m2 = m.ad.wc_m2 + (size_t)c * DD;
+      if (stage != 0) {
+        wc_n += 1;
+        double delta = 0.0, ud = 0.0;
+        if (ok[0]) {
+          const double v = AT(a.q, 0);
+          double mean = AT(m.ad.wc_mean, 0);
+          delta = v - mean;
+          mean = mean + delta / (double)wc_n;
+          AT(m.ad.wc_mean, 0) = mean;
+          ud = v - mean;
+        }
+        for (int i = 0; i < Dd; i++) {
+          const double ud_i = read_lane_f64(ud, i);
+          if (ok[0]) m2[i * Dd + lane] = m2[i * Dd + lane] + ud_i * delta;
+        }
+      }
+      if (wend) {
+        const double nn = (double)wc_n;
+        double *const Aw = m.imm_ws + (size_t)c * DD;  // scratch of the factorisation (then the transposed copy again)
+        __threadfence_block();
+        for (int idx = lane; idx < DD; idx += 64) {
+          const double cov = m2[idx] / (double)(wc_n - 1);
+          double im = (nn / (nn + 5)) * cov;
+          if (idx / Dd == idx % Dd) im = im + 1e-3 * (5 / (nn + 5));  // shrinkage * eye
+          m.ad.imm[(size_t)c * DD + idx] = im;  // (== a.imm: the metric bound to this call)
+          Aw[idx] = im;
+          m2[idx] = 0.0;
+        }
+        if (ok[0]) AT(m.ad.wc_mean, 0) = 0.0;
+        __threadfence_block();
+        wave_chol_inv_t(Aw, m.ad.sqrt_mass + (size_t)c * DD, Dd, lane);  // a non-PD estimate leaves NaNs (as the reference)
+        wave_transpose_to(a.imm + (size_t)c * DD, Aw, Dd, lane);
+        wc_n = 0;
+        adapt_da_restart(da, step_size);
+      }
+    } else {
     if (stage != 0) {
       wc_n += 1;
 #pragma unroll
@@ -575,6 +615,7 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK) void k_nu
       wc_n = 0;
       adapt_da_restart(da, step_size);
       __threadfence_block();  // the next momentum draw reads other lanes' sqrt_mass elements
+    }
     }
     if (t_idx == m.T - 1) step_size = exp(da.x_avg);  // window_adaptation.py:184-190
     eps_adapt = step_size;
@@ -623,8 +664,10 @@ inline hipError_t launch_nuts_resident_dense_v(const EngineArgs &a, const NutsSa
                        ((DENSE & RES_DENSE_TARGET) ? 1 : 0);
   const size_t dyn = (size_t)nmat * a.D * a.D * sizeof(double);
   const unsigned grid = (unsigned)((a.C + RES_DENSE_BLOCK / 64 - 1) / (RES_DENSE_BLOCK / 64));
-  const bool multi = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total;
-  if (m.adapt) return hipErrorInvalidValue;  // (the in-launch adaptation is the diagonal one)
+  const bool multi = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total || m.adapt;
+  // in-launch adaptation of dense matrices: one per chain, with the transposed-copy workspace as factorisation scratch
+  if (m.adapt && !((DENSE & RES_DENSE_METRIC) && (DENSE & RES_DENSE_PER_CHAIN) && m.ad.full && m.imm_ws))
+    return hipErrorInvalidValue;
 #define AEHMC_RD(MULTI)                                                                                      \
   do {                                                                                                       \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_resident<64, 1, MULTI, DENSE>), \

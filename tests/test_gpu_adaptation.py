@@ -363,6 +363,33 @@ def test_fused_warmup_equals_step_by_step(full, D, C):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("D,C,steps", [(12, 5, 130), (64, 3, 110), (1, 4, 37), (33, 11, 160)])
+def test_full_matrix_warmup_in_one_launch_equals_step_by_step(D, C, steps):
+    """is_mass_matrix_full with D <= 64 (round 3): the small-dense NUTS kernel runs the whole warm-up in one launch --
+    after each of its transitions a chain updates its dual averaging state and its D x D Welford sum, at a window
+    end forms its matrix, factors it (its transposed-copy workspace is the scratch) and goes on with the new
+    metric.  Dense-precision target.  State, step sizes, matrices, L^-T, the following transition and the
+    generator states equal the step-by-step loop (one launch per transition + k_adapt_update) bit for bit."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    r = np.random.default_rng(7 * D + C)
+    A = r.normal(size=(D, D))
+    prec = np.linalg.inv(A @ A.T / D + np.eye(D))
+    tgt = targets.DenseMVN(r.normal(size=D), 0.5 * (prec + prec.T))
+    q0 = r.normal(size=(C, D))
+    outs = []
+    for fused in (True, False):
+        srng = RandomStream(seeds=[4300 + c for c in range(C)])
+        kernel = nuts.new_kernel(srng, tgt)
+        state = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+        state, (eps, imm), upd = window_adaptation.run(kernel, state, steps, is_mass_matrix_full=True, fused=fused)
+        info, upd = kernel(state, eps, imm)
+        outs.append((state.position.clone(), state.potential_energy.clone(), eps.value.clone(), imm.value.clone(),
+                     imm.sqrt_mass.clone(), info.state.position.clone(), info.n_leapfrog.clone(), upd[srng].clone()))
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), k
+    assert torch.isfinite(outs[0][3]).all() and (outs[0][2] > 0).all()
+
+
 @pytest.mark.parametrize("C,steps", [(6, 130), (9, 37)])
 def test_regression_warmup_in_one_launch_equals_step_by_step(regression_data, C, steps):
     """Regression target, diagonal mass matrix: aehmc_nuts_warmup runs the WHOLE warm-up in one launch of
