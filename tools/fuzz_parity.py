@@ -64,7 +64,7 @@ def one(case):
     thr = float(r.choice([1000.0, 5.0]))
     max_exp, L, T = int(r.choice([10, 6, 2])), int(r.choice([0, 1, 7, 20])), int(r.choice([1, 3]))
     # per-chain step sizes / diagonal metrics (what window adaptation hands back), and sample() instead of calls
-    per_chain = bool((mk == "diag" and r.random() < 0.3) or (mk == "dense" and tk != "linreg" and D <= 130 and r.random() < 0.25))
+    per_chain = bool((mk == "diag" and r.random() < 0.3) or (mk == "dense" and D <= 130 and r.random() < 0.25))
     use_sample = bool(T > 1 and r.random() < 0.5)
     desc = dict(case=case, sampler=sampler, tk=tk, mk=mk, D=D, C=C, eps=eps, thr=thr, max_exp=max_exp, L=L, T=T,
                 per_chain=per_chain, use_sample=use_sample, **opts)
@@ -79,7 +79,13 @@ def one(case):
         dq0 = torch.as_tensor(q0, device="cuda")
         if per_chain:
             eps_c = eps * (0.5 + r.random(C))
-            if mk == "dense":  # every chain its own dense matrix (what is_mass_matrix_full adaptation hands back)
+            if mk == "dense" and tk == "linreg":  # the shared 2 x 2 matrix, rescaled and tilted per chain
+                sc = 0.5 + r.random((C, 1, 1))
+                tilt = 0.3 * (r.random(C) - 0.5)
+                imm_c = np.asarray(imm)[None] * sc
+                imm_c[:, 0, 1] += tilt * np.sqrt(imm_c[:, 0, 0] * imm_c[:, 1, 1])
+                imm_c[:, 1, 0] = imm_c[:, 0, 1]
+            elif mk == "dense":  # every chain its own dense matrix (what is_mass_matrix_full adaptation hands back)
                 Bc = r.normal(size=(C, D, D))
                 imm_c = Bc @ Bc.transpose(0, 2, 1) / D + 0.5 * np.eye(D)
                 imm_c = 0.5 * (imm_c + imm_c.transpose(0, 2, 1))
