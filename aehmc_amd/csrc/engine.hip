@@ -814,8 +814,7 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
-  if (want_resident && D <= FUSED_DENSE_MAX_D && (nd == 2 || tkind == AEHMC_T_DENSE_MVN) &&
-      (target_is_elem_host(tkind) || tkind == AEHMC_T_DENSE_MVN))
+  if (want_resident && nuts_resident_dense_supported(tkind, nd, D))
     return NUTS_PATH_FUSED_DENSE;  // (per-chain dense metrics included: each wavefront reads its own matrices)
   return NUTS_PATH_LOCKSTEP;
 }

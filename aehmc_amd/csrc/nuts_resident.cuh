@@ -656,7 +656,7 @@ inline bool nuts_resident_supported(int tkind, int met_ndim, long long D) {
 
 inline bool nuts_resident_dense_supported(int tkind, int met_ndim, long long D) {
   const bool elem = tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN;
-  return D <= 64 && (met_ndim == 2 || tkind == AEHMC_T_DENSE_MVN) && (elem || tkind == AEHMC_T_DENSE_MVN);
+  return D <= FUSED_DENSE_MAX_D && (met_ndim == 2 || tkind == AEHMC_T_DENSE_MVN) && (elem || tkind == AEHMC_T_DENSE_MVN);
 }
 template <int DENSE>
 inline hipError_t launch_nuts_resident_dense_v(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
