@@ -61,6 +61,8 @@ SYMBOLS = {
                                _P, _P, _P, _P, _P]),
     "aehmc_nuts_warmup": (_I, [_P, _I64, _P, _I64, _P, _P, _D, _I64, _D, _P, _P, _P, ct.POINTER(CDiagnostics),
                                ct.POINTER(CAdaptState), _P]),
+    "aehmc_hmc_warmup": (_I, [_P, _I64, _P, _I64, _P, _P, _D, _I64, _D, _P, _P, _P, ct.POINTER(CDiagnostics),
+                              ct.POINTER(CAdaptState), _P]),
     "aehmc_leapfrog": (_I, [_P, _I64, _D, _I64, _P, _P, _P, _P, _P]),
     "aehmc_kinetic_energy": (_I, [_P, _I64, _P, _P, _P]),
     "aehmc_is_turning": (_I, [_P, _I64, _P, _P, _P, _P, _P]),

@@ -1214,6 +1214,33 @@ extern "C" int aehmc_hmc_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double
                  acceptance_history, divergence_history, (hipStream_t)stream);
 }
 
+// window_adaptation.run around an HMC kernel (window_adaptation.py:66: `kernel(chain_state, *parameters)` with the
+// trajectory length closed over): num_steps x (one HMC transition with the current per-chain parameters, then
+// aehmc_adapt_update), enqueued in one call -- the same kernels in the same order as the caller's own loop
+extern "C" int aehmc_hmc_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t num_steps, const int32_t *stage,
+                                const int32_t *is_window_end, double target_acceptance_rate,
+                                int64_t num_integration_steps, double divergence_threshold, double *q, double *U,
+                                double *g, const aehmc_diagnostics *out, const aehmc_adapt_state *state,
+                                void *stream) {
+  if (!ctx || !out || !state || !stage || !is_window_end) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->has_tgt) FAIL("set_target and set_metric must be called first");
+  if (!ctx->eps_c || !ctx->met.per_chain) FAIL("warm-up needs per-chain step sizes and a per-chain metric bound to the adaptation state");
+  if (ctx->met.imm != state->imm || ctx->met.sqrt_mass != state->sqrt_mass || ctx->eps_c != state->step_size)
+    FAIL("warm-up: the bound per-chain metric / step sizes are not the adaptation state's own arrays "
+         "(bind state->imm, state->sqrt_mass with aehmc_set_metric and state->step_size with aehmc_set_step_sizes)");
+  const int64_t D = ctx->tgt.D;
+  for (int64_t i = 0; i < num_steps; i++) {
+    if (int rc = hmc_run(ctx, C, rng, 0.0, num_integration_steps, divergence_threshold, 1, q, U, g, out, nullptr,
+                         nullptr, nullptr, (hipStream_t)stream))
+      return rc;
+    if (int rc = aehmc_adapt_update(ctx, C, D, stage[i], is_window_end[i], i == num_steps - 1,
+                                    target_acceptance_rate, out->acceptance_probability, q, state, stream))
+      return rc;
+  }
+  return 0;
+}
+
 extern "C" int aehmc_leapfrog(aehmc_ctx *ctx, int64_t C, double step_size, int64_t nsteps, double *q,
                               double *p, double *U, double *g, void *stream) {
   if (!ctx) return -2;

@@ -356,6 +356,22 @@ class Engine:
                         ct.byref(c), ct.byref(cstate), self.stream)
         return out
 
+    def hmc_warmup(self, rng, schedule, target_accept, L, thr, q, U, g, st, cstate, imm_param):
+        """window_adaptation.run around an HMC kernel in one C-ABI call (no Python between warm-up steps)."""
+        C, D = q.shape
+        out, c = self._diag(C, D, False)
+        n = len(schedule)
+        stage = (ct.c_int32 * n)(*[int(s) for s, _ in schedule])
+        wend = (ct.c_int32 * n)(*[int(bool(e)) for _, e in schedule])
+        self.set_metric(imm_param, D)
+        self.ensure_workspace(C, 1)
+        self._keep["eps"] = st["step_size"]
+        self._check(self.lib.aehmc_set_step_sizes(self.ctx, st["step_size"].data_ptr(), C), "aehmc_set_step_sizes")
+        self._step_call(self.lib.aehmc_hmc_warmup, "aehmc_hmc_warmup", self.ctx, C, rng.data_ptr(), n, stage, wend,
+                        float(target_accept), int(L), float(thr), q.data_ptr(), U.data_ptr(), g.data_ptr(),
+                        ct.byref(c), ct.byref(cstate), self.stream)
+        return out
+
     def leapfrog(self, eps, nsteps, q, p, U, g):
         C, D = q.shape
         self.ensure_workspace(C, 1)

@@ -62,5 +62,6 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
 
     step.sample = sample
     step.num_chains, step.batched = srng.num_chains, srng.batched
-    step._hmc = dict(srng=srng, rng_host=rng_host, holder=holder)  # (the device RNG state, for tests / resuming)
+    step._hmc = dict(srng=srng, rng_host=rng_host, holder=holder, logprob_fn=logprob_fn,  # (for tests / resuming /
+                     divergence_threshold=float(divergence_threshold))                    #  the one-call warm-up)
     return step

@@ -44,8 +44,8 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     step size and one (diagonal or dense) inverse mass matrix per chain, exactly as running the
     reference once per chain would produce -- to be passed back to ``kernel``.
 
-    With a NUTS kernel of this package the whole loop runs inside one C-ABI call
-    (``aehmc_nuts_warmup``: transition, adaptation update, transition, ... enqueued back to back);
+    With a NUTS or HMC kernel of this package the whole loop runs inside one C-ABI call
+    (``aehmc_nuts_warmup`` / ``aehmc_hmc_warmup``: transition, adaptation update, transition, ... enqueued back to back);
     ``fused=False`` -- and any other kernel -- takes the step-by-step loop below, which issues the
     same kernels in the same order (identical results).
 
@@ -86,6 +86,19 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
                               nk["max_num_expansions"], nk["divergence_threshold"], q, U, g, st, cst, imm_param())
         info = diagnostics(layout, q, U, g, out, True)
         state, updates = info.state._replace(momentum=None), {nk["srng"]: nk["holder"]["rng"]}
+        schedule = []
+    elif fused and getattr(kernel, "_hmc", None) is not None and len(schedule) > 0:
+        from ._common import diagnostics, state_rows
+        from .engine import rng_to_device
+        hk = kernel._hmc
+        if "rng" not in hk["holder"]:
+            hk["holder"]["rng"] = rng_to_device(hk["rng_host"], eng.device)
+        q, U, g = state_rows(initial_state, layout, eng.device)
+        eng.set_target(hk["logprob_fn"], D)
+        out = eng.hmc_warmup(hk["holder"]["rng"], schedule, float(target_acceptance_rate), extra[0],
+                             hk["divergence_threshold"], q, U, g, st, cst, imm_param())
+        info = diagnostics(layout, q, U, g, out, False)
+        state, updates = info.state._replace(momentum=None), {hk["srng"]: hk["holder"]["rng"]}
         schedule = []
     else:
         state, updates = initial_state, {}

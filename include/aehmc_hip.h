@@ -222,6 +222,15 @@ int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t num_step
                       int64_t max_num_expansions, double divergence_threshold, double *q, double *U,
                       double *g, const aehmc_diagnostics *out, const aehmc_adapt_state *state, void *stream);
 
+/* The same loop around an HMC kernel (the reference's run() calls `kernel(chain_state, *parameters)`,
+ * window_adaptation.py:66, so there an HMC kernel is wrapped in a function that closes over the trajectory length
+ * num_integration_steps): num_steps x (one HMC transition with the current per-chain parameters, then
+ * aehmc_adapt_update).  Same binding rules, same `stage` / `is_window_end` host arrays as aehmc_nuts_warmup. */
+int aehmc_hmc_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t num_steps, const int32_t *stage,
+                     const int32_t *is_window_end, double target_acceptance_rate, int64_t num_integration_steps,
+                     double divergence_threshold, double *q, double *U, double *g, const aehmc_diagnostics *out,
+                     const aehmc_adapt_state *state, void *stream);
+
 /* num_samples consecutive NUTS transitions per chain (the user-level scan of
  * tests/test_hmc.py:296-324); same optional outputs as aehmc_hmc_sample plus the per-chain
  * leapfrog total [C].  `out` describes the last transition.  (Regression target and register-resident

@@ -138,6 +138,41 @@ def test_window_adaptation_of_an_hmc_kernel():
     np.testing.assert_allclose(var, sigma ** 2, rtol=0.35)
 
 
+@pytest.mark.parametrize("tk,D,C,full", [("diag", 3, 9, False), ("diag", 700, 3, False), ("dense", 12, 5, True),
+                                         ("dense", 70, 4, False), ("diag", 1500, 2, False)])
+def test_hmc_warmup_in_one_call_equals_step_by_step(tk, D, C, full):
+    """aehmc_hmc_warmup (round 3) enqueues the warm-up loop of an HMC kernel -- transition, aehmc_adapt_update,
+    transition, ... -- in one C-ABI call: state, step sizes, matrices, the following transition and the generator
+    states equal window_adaptation.run(fused=False), the caller-side loop, bit for bit (register-resident, wide,
+    small-dense and lock-step HMC paths)."""
+    from aehmc_amd import RandomStream, hmc, targets, window_adaptation
+    r = np.random.default_rng(D + C)
+    if tk == "dense":
+        A = r.normal(size=(D, D))
+        prec = np.linalg.inv(A @ A.T / D + np.eye(D))
+        tgt = targets.DenseMVN(r.normal(size=D), 0.5 * (prec + prec.T))
+        q0 = r.normal(size=(C, D))
+    else:
+        mu, sigma = r.normal(size=D), 0.5 + r.random(D)
+        tgt = targets.DiagGaussian(mu, sigma)
+        q0 = mu + sigma * r.normal(size=(C, D))
+    outs = []
+    for fused in (True, False):
+        srng = RandomStream(seeds=[800 + c for c in range(C)])
+        kernel = hmc.new_kernel(srng, tgt)
+        state = hmc.new_state(torch.as_tensor(q0, device="cuda"), tgt)
+        state, (eps, imm), upd = window_adaptation.run(kernel, state, 120, is_mass_matrix_full=full, fused=fused,
+                                                       num_integration_steps=6)
+        assert torch.equal(upd[srng], kernel._hmc["holder"]["rng"])
+        info, upd = kernel(state, eps, imm, 6)
+        outs.append((state.position.clone(), state.potential_energy.clone(), eps.value.clone(), imm.value.clone(),
+                     imm.sqrt_mass.clone(), info.state.position.clone(), info.acceptance_probability.clone(),
+                     upd[srng].clone()))
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), k
+    assert torch.isfinite(outs[0][3]).all() and (outs[0][2] > 0).all()
+
+
 def test_target_parameters_are_keyed_by_content():
     """A numpy parameter edited in place between two calls must be seen (the reference re-reads its graph
     inputs on every call); the same content under another object must not re-upload."""
