@@ -839,7 +839,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   if (nuts_path(ctx, C, max_num_expansions) == NUTS_PATH_LINREG) {
     NutsSampleArgs m{};
     m.T = 1;
-    if (multi && multi_done) {
+    if (multi && multi_done && !(multi->adapt && a.met_ndim == 2 && !(multi->ad.full && ctx->met.per_chain))) {
       m = *multi;
       *multi_done = true;
     }
@@ -972,7 +972,9 @@ extern "C" int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64
   const bool one_launch_diag = (path == NUTS_PATH_LINREG || path == NUTS_PATH_TEAMS) && !state->full &&
                                (ctx->met.ndim == 1 || (ctx->met.ndim == 0 && D == 1 && path == NUTS_PATH_TEAMS));
   // is_mass_matrix_full with D <= 64: the small-dense kernel adapts its chain's matrix itself
-  const bool one_launch_full = path == NUTS_PATH_FUSED_DENSE && state->full && ctx->met.ndim == 2;
+  // (and the regression kernel its chain's 2 x 2 matrix)
+  const bool one_launch_full = (path == NUTS_PATH_FUSED_DENSE || path == NUTS_PATH_LINREG) && state->full &&
+                               ctx->met.ndim == 2;
   if (num_steps > 0 && (one_launch_diag || one_launch_full) && ctx->met.per_chain) {
     hipStream_t st = (hipStream_t)stream;
     AdaptArgs aa;

@@ -22,7 +22,12 @@
 // parameters -- early warm-up trees range from 1 to 1023 leapfrogs, which is where not waiting
 // for the slowest chain pays most.
 //
-// Diagonal / scalar metric (shared or per chain).  Arithmetic and its order are those of nuts_book
+// Diagonal / scalar metric (shared or per chain); DM instantiation (round 3): a dense 2 x 2 inverse mass matrix,
+// shared or one per chain (what is_mass_matrix_full adaptation of this example hands back) -- row `lane` of the
+// matrix and of L^-T in two registers, velocities formed literally (metrics.py:71: M[i][0] p0 + M[i][1] p1, the
+// order of the per-chain products of the lock-step path); with m.adapt the chain adapts its full 2 x 2 matrix in
+// the launch: the arithmetic of k_adapt_update's full branch and of wave_chol_inv_t written out for D = 2.
+// Arithmetic and its order are those of nuts_book
 // (engine.cuh) / k_nuts_resident; reference: nuts.py:56-153, trajectory.py:154-374,428-714,
 // termination.py:85-235, proposals.py:19-174, integrators.py:54-73, metrics.py:44-104.
 #pragma once
@@ -47,6 +52,7 @@ namespace aehmc {
 constexpr int NUTS_LINREG_MAX_EXP = 32;  // checkpoint levels that fit the lanes of a wavefront
 constexpr long long NUTS_LINREG_LDS_ROWS = 10176;  // rows kept in LDS (2 x 8 B each, next to ~1 KB static)
 
+template <bool DM>
 __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSampleArgs m) {
   __shared__ double lr_w[4], lr_part[LR_WAVES][8];
   __shared__ int lr_fin[4];
@@ -70,23 +76,32 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
   double end_q[2], end_p[2], end_g[2], slot_q[2], slot_p[2], slot_g[2], psum = 0.0;
   double ckp = 0.0, cks = 0.0;                 // checkpoints: level i, element e in lane 2 i + e
   double imr = 1.0, smr = 0.0, eps = 0.0;
+  double im0 = 0.0, im1 = 0.0, sm0 = 0.0, sm1 = 0.0;  // DM: row `lane` of the inverse mass matrix and of L^-T
+  // velocity element `lane` of the momentum whose elements sit in lanes 0, 1 of pv (metrics.py:71)
+  auto vel = [&](double pv) -> double {
+    if (!DM) return imr * pv;
+    const double p0 = read_lane_f64(pv, 0), p1 = read_lane_f64(pv, 1);
+    return im0 * p0 + im1 * p1;
+  };
   ChainRng rng = {};
   ChainCtl ct = {};
   long long t_idx = 0, nleap_sum = 0;
   DualAvg da = {1, 0.0, 0.0, 0.0, 0.0};  // warm-up state of the chain (m.adapt)
   long long wc_n = 0;
   double wmean = 0.0, wm2 = 0.0;
+  double wm2_0 = 0.0, wm2_1 = 0.0;  // DM: row `lane` of the 2 x 2 Welford sum
 #pragma unroll
   for (int s = 0; s < 2; s++) end_q[s] = end_p[s] = end_g[s] = slot_q[s] = slot_p[s] = slot_g[s] = 0.0;
 
   // ---- nuts.py:113-125: momentum (site #1, metrics.py:65-68), initial energy, fresh tree --------
   auto begin_transition = [&]() {
     const double z0 = rng_standard_normal(rng.g[0]), z1 = rng_standard_normal(rng.g[0]);
-    p = el ? smr * (lane == 0 ? z0 : z1) : 0.0;
+    p = el ? (DM ? sm0 * z0 + sm1 * z1 : smr * (lane == 0 ? z0 : z1)) : 0.0;  // metrics.py:66-67: L^-T z
     q = sq;
     g = sg;
     pb = 0.0;
-    const double kd = sum2(el ? (imr * p) * p : 0.0);
+    const double v_init = vel(p);
+    const double kd = sum2(el ? v_init * p : 0.0);
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       end_q[s] = q;
@@ -120,8 +135,16 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
     if (el) {
       sq = a.q[c * 2 + lane];
       sg = a.g[c * 2 + lane];
-      imr = a.imm[imo + (a.met_ndim == 0 ? 0 : lane)];
-      smr = a.sqrt_mass[imo + (a.met_ndim == 0 ? 0 : lane)];
+      if (DM) {  // [2, 2] shared, or [C, 2, 2]
+        const size_t mo = a.imm_cs ? (size_t)c * 4 : 0;
+        im0 = a.imm[mo + 2 * lane];
+        im1 = a.imm[mo + 2 * lane + 1];
+        sm0 = a.sqrt_mass[mo + 2 * lane];
+        sm1 = a.sqrt_mass[mo + 2 * lane + 1];
+      } else {
+        imr = a.imm[imo + (a.met_ndim == 0 ? 0 : lane)];
+        smr = a.sqrt_mass[imo + (a.met_ndim == 0 ? 0 : lane)];
+      }
     }
     U_state = a.U[c];
     eps = a.eps_c ? a.eps_c[c] : a.eps;
@@ -134,7 +157,12 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
       wc_n = m.ad.wc_n[c];
       if (el) {
         wmean = m.ad.wc_mean[c * 2 + lane];
-        wm2 = m.ad.wc_m2[c * 2 + lane];
+        if (DM) {
+          wm2_0 = m.ad.wc_m2[c * 4 + 2 * lane];
+          wm2_1 = m.ad.wc_m2[c * 4 + 2 * lane + 1];
+        } else {
+          wm2 = m.ad.wc_m2[c * 2 + lane];
+        }
       }
     }
     rng = rng_load(a, c);
@@ -149,7 +177,14 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
     // ---- one leapfrog of the moving end (integrators.py:54-73), first half ------------------
     const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
     const double b = 0.5 * step_size, aa = 1 * step_size;
-    if (!fin && el) {
+    if (DM) {
+      const double pp = p - b * g;
+      const double vh = vel(pp);  // (both elements of p_half are needed: outside the lane mask)
+      if (!fin && el) {
+        q = q + aa * vh;
+        p = pp;
+      }
+    } else if (!fin && el) {
       const double pp = p - b * g;
       q = q + aa * (imr * pp);
       p = pp;
@@ -207,7 +242,11 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
         const double pp = p - b * gg;
         g = gg;
         p = pp;
-        kl = (imr * pp) * pp;
+        if (!DM) kl = (imr * pp) * pp;
+      }
+      if (DM) {
+        const double vn = vel(p);
+        kl = el ? vn * p : 0.0;
       }
       kd = sum2(kl);
     }
@@ -264,9 +303,10 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
         for (;;) {
           const double pl = __shfl(ckp, 2 * idx + e), ks = __shfl(cks, 2 * idx + e);
           double dl = 0.0, dr = 0.0;
+          const double vl_d = DM ? vel(pl) : 0.0, vr_d = DM ? vel(p) : 0.0;
           if (el) {
             const double pr = p;
-            const double vl = imr * pl, vr = imr * pr;
+            const double vl = DM ? vl_d : imr * pl, vr = DM ? vr_d : imr * pr;
             const double sub = pb - ks + pl;
             const double rho = sub - (pr + pl) / 2;
             dl = vl * rho;
@@ -315,7 +355,7 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
       double dl = 0.0, dr = 0.0;
       {
         const double pc = p, po = pick2(end_p, oth);
-        const double vc = imr * pc, vo = imr * po;
+        const double vc = vel(pc), vo = vel(po);
         const double s = psum + pb;
         psum = s;
         const double pl = dir ? po : pc, pr = dir ? pc : po;
@@ -396,6 +436,44 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
       if (m.adapt) {  // the update of k_adapt_update, same order: step size, Welford, window end, last
         const int stage = m.stage[t_idx], wend = m.window_end[t_idx];
         double step_size = adapt_da_update(da, m.target, ct.acc_prob, m.gamma, m.t0, m.kappa);
+        if (DM) {
+          // full 2 x 2 covariance: k_adapt_update's full branch (algorithms.py:187-197 with np.outer,
+          // mass_matrix.py:83-118) and wave_chol_inv_t (metrics.py:56-58) written out for D = 2, row `lane` per lane
+          if (stage != 0) {
+            wc_n += 1;
+            double delta = 0.0, ud = 0.0;
+            if (el) {
+              delta = sq - wmean;
+              wmean = wmean + delta / (double)wc_n;
+              ud = sq - wmean;
+            }
+            const double d0 = read_lane_f64(delta, 0), d1 = read_lane_f64(delta, 1);
+            wm2_0 = wm2_0 + ud * d0;
+            wm2_1 = wm2_1 + ud * d1;
+          }
+          if (wend) {
+            const double nn = (double)wc_n;
+            double c0 = wm2_0 / (double)(wc_n - 1), c1 = wm2_1 / (double)(wc_n - 1);
+            im0 = (nn / (nn + 5)) * c0;
+            im1 = (nn / (nn + 5)) * c1;
+            if (lane == 0) im0 = im0 + 1e-3 * (5 / (nn + 5));  // shrinkage * eye
+            if (lane == 1) im1 = im1 + 1e-3 * (5 / (nn + 5));
+            wm2_0 = wm2_1 = 0.0;
+            wmean = 0.0;
+            // L = chol(imm) from its lower triangle, S = L^-T (the column-by-column forward substitution for D = 2)
+            const double a00 = read_lane_f64(im0, 0), a10 = read_lane_f64(im0, 1), a11 = read_lane_f64(im1, 1);
+            const double l00 = sqrt(a00);
+            const double l10 = a10 / l00;
+            const double l11 = sqrt(a11 - l10 * l10);
+            const double s00 = 1.0 / l00;
+            const double s01 = (0.0 - l10 * s00) / l11;
+            const double s11 = 1.0 / l11;
+            sm0 = lane == 0 ? s00 : 0.0;
+            sm1 = lane == 0 ? s01 : s11;
+            wc_n = 0;
+            adapt_da_restart(da, step_size);
+          }
+        } else {
         if (stage != 0) {
           wc_n += 1;
           if (el) adapt_welford_elem(sq, wc_n, wmean, wm2);
@@ -404,6 +482,7 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
           if (el) adapt_window_end_elem(wc_n, wmean, wm2, imr, smr);
           wc_n = 0;
           adapt_da_restart(da, step_size);
+        }
         }
         if (t_idx == m.T - 1) step_size = exp(da.x_avg);  // window_adaptation.py:184-190
         eps = step_size;
@@ -415,7 +494,15 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
           a.q[c * 2 + lane] = sq;
           a.g[c * 2 + lane] = sg;
           if (a.out.momentum) a.out.momentum[c * 2 + lane] = sp;
-          if (m.adapt) {
+          if (m.adapt && DM) {
+            m.ad.wc_mean[c * 2 + lane] = wmean;
+            m.ad.wc_m2[c * 4 + 2 * lane] = wm2_0;
+            m.ad.wc_m2[c * 4 + 2 * lane + 1] = wm2_1;
+            m.ad.imm[c * 4 + 2 * lane] = im0;
+            m.ad.imm[c * 4 + 2 * lane + 1] = im1;
+            m.ad.sqrt_mass[c * 4 + 2 * lane] = sm0;
+            m.ad.sqrt_mass[c * 4 + 2 * lane + 1] = sm1;
+          } else if (m.adapt) {
             m.ad.wc_mean[c * 2 + lane] = wmean;
             m.ad.wc_m2[c * 2 + lane] = wm2;
             m.ad.imm[c * 2 + lane] = imr;
@@ -458,16 +545,24 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
 }
 
 inline bool nuts_linreg_supported(int tkind, int met_ndim, long long D, long long max_exp) {
-  return tkind == AEHMC_T_LINREG && met_ndim < 2 && D == 2 && max_exp <= NUTS_LINREG_MAX_EXP;
+  return tkind == AEHMC_T_LINREG && met_ndim <= 2 && D == 2 && max_exp <= NUTS_LINREG_MAX_EXP;
 }
 
 inline hipError_t launch_nuts_linreg(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
   const unsigned grid = (unsigned)((a.C + 3) / 4);
   const size_t dyn = (size_t)2 * (a.N <= NUTS_LINREG_LDS_ROWS ? a.N : NUTS_LINREG_LDS_ROWS) * sizeof(double);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_linreg),
+  if (a.met_ndim == 2) {
+    if (m.adapt && !(m.ad.full && a.imm_cs)) return hipErrorInvalidValue;  // (adaptation: one matrix per chain)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_linreg<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_nuts_linreg<true>, dim3(grid), dim3(LR_BLOCK), dyn, st, a, m);
+    return hipGetLastError();
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_linreg<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_nuts_linreg, dim3(grid), dim3(LR_BLOCK), dyn, st, a, m);
+  hipLaunchKernelGGL(k_nuts_linreg<false>, dim3(grid), dim3(LR_BLOCK), dyn, st, a, m);
   return hipGetLastError();
 }
 

@@ -215,7 +215,7 @@ int aehmc_dual_averaging_update(aehmc_ctx *ctx, int64_t C, double target_accepta
  * `out` receives the diagnostics of the last warm-up transition.  Diagonal mass matrix with the
  * regression target, or with a coordinate-wise target of D <= 512 on the register-resident kernel,
  * and a full mass matrix per chain (state->full) with D <= 64 and a coordinate-wise or dense-precision
- * target: the whole warm-up is ONE launch in which the chains adapt and move on at their own pace
+ * target, or with the regression target: the whole warm-up is ONE launch in which the chains adapt and move on at their own pace
  * (same arithmetic, same results as the loop). */
 int aehmc_nuts_warmup(aehmc_ctx *ctx, int64_t C, uint64_t *rng, int64_t num_steps, const int32_t *stage,
                       const int32_t *is_window_end, double target_acceptance_rate,

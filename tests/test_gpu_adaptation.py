@@ -390,13 +390,14 @@ def test_full_matrix_warmup_in_one_launch_equals_step_by_step(D, C, steps):
     assert torch.isfinite(outs[0][3]).all() and (outs[0][2] > 0).all()
 
 
-@pytest.mark.parametrize("C,steps", [(6, 130), (9, 37)])
-def test_regression_warmup_in_one_launch_equals_step_by_step(regression_data, C, steps):
-    """Regression target, diagonal mass matrix: aehmc_nuts_warmup runs the WHOLE warm-up in one launch of
-    k_nuts_linreg -- every chain applies its own adaptation update after each of its transitions and
-    goes on without waiting for the others.  State, step sizes, inverse mass matrix, its square root,
-    the following transition and the RNG state equal the step-by-step loop (one launch per transition
-    plus k_adapt_update) bit for bit.  37 steps: a schedule without a slow window."""
+@pytest.mark.parametrize("C,steps,full", [(6, 130, False), (9, 37, False), (6, 130, True), (9, 160, True), (3, 37, True)])
+def test_regression_warmup_in_one_launch_equals_step_by_step(regression_data, C, steps, full):
+    """Regression target, diagonal mass matrix -- or (round 3) is_mass_matrix_full, one dense 2 x 2 matrix per
+    chain: aehmc_nuts_warmup runs the WHOLE warm-up in one launch of k_nuts_linreg -- every chain applies its own
+    adaptation update after each of its transitions and goes on without waiting for the others.  State, step
+    sizes, inverse mass matrix, its square root / L^-T, the following transition and the RNG state equal the
+    step-by-step loop (one launch per transition plus k_adapt_update, whose full branch factors with the general
+    wave_chol_inv_t) bit for bit.  37 steps: a schedule without a slow window."""
     from aehmc_amd import RandomStream, nuts, targets, window_adaptation
     X, y = regression_data
     r = np.random.default_rng(C)
@@ -407,7 +408,8 @@ def test_regression_warmup_in_one_launch_equals_step_by_step(regression_data, C,
         srng = RandomStream(seeds=[700 + c for c in range(C)])
         kernel = nuts.new_kernel(srng, tgt)
         state = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
-        state, (eps, imm), upd = window_adaptation.run(kernel, state, steps, fused=fused)
+        state, (eps, imm), upd = window_adaptation.run(kernel, state, steps, fused=fused, is_mass_matrix_full=full)
+        assert tuple(imm.value.shape) == ((C, 2, 2) if full else (C, 2))
         info, upd = kernel(state, eps, imm)
         outs.append((state.position.clone(), state.potential_energy.clone(), state.potential_energy_grad.clone(),
                      eps.value.clone(), imm.value.clone(), imm.sqrt_mass.clone(),
