@@ -269,12 +269,13 @@ def test_regression_nuts_matches_oracle(eng, regression_data, metric_kind, C, re
 
 
 @pytest.mark.parametrize("N,metric_kind,max_exp", [(37, "diag", 10), (10177, "scalar", 10), (30001, "diag", 10),
-                                                  (30001, "diag", 2), (12288, "diag", 10)])
+                                                  (30001, "diag", 2), (12288, "diag", 10), (10177, "dense", 10),
+                                                  (30001, "dense", 10)])
 def test_regression_nuts_row_counts_match_oracle(eng, N, metric_kind, max_exp):
     """k_nuts_linreg over the row-count regimes of its sweep: fewer rows than threads (37), all rows in
     LDS (<= 10176), LDS rows + streamed blocks + an odd tail (30001), LDS rows + whole blocks only
-    (12288 = 10176 + 2112: one 512-piece block per wave short of 8 waves), a scalar metric, and a
-    tree cut by max_num_expansions.  Row-wise noise so that the posterior has a real width."""
+    (12288 = 10176 + 2112: one 512-piece block per wave short of 8 waves), a scalar metric, a dense 2 x 2 metric
+    and a tree cut by max_num_expansions.  Row-wise noise so that the posterior has a real width."""
     from aehmc_amd import RandomStream, nuts, targets
     r = np.random.default_rng(N)
     X = r.normal(size=N)
@@ -282,6 +283,8 @@ def test_regression_nuts_row_counts_match_oracle(eng, N, metric_kind, max_exp):
     tgt, otgt = targets.LinearRegression(X, y), co.Target(co.T_LINREG, 2, X=X, y=y)
     C = 5
     imm = np.float64(1.0 / N) if metric_kind == "scalar" else np.array([1.0 / N, 0.5 / N])
+    if metric_kind == "dense":  # k_nuts_linreg<DM> (round 3): a full 2 x 2 inverse mass matrix
+        imm = np.array([[1.0 / N, 0.22 / N], [0.22 / N, 0.5 / N]])
     eps = 0.5
     seeds = [31 + c for c in range(C)]
     q0 = np.array([3.0, np.log(0.5)]) + 0.02 * r.normal(size=(C, 2))
