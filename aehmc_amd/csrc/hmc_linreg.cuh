@@ -10,6 +10,8 @@
 // every leapfrog of every transition; otherwise they stream from L2 through the LDS-DMA ring of
 // the NUTS kernel (config c5's 1e5 rows).  Two barriers per leapfrog.
 //
+// Diagonal / scalar metric, or (round 3) a dense 2 x 2 inverse mass matrix, shared or one per chain: row `lane` of
+// the matrix and of L^-T in two registers, velocities formed literally (metrics.py:71), as in k_nuts_linreg<DM>.
 // Same arithmetic as the lock-step path except for the order of the row sums (1e-13).
 // Reference: hmc.py:77-124,157-204, trajectory.py:31-107, integrators.py:54-73, metrics.py:44-73.
 #pragma once
@@ -44,11 +46,27 @@ __global__ __launch_bounds__(LR_BLOCK) void k_hmc_linreg(HmcFusedArgs a) {
     __syncthreads();
   }
   double q = 0.0, g = 0.0, im = 1.0, sm = 1.0, U = 0.0, eps = 0.0;
+  double im0 = 0.0, im1 = 0.0, sm0 = 0.0, sm1 = 0.0;  // dense metric: row `lane` of the matrix and of L^-T
+  const bool dm = a.met_ndim == 2;                     // (a kernel argument: wave-uniform)
+  // velocity element `lane` of the momentum whose elements sit in lanes 0, 1 of pv
+  auto vel = [&](double pv) -> double {
+    if (!dm) return im * pv;
+    const double pv0 = read_lane_f64(pv, 0), pv1 = read_lane_f64(pv, 1);
+    return im0 * pv0 + im1 * pv1;
+  };
   Pcg64 g1{}, g2{};
   if (!ghost) {
-    const size_t mo = (size_t)c * a.imm_cs + (a.met_ndim == 0 ? 0 : (lane < 2 ? lane : 0));
-    im = a.imm[mo];
-    sm = a.sqrt_mass[mo];
+    if (dm) {  // [2, 2] shared, or [C, 2, 2]
+      const size_t mo = (a.imm_cs ? (size_t)c * 4 : 0) + 2 * (lane < 2 ? lane : 0);
+      im0 = a.imm[mo];
+      im1 = a.imm[mo + 1];
+      sm0 = a.sqrt_mass[mo];
+      sm1 = a.sqrt_mass[mo + 1];
+    } else {
+      const size_t mo = (size_t)c * a.imm_cs + (a.met_ndim == 0 ? 0 : (lane < 2 ? lane : 0));
+      im = a.imm[mo];
+      sm = a.sqrt_mass[mo];
+    }
     q = ok ? a.q[c * 2 + lane] : 0.0;
     g = ok ? a.g[c * 2 + lane] : 0.0;
     U = a.U[c];
@@ -65,13 +83,21 @@ __global__ __launch_bounds__(LR_BLOCK) void k_hmc_linreg(HmcFusedArgs a) {
     const double qs = q, gs = g;
     if (!ghost) {  // metrics.py:65-68: z ~ normal(size=2), two consecutive draws of site #1
       const double z0 = rng_standard_normal(g1), z1 = rng_standard_normal(g1);
-      p = ok ? sm * (lane == 0 ? z0 : z1) : 0.0;
+      p = ok ? (dm ? sm0 * z0 + sm1 * z1 : sm * (lane == 0 ? z0 : z1)) : 0.0;
       p0 = p;
-      kd = wave_sum(ok ? (im * p) * p : 0.0);
+      const double v_init = vel(p);
+      kd = wave_sum(ok ? v_init * p : 0.0);
     }
     const double H0 = U + 0.5 * kd;  // hmc.py:187
     for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
-      if (ok) {
+      if (dm) {
+        const double ph = p - b * g;
+        const double vh = vel(ph);  // (both elements of p_half: outside the lane mask)
+        if (ok) {
+          p = ph;
+          q = q + aa * vh;
+        }
+      } else if (ok) {
         p = p - b * g;
         q = q + aa * (im * p);
       }
@@ -130,7 +156,8 @@ __global__ __launch_bounds__(LR_BLOCK) void k_hmc_linreg(HmcFusedArgs a) {
     }
     if (!ghost) {
       const double pf = -1.0 * p;  // hmc.py:185
-      kd = wave_sum(ok ? (im * pf) * pf : 0.0);
+      const double v_fin = vel(pf);
+      kd = wave_sum(ok ? v_fin * pf : 0.0);
       if (a.L == 0) Unew = U;
       double delta = H0 - (Unew + 0.5 * kd);
       if (isnan(delta)) delta = -INFINITY;
@@ -170,7 +197,7 @@ __global__ __launch_bounds__(LR_BLOCK) void k_hmc_linreg(HmcFusedArgs a) {
 }
 
 inline bool hmc_linreg_supported(int tkind, int met_ndim, long long D) {
-  return tkind == AEHMC_T_LINREG && met_ndim < 2 && D == 2;
+  return tkind == AEHMC_T_LINREG && met_ndim <= 2 && D == 2;
 }
 template <bool RES, int K>
 inline hipError_t launch_hmc_linreg_k(const HmcFusedArgs &a, hipStream_t st) {

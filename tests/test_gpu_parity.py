@@ -197,18 +197,23 @@ def test_g2_g3_regression_on_gpu(regression_data):
     assert info.acceptance_probability.item() == 1.0 and not info.is_diverging.item()
 
 
-@pytest.mark.parametrize("N,C,L", [(10_000, 1, 64), (10_000, 6, 33), (10_176, 9, 20), (10_177, 5, 20), (25_001, 7, 12), (700, 4, 50)])
-def test_regression_hmc_fused_matches_oracle(eng, N, C, L):
+@pytest.mark.parametrize("N,C,L,mk", [(10_000, 1, 64, "diag"), (10_000, 6, 33, "diag"), (10_176, 9, 20, "diag"),
+                                      (10_177, 5, 20, "diag"), (25_001, 7, 12, "diag"), (700, 4, 50, "diag"),
+                                      (10_000, 1, 64, "dense"), (10_177, 5, 20, "dense"), (700, 6, 50, "dense")])
+def test_regression_hmc_fused_matches_oracle(eng, N, C, L, mk):
     """HMC on the regression target in one launch (hmc_linreg.cuh): rows resident in LDS (N <= 10176)
     or streamed by direct loads (N above), workgroups with 1..4 live chains, three consecutive
     transitions through kernel.sample -- against the oracle, and against the lock-step path
-    (`fused_hmc` = 0), which differs in the order of the row sums only."""
+    (`fused_hmc` = 0), which differs in the order of the row sums only (dense 2 x 2 metric, round 3: and in the
+    products, an MFMA GEMM there)."""
     from aehmc_amd import PerChain, RandomStream, hmc, targets
     r = np.random.default_rng(N + C)
     X = r.normal(0, 1, size=N)
     y = 3 * X + 0.5 * r.normal(0, 1, size=N)  # (row-wise noise: a well-conditioned posterior for any N)
     tgt, otgt = targets.LinearRegression(X, y), co.Target(co.T_LINREG, 2, X=X, y=y)
     imm = np.array([0.25 / N, 0.5 / N])  # ~ posterior variances of w and log n
+    if mk == "dense":
+        imm = np.array([[0.25 / N, -0.08 / N], [-0.08 / N, 0.5 / N]])
     eps = 0.3
     seeds = [500 + c for c in range(C)]
     q0 = np.array([3.0, np.log(0.5)]) + (0.5 / np.sqrt(N)) * r.normal(size=(C, 2))
