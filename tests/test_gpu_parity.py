@@ -163,6 +163,34 @@ def test_gemm_small_tiles_bitwise_equals_tiled(eng, M, N, K):
         assert torch.equal(outs[mode], outs[0]), mode
 
 
+@pytest.mark.parametrize("sampler,D,C", [("nuts", 100, 300), ("hmc", 200, 1000), ("nuts", 333, 160)])
+def test_mid_size_dense_transitions_do_not_depend_on_the_gemm_tiles(eng, sampler, D, C):
+    """The lock-step path of a mid-size dense problem with its products on the small tiles (default) and on the
+    128 x 128 / tail kernels (`gemm_small_tiles` = 0): the same transitions bit for bit -- positions, energies,
+    diagnostics, generator states -- because every GEMM variant sums each output element's k-chain in the same order."""
+    from aehmc_amd import RandomStream, hmc, nuts
+    r = np.random.default_rng(D + C)
+    tgt, _, imm = make_case("dense", "dense", D, r)
+    q0 = r.normal(size=(C, D))
+    mod, extra = (nuts, ()) if sampler == "nuts" else (hmc, (12,))
+    outs = []
+    try:
+        for mode in (1, 0):
+            eng.set_option("gemm_small_tiles", mode)
+            srng = RandomStream(seeds=[60 + c for c in range(C)])
+            kernel = mod.new_kernel(srng, tgt)
+            state = mod.new_state(dev(q0), tgt)
+            for _ in range(2):
+                info, upd = kernel(state, 0.3 / D ** 0.25, imm, *extra)
+                state = info.state._replace(momentum=None)
+            outs.append((info.state.position.clone(), info.state.potential_energy.clone(), info.state.momentum.clone(),
+                         info.acceptance_probability.clone(), info.n_leapfrog.clone(), upd[srng].clone()))
+    finally:
+        eng.set_option("gemm_small_tiles", 1)
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), k
+
+
 # ------------------------------------------------------------------ G1 on the GPU
 def test_g1_readme_bit_exact_on_gpu():
     """README.md:22-54 through the drop-in API: position after one NUTS transition."""
