@@ -99,3 +99,15 @@ def test_window_adaptation_schedule_and_hmc_argument():
     fake_hmc._hmc = {}
     with pytest.raises(ValueError, match="num_integration_steps"):
         window_adaptation.run(fake_hmc, None, 10)
+
+
+def test_every_engine_option_is_documented_in_the_header():
+    """aehmc_set_option accepts the names the header's option table lists, and no others."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "aehmc_amd", "csrc", "engine.hip")).read()
+    hdr = open(os.path.join(root, "include", "aehmc_hip.h")).read()
+    accepted = set(re.findall(r'strcmp\(name, "([a-z_]+)"\)', src))
+    table = hdr[hdr.index("/* engine options (name, default):"):hdr.index("int aehmc_set_option")]
+    documented = set(re.findall(r'^ \*  "([a-z_]+)"', table, flags=re.M))
+    assert accepted and accepted == documented, accepted ^ documented
