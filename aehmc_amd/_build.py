@@ -1,0 +1,66 @@
+"""Build bookkeeping of libaehmc_hip.so: the library is stamped with a hash of the sources it was
+compiled from, so that "is the binary the tree's?" is decided by CONTENT, not by file times (a `.so`
+copied onto another box, a header edited after the build, a checkout that resets mtimes)."""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB = os.path.join(_HERE, "libaehmc_hip.so")
+STAMP = LIB + ".srchash"
+
+
+def source_files():
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+             if f.endswith((".hip", ".cuh", ".h")) or f == "Makefile"]
+    files += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return sorted(files)
+
+
+def source_hash() -> str:
+    """sha256 over (relative path, content) of every file the library is compiled from."""
+    h = hashlib.sha256()
+    for path in source_files():
+        h.update(os.path.relpath(path, ROOT).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def stamped_hash():
+    try:
+        with open(STAMP) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def library_hash(path: str = LIB) -> str:
+    """sha256 of the shared library itself (profiles/ summaries are tied to the binary they measured)."""
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for block in iter(lambda: f.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
+def is_current() -> bool:
+    return os.path.exists(LIB) and stamped_hash() == source_hash()
+
+
+def build(force: bool = False, quiet: bool = True) -> bool:
+    """Compile the library unless the stamped source hash equals the tree's.  Returns True if it compiled."""
+    want = source_hash()
+    if not force and os.path.exists(LIB) and stamped_hash() == want:
+        return False
+    cmd = ["make", "-C", CSRC, "-B"] + (["-s"] if quiet else [])
+    subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(want + "\n")
+    return True

@@ -83,6 +83,13 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or `make -C aehmc_amd/csrc`); aehmc_amd has no CPU fallback")
+        if not os.environ.get("AEHMC_AMD_LIB") and not os.environ.get("AEHMC_AMD_ALLOW_STALE"):
+            from . import _build
+            if not _build.is_current():  # a binary of OTHER sources must not pass for this tree's
+                raise RuntimeError(
+                    f"{LIB_PATH} was not built from the sources in this tree (source hash "
+                    f"{_build.source_hash()[:16]}, stamped {str(_build.stamped_hash())[:16]}): rebuild it with "
+                    "`python -c 'import __graft_entry__ as g; g.build()'`")
         lib = ct.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -17,7 +17,11 @@ from . import _lib
 from .targets import Target
 
 
-_FULL_HASH_BYTES = 64 << 20
+# Host arrays are keyed by their FULL content at any size (the reference re-reads the matrix on every call, so an
+# in-place edit must be seen).  `SAMPLED_HASH_ABOVE` (bytes; None = never) is an explicit opt-in for callers who
+# promise not to edit large arrays in place: above it only a strided sample is hashed.
+SAMPLED_HASH_ABOVE = None
+_WARN_HOST_BYTES = 64 << 20
 _warned_big_host_array = False
 
 
@@ -29,30 +33,27 @@ def _digest(buf):
 
 def _content_key(arr: np.ndarray):
     """Key a host array by CONTENT: numpy inputs may be edited in place between calls (the
-    reference re-reads the matrix on every call), so id() alone must never hit the cache.
-
-    Up to 64 MB the whole array is hashed (xxh3: ~10 GB/s).  Above that -- an 800 MB dense matrix at
-    D = 1e4 would cost 0.1-1 s per step() call, as much as the transition itself -- the key is the
-    buffer's address, shape and strides plus the hash of a strided 1/256 sample and of the first and
-    last MB: an in-place edit that misses the sample needs ``set_metric(..., force=True)`` /
-    ``set_target(..., force=True)``.  Passing a torch tensor (keyed by identity and version counter,
-    already on the device) avoids both the hashing and the upload; a warning says so once."""
+    reference re-reads the matrix on every call), so neither id() nor a sample of the elements may
+    hit the cache.  The whole array is hashed (xxh3: ~10 GB/s, i.e. ~0.1 s for the 800 MB matrix of
+    D = 1e4 -- once per step() call; a warning says once that a torch tensor on the device, keyed by
+    identity and version counter, avoids both the hashing and the upload).  With the module-level
+    opt-in ``SAMPLED_HASH_ABOVE`` set, larger arrays are keyed by shape plus the hashes of a 1/256
+    strided sample and of the first and last MB (then an in-place edit that misses the sample needs
+    ``force=True``)."""
     global _warned_big_host_array
     a = np.ascontiguousarray(arr)
     buf = memoryview(a).cast("B")
-    if a.nbytes <= _FULL_HASH_BYTES:
-        return _digest(buf)
-    if not _warned_big_host_array:
+    if a.nbytes > _WARN_HOST_BYTES and not _warned_big_host_array:
         _warned_big_host_array = True
         import warnings
-        warnings.warn(f"aehmc_amd: a {a.nbytes >> 20} MB host array is re-checked (sampled hash) on every call and "
-                      "re-uploaded when it changes; pass a torch tensor on the device to skip both "
-                      "(in-place edits of a large numpy array need force=True)", stacklevel=4)
+        warnings.warn(f"aehmc_amd: a {a.nbytes >> 20} MB host array is hashed on every call and re-uploaded when it "
+                      "changes; pass a torch tensor on the device to skip both", stacklevel=4)
+    if SAMPLED_HASH_ABOVE is None or a.nbytes <= SAMPLED_HASH_ABOVE:
+        return _digest(buf)
     flat = a.reshape(-1)
     sample = np.ascontiguousarray(flat[::256])
     mb = (1 << 20) // a.itemsize
-    return ("sampled", a.__array_interface__["data"][0], a.shape, a.strides,
-            _digest(memoryview(sample).cast("B")), _digest(memoryview(flat[:mb]).cast("B")),
+    return ("sampled", a.shape, _digest(memoryview(sample).cast("B")), _digest(memoryview(flat[:mb]).cast("B")),
             _digest(memoryview(flat[-mb:]).cast("B")))
 
 

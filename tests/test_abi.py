@@ -111,3 +111,60 @@ def test_every_engine_option_is_documented_in_the_header():
     table = hdr[hdr.index("/* engine options (name, default):"):hdr.index("int aehmc_set_option")]
     documented = set(re.findall(r'^ \*  "([a-z_]+)"', table, flags=re.M))
     assert accepted and accepted == documented, accepted ^ documented
+
+
+def test_build_is_keyed_by_source_content_not_mtime(monkeypatch):
+    """__graft_entry__.build() recompiles when the hash of csrc/* + include/* differs from the one stamped beside the
+    .so -- a comment edited in a header is enough, file times are not consulted -- and the loader refuses a binary
+    that was built from other sources."""
+    import subprocess
+
+    from aehmc_amd import _build, _lib
+    assert _build.is_current(), "run build() first"
+    calls = []
+    monkeypatch.setattr(subprocess, "check_call", lambda cmd, *a, **k: calls.append(cmd))
+    assert _build.build() is False and calls == []  # up to date: nothing compiled
+    hdr = os.path.join(ROOT, "include", "aehmc_hip.h")
+    saved, stamp = open(hdr).read(), open(_build.STAMP).read()
+    st = os.stat(hdr)
+    try:
+        with open(hdr, "a") as f:
+            f.write("/* edited */\n")
+        os.utime(hdr, (st.st_atime, st.st_mtime))  # same mtime as before: make alone would not rebuild
+        assert not _build.is_current()
+        monkeypatch.delenv("AEHMC_AMD_LIB", raising=False)
+        monkeypatch.setattr(_lib, "_lib", None)
+        with pytest.raises(RuntimeError, match="was not built from the sources"):
+            _lib.load()
+        assert _build.build() is True
+        assert calls and calls[0][:3] == ["make", "-C", _build.CSRC] and "-B" in calls[0]
+    finally:
+        open(hdr, "w").write(saved)
+        os.utime(hdr, (st.st_atime, st.st_mtime))
+        open(_build.STAMP, "w").write(stamp)
+    assert _build.is_current()
+
+
+def test_large_host_arrays_are_keyed_by_full_content():
+    """An in-place edit of ONE element of a > 64 MB numpy parameter changes the cache key (round 3 hashed a 1/256
+    sample there and missed it); the sampled key exists only as an explicit opt-in."""
+    import warnings
+
+    import numpy as np
+    from aehmc_amd import engine
+    a = np.zeros((3000, 3000))  # 72 MB
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        k0 = engine._param_key(a)
+        a[1234, 1235] = 1e-300  # flat index 3703235: not a multiple of 256, not in the first or last MB
+        k1 = engine._param_key(a)
+        assert k0 != k1
+        # lists / float32 / non-contiguous inputs are keyed by content too: equal content, equal key
+        assert engine._param_key(a[::2, ::2]) == engine._param_key(np.ascontiguousarray(a[::2, ::2]))
+        try:
+            engine.SAMPLED_HASH_ABOVE = 64 << 20
+            s0 = engine._param_key(a)
+            a[1234, 1237] = 1e-300
+            assert engine._param_key(a) == s0  # the opt-in's documented blind spot
+        finally:
+            engine.SAMPLED_HASH_ABOVE = None
