@@ -49,6 +49,8 @@ SYMBOLS = {
     "aehmc_adapt_update": (_I, [_P, _I64, _I64, ct.c_int32, ct.c_int32, ct.c_int32, _D, _P, _P,
                                 ct.POINTER(CAdaptState), _P]),
     "aehmc_dual_averaging_update": (_I, [_P, _I64, _D, _D, _D, _D, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "aehmc_welford_update": (_I, [_P, _I64, _I64, ct.c_int32, _P, _P, _P, _P, _P]),
+    "aehmc_covariance_final": (_I, [_P, _I64, _I64, ct.c_int32, ct.c_int32, _P, _P, _P, _P]),
     "aehmc_set_option": (_I, [_P, ct.c_char_p, _I64]),
     "aehmc_workspace_bytes": (_I64, [_P, _I64, _I64]),
     "aehmc_set_workspace": (_I, [_P, _P, _I64]),

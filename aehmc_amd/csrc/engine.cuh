@@ -698,9 +698,11 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
 }
 
 // nuts.py:113-125 after the momentum is in cur_p (and cur_v for a dense metric)
+// U_in (optional): the chain's potential energy from a register instead of a.U[c] (kernels that run several
+// transitions per launch keep it there)
 template <bool MET_DENSE>
 __device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lane, ChainCtl &ct,
-                                       ChainRng &rng) {
+                                       ChainRng &rng, const double *U_in = nullptr) {
   const size_t row = (size_t)c * a.D;
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
@@ -723,7 +725,7 @@ __device__ inline void nuts_init_chain(const EngineArgs &a, long long c, int lan
     a.psum[row + i] = p;
   }
   kd = wave_sum(kd);
-  const double U = a.U[c];
+  const double U = U_in ? *U_in : a.U[c];
   ct.H0 = U + 0.5 * kd;
   ct.prop_E = ct.H0;
   ct.prop_w = 0.0;
@@ -1015,7 +1017,7 @@ __global__ void k_count_active(const ChainCtl *ctl, long long C, int *out) {
 
 // ---- HMC (hmc.py:77-124, 157-204; trajectory.py:31-107) ---------------------------
 template <bool MET_DENSE>
-__device__ inline ChainCtl hmc_init_chain(const EngineArgs &a, long long c, int lane) {
+__device__ inline ChainCtl hmc_init_chain(const EngineArgs &a, long long c, int lane, const double *U_in = nullptr) {
   const size_t row = (size_t)c * a.D;
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
@@ -1028,7 +1030,7 @@ __device__ inline ChainCtl hmc_init_chain(const EngineArgs &a, long long c, int 
   }
   kd = wave_sum(kd);
   ChainCtl ct = {};
-  ct.U_cur = a.U[c];
+  ct.U_cur = U_in ? *U_in : a.U[c];
   ct.H0 = ct.U_cur + 0.5 * kd;  // hmc.py:187
   ct.dir = 1;
   if (lane == 0) a.ctl[c] = ct;
@@ -1046,9 +1048,15 @@ __global__ __launch_bounds__(256) void k_hmc_begin_diag(EngineArgs a) {
   rng_store(a, c, lane, rng, 0, 0);
   hmc_init_chain<false>(a, c, lane);
 }
-// hmc.py:185-204 after the L leapfrogs: flip, energy difference, accept / reject, outputs
+// hmc.py:185-204 after the L leapfrogs: flip, energy difference, accept / reject, outputs.  The accept draw comes
+// from `g2` (site #2), which the caller owns (registers, for kernels that run several transitions per launch).
+struct HmcEnd {
+  int acc, is_div;
+  double pa;
+};
 template <bool MET_DENSE>
-__device__ inline void hmc_end_chain(const EngineArgs &a, long long c, int lane, const ChainCtl &ct, long long L) {
+__device__ inline HmcEnd hmc_end_chain_rng(const EngineArgs &a, long long c, int lane, const ChainCtl &ct, long long L,
+                                           Pcg64 &g2) {
   const size_t row = (size_t)c * a.D;
   double kd = 0.0;
   for (long long i = lane; i < a.D; i += 64) {
@@ -1064,9 +1072,7 @@ __device__ inline void hmc_end_chain(const EngineArgs &a, long long c, int lane,
   double pa = exp(delta);
   if (pa > 1.0) pa = 1.0;
   if (pa < 0.0) pa = 0.0;
-  Pcg64 g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
   int acc = rng_bernoulli(g2, pa);  // hmc.py:193-194
-  if (lane == 0) pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
   for (long long i = lane; i < a.D; i += 64) {
     if (acc) {
       a.q[row + i] = a.cur_q[row + i];
@@ -1083,6 +1089,14 @@ __device__ inline void hmc_end_chain(const EngineArgs &a, long long c, int lane,
     if (a.out.n_leapfrog) a.out.n_leapfrog[c] = L;
     if (a.out.is_turning) a.out.is_turning[c] = acc;  // HMC: reused as the accept flag
   }
+  HmcEnd e = {acc, is_div, pa};
+  return e;
+}
+template <bool MET_DENSE>
+__device__ inline void hmc_end_chain(const EngineArgs &a, long long c, int lane, const ChainCtl &ct, long long L) {
+  Pcg64 g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
+  hmc_end_chain_rng<MET_DENSE>(a, c, lane, ct, L, g2);
+  if (lane == 0) pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
 }
 template <bool MET_DENSE>
 __global__ __launch_bounds__(256) void k_hmc_end(EngineArgs a, long long L) {
@@ -1630,6 +1644,62 @@ __global__ __launch_bounds__(256) void k_dual_averaging(long long C, double targ
   x_avg[c] = da.x_avg;
   g_avg[c] = da.g_avg;
   if (step_size_out) step_size_out[c] = eps;
+}
+
+// ---- the adaptation building blocks on their own (algorithms.py:120-204, mass_matrix.py:83-118) ----
+// algorithms.welford_covariance's update for C independent estimators, one wavefront each: the arithmetic of
+// adapt_welford_elem / k_adapt_update's full branch, hence the bits of the warm-up kernels.  full: m2 is [C,D,D] and
+// grows by outer(updated_delta, delta) (LDS: delta [D], updated delta [D]).
+__global__ __launch_bounds__(64) void k_welford_update(long long C, long long D, int full, const double *value,
+                                                        double *mean, double *m2, long long *n_arr) {
+  extern __shared__ __attribute__((aligned(16))) double wf_lds[];
+  const int lane = threadIdx.x;
+  const long long c = blockIdx.x;
+  const long long n = n_arr[c] + 1;
+  if (!full) {
+    for (long long i = lane; i < D; i += 64) {
+      double mu = mean[c * D + i], s = m2[c * D + i];
+      adapt_welford_elem(value[c * D + i], n, mu, s);
+      mean[c * D + i] = mu;
+      m2[c * D + i] = s;
+    }
+  } else {
+    double *const fl_delta = wf_lds, *const fl_ud = wf_lds + D;
+    for (long long i = lane; i < D; i += 64) {
+      const double v = value[c * D + i];
+      double mu = mean[c * D + i];
+      const double delta = v - mu;
+      mu = mu + delta / (double)n;
+      mean[c * D + i] = mu;
+      fl_delta[i] = delta;
+      fl_ud[i] = v - mu;
+    }
+    __threadfence_block();
+    for (long long i = 0; i < D; i++) {
+      const double ud = fl_ud[i];
+      double *row = m2 + c * D * D + i * D;
+      for (long long j = lane; j < D; j += 64) row[j] = row[j] + ud * fl_delta[j];
+    }
+  }
+  if (lane == 0) n_arr[c] = n;
+}
+// welford_covariance's final (algorithms.py:199-202: m2 / (n - 1)) and, with `shrink`, covariance_adaptation's final
+// (mass_matrix.py:83-118: Stan's shrinkage towards 1e-3 -- on every element of a diagonal estimate, on the diagonal
+// of a full one), one thread per element; the expressions of adapt_window_end_elem
+__global__ __launch_bounds__(256) void k_covariance_final(long long C, long long per, long long D, int full, int shrink,
+                                                           const double *m2, const long long *n_arr, double *out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= C * per) return;
+  const long long c = e / per, idx = e % per;
+  const long long n = n_arr[c];
+  const double nn = (double)n;
+  const double cov = m2[e] / (double)(n - 1);
+  double r = cov;
+  if (shrink) {
+    r = (nn / (nn + 5)) * cov;
+    if (!full || idx / D == idx % D) r = r + 1e-3 * (5 / (nn + 5));
+  }
+  out[e] = r;
 }
 
 __global__ __launch_bounds__(256) void k_fill_i64(long long *x, long long n, long long v) {

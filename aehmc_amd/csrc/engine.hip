@@ -14,6 +14,8 @@
 #include "hmc_fused.cuh"
 #include "hmc_linreg.cuh"
 #include "nuts_linreg.cuh"
+#include "nuts_block.cuh"
+#include "nuts_block_reg.cuh"
 #include "nuts_resident.cuh"
 #include "nuts_wide.cuh"
 
@@ -48,6 +50,9 @@ struct aehmc_ctx {
   bool opt_fused_nuts = false;   // whole NUTS transition in one launch (diag metric, coordinate-wise target)
   bool opt_dense_linear = true;  // one metric GEMM per leapfrog (v carried by linearity)
   bool opt_compact = true;       // finished chains drop out of the GEMMs
+  int opt_block_dense = 1;       // mid-size dense problems (64 < D <= 512): one workgroup per 16 chains, whole call in one launch
+                                 // (1: chain state in registers up to D = 256, in L2-resident work rows above; 2: always work rows)
+  bool opt_fp_contract = false;  // fast arithmetic in the leapfrog bodies of the register-resident kernels (1e-6, not bit parity)
   // profiling of the dominant (GEMM / fused) kernel with HIP events on the launch stream
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -74,6 +79,8 @@ struct aehmc_ctx {
   size_t pc_work_bytes = 0;
   double *fd_ws = nullptr;  // small-dense kernels, per-chain metrics: the chains' transposed matrices (kept, grown)
   size_t fd_ws_bytes = 0;
+  double *blk_pack = nullptr;  // block-resident dense kernels: the launch's matrices zero-padded to [Dp][Dp] (kept, grown)
+  size_t blk_pack_bytes = 0;
 };
 
 #define HIPCHK(expr)                                                                     \
@@ -168,6 +175,7 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (ctx->d_sched) (void)hipFree(ctx->d_sched);
   if (ctx->pc_work) (void)hipFree(ctx->pc_work);
   if (ctx->fd_ws) (void)hipFree(ctx->fd_ws);
+  if (ctx->blk_pack) (void)hipFree(ctx->blk_pack);
   for (int i = 0; i < NRING; i++)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -428,6 +436,30 @@ extern "C" int aehmc_dual_averaging_update(aehmc_ctx *ctx, int64_t C, double tar
   return 0;
 }
 
+extern "C" int aehmc_welford_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t full, const double *value,
+                                    double *mean, double *m2, int64_t *sample_size, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (C <= 0 || D <= 0 || !value || !mean || !m2 || !sample_size) FAIL("welford_update: bad arguments");
+  const size_t dyn = full ? (size_t)2 * D * sizeof(double) : 0;
+  if (dyn > 64 * 1024) FAIL("welford_update: full covariance is supported up to D = 4096");
+  hipLaunchKernelGGL(k_welford_update, dim3((unsigned)C), dim3(64), dyn, (hipStream_t)stream, (long long)C, (long long)D,
+                     (int)full, value, mean, m2, (long long *)sample_size);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int aehmc_covariance_final(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t full, int32_t shrink,
+                                      const double *m2, const int64_t *sample_size, double *out, void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (C <= 0 || D <= 0 || !m2 || !sample_size || !out) FAIL("covariance_final: bad arguments");
+  const long long per = full ? D * D : D;
+  hipLaunchKernelGGL(k_covariance_final, dim3((unsigned)((C * per + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (long long)C, per, (long long)D, (int)full, (int)shrink, m2, (const long long *)sample_size, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value) {
   if (!ctx || !name) return -2;
   if (!strcmp(name, "fused_hmc")) {
@@ -460,6 +492,14 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
   }
   if (!strcmp(name, "compact")) {
     ctx->opt_compact = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "block_dense")) {
+    ctx->opt_block_dense = (int)value;
+    return 0;
+  }
+  if (!strcmp(name, "fp_contract")) {
+    ctx->opt_fp_contract = value != 0;
     return 0;
   }
   FAIL(std::string("unknown option ") + name);
@@ -788,7 +828,8 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
 
 // which kernel family a NUTS call takes (one place: aehmc_nuts_warmup asks before it commits to a
 // single-launch warm-up)
-enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE, NUTS_PATH_FUSED_DENSE };
+enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE, NUTS_PATH_FUSED_DENSE,
+       NUTS_PATH_BLOCK_DENSE };
 // workspace of the small-dense kernels with per-chain metrics (hipFree waits for earlier launches that use it)
 static int fused_dense_workspace(aehmc_ctx *ctx, size_t need, double **out) {
   if (ctx->fd_ws_bytes < need) {
@@ -799,6 +840,18 @@ static int fused_dense_workspace(aehmc_ctx *ctx, size_t need, double **out) {
     ctx->fd_ws_bytes = need;
   }
   *out = ctx->fd_ws;
+  return 0;
+}
+static int block_pack_workspace(aehmc_ctx *ctx, int64_t D, double **out) {
+  const size_t need = blk_pack_bytes(D);
+  if (ctx->blk_pack_bytes < need) {
+    if (ctx->blk_pack) HIPCHK(hipFree(ctx->blk_pack));
+    ctx->blk_pack = nullptr;
+    ctx->blk_pack_bytes = 0;
+    HIPCHK(hipMalloc((void **)&ctx->blk_pack, need));
+    ctx->blk_pack_bytes = need;
+  }
+  *out = ctx->blk_pack;
   return 0;
 }
 static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions) {
@@ -816,6 +869,11 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
   if (want_resident && nuts_resident_dense_supported(tkind, nd, D))
     return NUTS_PATH_FUSED_DENSE;  // (per-chain dense metrics included: each wavefront reads its own matrices)
+  // mid-size dense problems (shared dense metric, 64 < D <= 512, linear dense mode): a workgroup per 16 chains runs
+  // the lock-step loop itself, products on MFMA inside the workgroup (nuts_block.cuh)
+  if (want_resident && ctx->opt_block_dense && ctx->opt_dense_linear &&
+      block_dense_supported(tkind, nd, ctx->met.per_chain, D))
+    return NUTS_PATH_BLOCK_DENSE;
   return NUTS_PATH_LOCKSTEP;
 }
 
@@ -884,6 +942,22 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
     HIPCHK(launch_nuts_resident_dense(a, m, st, md, td, pc));
+    return prof_end(ctx, st, p);
+  }
+  if (path == NUTS_PATH_BLOCK_DENSE) {  // mid-size dense problems: every transition of the call in one launch
+    NutsSampleArgs m{};
+    m.T = 1;
+    if (multi && multi_done && !multi->adapt) {
+      m = *multi;
+      *multi_done = true;
+    }
+    m.prec = ctx->tgt.prec;
+    double *bp = nullptr;
+    if (int rc = block_pack_workspace(ctx, a.D, &bp)) return rc;
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(launch_nuts_block_reg(a, m, bp, st));
+    else HIPCHK(launch_nuts_block_dense(a, m, bp, st));
     return prof_end(ctx, st, p);
   }
   if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
@@ -1079,6 +1153,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
     f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
     f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;
+    f.fc = ctx->opt_fp_contract;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
     HIPCHK(launch_hmc_fused(f, st));
@@ -1110,6 +1185,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     f.eps_c = ctx->eps_c;
     f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
     f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
+    f.fc = ctx->opt_fp_contract;
     // A launch pair per CHUNK of transitions: the momenta of the chunk are drawn first, at one wavefront per
     // chain (k_draw_momentum), into [nt][C][D]; the workgroup-per-chain kernel then runs the nt transitions
     // with the position on chip.  The chunk's normals live in the first work vectors of the workspace (cur_q
@@ -1172,6 +1248,22 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     else AEHMC_FD_LAUNCH(false, true, false);
 #undef AEHMC_FD_LAUNCH
     HIPCHK(hipGetLastError());
+    if (int rc = prof_end(ctx, st, p)) return rc;
+    if (T > 1 && out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
+    return 0;
+  }
+  // mid-size dense problems (shared dense metric, 64 < D <= 512, linear dense mode): all T transitions in one launch,
+  // a workgroup per 16 chains, products on MFMA inside the workgroup (nuts_block.cuh)
+  if (ctx->opt_fused_hmc && ctx->opt_block_dense && a.linear &&
+      block_dense_supported(a.tkind, a.met_ndim, ctx->met.per_chain, D)) {
+    double *bp = nullptr;
+    if (int rc = block_pack_workspace(ctx, D, &bp)) return rc;
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (ctx->opt_block_dense != 2 && block_reg_supported(D))
+      HIPCHK(launch_hmc_block_reg(a, ctx->tgt.prec, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist, bp, st));
+    else
+      HIPCHK(launch_hmc_block_dense(a, ctx->tgt.prec, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist, bp, st));
     if (int rc = prof_end(ctx, st, p)) return rc;
     if (T > 1 && out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
     return 0;

@@ -39,6 +39,7 @@ struct HmcFusedArgs {
   double *samples;   // [T,C,D] or null
   double *acc_hist;  // [T,C] or null
   int32_t *div_hist; // [T,C] or null
+  int fc;            // "fp_contract" option: fast arithmetic in the leapfrog bodies (1e-6 instead of bit parity)
 };
 
 inline bool target_is_elem_host(int k) {
@@ -48,7 +49,14 @@ inline bool hmc_fused_supported(int tkind, int met_ndim, long long D) {
   return target_is_elem_host(tkind) && met_ndim < 2 && D <= 1024;
 }
 
-template <int R, int TK>
+// FC ("fp_contract" option, off by default): the leapfrog bodies in fast arithmetic -- every a*b+c one fused
+// multiply-add, the loop-invariant products eps*imm and 1/sigma^2 formed once, and the two half kicks that meet
+// between consecutive leapfrogs of the static trajectory merged into one full kick (p - eps g instead of
+// (p - b g) - b g): 2 fp64 operations per element and leapfrog instead of 6 (diagonal-Gaussian target: 4 instead
+// of 8 + two divisions).  Mathematically the integrator of integrators.py:54-73; results within the north star's
+// 1e-6 (relative) of the default mode, which stays bit-identical to the oracle.  Everything outside the
+// trajectory loop (momentum draw, energies, accept) is the default mode's code.
+template <int R, int TK, bool FC = false>
 __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double zlds[];  // [4 waves][R*64]
   __shared__ double ztab[ZIG_LDS_DOUBLES];
@@ -80,6 +88,14 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   const double b = 0.5 * eps, aa = 1 * eps;
   double pa = 0.0;
   int is_div = 0, acc = 0;
+  double aim[FC ? R : 1], iv[(FC && TK == AEHMC_T_DIAG_GAUSSIAN) ? R : 1];
+  if (FC) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      aim[FC ? r : 0] = aa * im[r];
+      if (TK == AEHMC_T_DIAG_GAUSSIAN) iv[FC ? r : 0] = 1.0 / (sg[r] * sg[r]);
+    }
+  }
 
   const PcgLaneJump jump1 = pcg_lane_jump(g1);
   for (long long t = 0; t < a.T; t++) {
@@ -98,7 +114,35 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
     kd = wave_sum(kd);
     const double H0 = U + 0.5 * kd;  // hmc.py:187
 
-    if (TK == AEHMC_T_DIAG_GAUSSIAN) {
+    if (FC) {
+      constexpr bool DGT = TK == AEHMC_T_DIAG_GAUSSIAN;  // otherwise dU/dq == q
+      if (a.L > 0) {
+        // half kick | (drift, full kick) x (L - 1) | drift, half kick: no per-iteration select, four leapfrogs per
+        // trip of the loop (the body is four instructions per element: loop overhead would otherwise match it)
+        const double neg_eps = -eps;
+#pragma unroll
+        for (int r = 0; r < R; r++) p[r] = __builtin_fma(-b, DGT ? g[r] : q[r], p[r]);
+#pragma unroll 4
+        for (long long l = 1; l < a.L; l++) {
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            q[r] = __builtin_fma(aim[FC ? r : 0], p[r], q[r]);
+            if (DGT) g[r] = (q[r] - mu[r]) * iv[(FC && DGT) ? r : 0];
+            p[r] = __builtin_fma(neg_eps, DGT ? g[r] : q[r], p[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          q[r] = __builtin_fma(aim[FC ? r : 0], p[r], q[r]);
+          if (DGT) g[r] = (q[r] - mu[r]) * iv[(FC && DGT) ? r : 0];
+          p[r] = __builtin_fma(-b, DGT ? g[r] : q[r], p[r]);
+        }
+      }
+      if (!DGT) {
+#pragma unroll
+        for (int r = 0; r < R; r++) g[r] = q[r];
+      }
+    } else if (TK == AEHMC_T_DIAG_GAUSSIAN) {
       for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -207,7 +251,7 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
 // element and leapfrog: from L2 they cost the loop its registers -- 264 B/lane of scratch, 5.6 ms per transition
 // at D = 1e4), and the fall-back state is the caller's q / dU/dq, rewritten at every accepted transition.  Cross-wave sums take one LDS hop, so the summation order differs from the lock-step
 // path (1e-13).  Slots past D replicate element D-1 (in bounds), are masked out of the sums, never stored.
-template <int T, int R, int TK>
+template <int T, int R, int TK, bool FC = false>
 __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zbuf, int nt) {
   constexpr int NW = T / 64;
   constexpr bool DG = TK == AEHMC_T_DIAG_GAUSSIAN;  // otherwise dU/dq == q, no separate copy
@@ -261,7 +305,8 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
     if (DG) g[r] = grow[EI(r)];
     im[r] = a.imm[imo + (a.met_ndim == 0 ? 0 : EI(r))];
     if (DG) {  // (a thread reads back only the entries it wrote: no barrier)
-      psig[EI(r)] = a.sigma[EI(r)];
+      const double sd0 = a.sigma[EI(r)];
+      psig[EI(r)] = FC ? 1.0 / (sd0 * sd0) : sd0;  // FC: the reciprocal variance, formed once
       pmu[EI(r)] = a.mu[EI(r)];
     }
   }
@@ -285,7 +330,34 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
     }
     sum2(kd, zero);
     const double H0 = U + 0.5 * kd;  // hmc.py:187
-    if (DG) {
+    if (FC) {  // fast arithmetic (see k_hmc_fused): fused multiply-adds, eps * imm formed once, inner half kicks merged
+      if (a.L > 0) {
+        double aim[FC ? R : 1];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          aim[FC ? r : 0] = aa * im[r];
+          p[r] = __builtin_fma(-b, GR(r), p[r]);
+        }
+        const double neg_eps = -eps;
+#pragma unroll 4
+        for (long long l = 1; l < a.L; l++) {  // (drift, full kick) x (L - 1)
+          if (DG) RENEW_TB();
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            q[r] = __builtin_fma(aim[FC ? r : 0], p[r], q[r]);
+            if (DG) g[DG ? r : 0] = (q[r] - pmu[EI(r)]) * psig[EI(r)];  // psig holds 1 / sigma^2 in this mode
+            p[r] = __builtin_fma(neg_eps, GR(r), p[r]);
+          }
+        }
+        if (DG) RENEW_TB();
+#pragma unroll
+        for (int r = 0; r < R; r++) {  // last drift, half kick
+          q[r] = __builtin_fma(aim[FC ? r : 0], p[r], q[r]);
+          if (DG) g[DG ? r : 0] = (q[r] - pmu[EI(r)]) * psig[EI(r)];
+          p[r] = __builtin_fma(-b, GR(r), p[r]);
+        }
+      }
+    } else if (DG) {
       for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
         RENEW_TB();
 #pragma unroll
@@ -323,7 +395,10 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
       double u;
       if (TK == AEHMC_T_STD_NORMAL) u = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
       else if (TK == AEHMC_T_ISO_GAUSSIAN) u = qq * qq;
-      else {
+      else if (FC) {  // z^2 = d^2 / sigma^2 with the reciprocal variance in LDS
+        const double d = qq - pmu[EI(r)];
+        u = 0.5 * ((d * d) * psig[EI(r)]) + a.log_sigma[EI(r)] + AEHMC_LOG_SQRT_2PI;
+      } else {
         const double z = (qq - pmu[EI(r)]) / psig[EI(r)];
         u = 0.5 * (z * z) + a.log_sigma[EI(r)] + AEHMC_LOG_SQRT_2PI;
       }
@@ -419,12 +494,17 @@ template <int T, int R>
 inline hipError_t launch_hmc_wide_r(const HmcFusedArgs &a, const double *zbuf, int nt, hipStream_t st) {
   const bool dg = a.tkind == AEHMC_T_DIAG_GAUSSIAN;
   const size_t dyn = (size_t)a.D * sizeof(double) * (dg ? 2 : 1);
-#define AEHMC_WIDE_LAUNCH(TK)                                                                              \
+#define AEHMC_WIDE_LAUNCH_FC(TK, FCV)                                                                      \
   do {                                                                                                     \
-    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_wide<T, R, TK>),             \
+    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_wide<T, R, TK, FCV>),        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);             \
     if (e_ != hipSuccess) return e_;                                                                       \
-    hipLaunchKernelGGL((k_hmc_wide<T, R, TK>), dim3((unsigned)a.C), dim3(T), dyn, st, a, zbuf, nt);        \
+    hipLaunchKernelGGL((k_hmc_wide<T, R, TK, FCV>), dim3((unsigned)a.C), dim3(T), dyn, st, a, zbuf, nt);   \
+  } while (0)
+#define AEHMC_WIDE_LAUNCH(TK)                  \
+  do {                                         \
+    if (a.fc) AEHMC_WIDE_LAUNCH_FC(TK, true);  \
+    else AEHMC_WIDE_LAUNCH_FC(TK, false);      \
   } while (0)
   switch (a.tkind) {
     case AEHMC_T_STD_NORMAL:
@@ -437,6 +517,7 @@ inline hipError_t launch_hmc_wide_r(const HmcFusedArgs &a, const double *zbuf, i
       AEHMC_WIDE_LAUNCH(AEHMC_T_DIAG_GAUSSIAN);
   }
 #undef AEHMC_WIDE_LAUNCH
+#undef AEHMC_WIDE_LAUNCH_FC
   return hipGetLastError();
 }
 // `nt` consecutive transitions; `samples`, `acc_hist`, `div_hist` point at the FIRST of them ([nt][C][..] slices);
@@ -448,29 +529,33 @@ inline hipError_t launch_hmc_resident(const HmcFusedArgs &a, const double *zbuf,
   return launch_hmc_wide_r<1024, 10>(a, zbuf, nt, st);
 }
 
-template <int R>
+template <int R, bool FC>
 inline hipError_t launch_hmc_fused_r(const HmcFusedArgs &a, hipStream_t st) {
   dim3 grid((unsigned)((a.C + 3) / 4)), block(256);
   size_t lds = (size_t)4 * R * 64 * sizeof(double);
   switch (a.tkind) {
     case AEHMC_T_STD_NORMAL:
-      hipLaunchKernelGGL((k_hmc_fused<R, AEHMC_T_STD_NORMAL>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((k_hmc_fused<R, AEHMC_T_STD_NORMAL, FC>), grid, block, lds, st, a);
       break;
     case AEHMC_T_ISO_GAUSSIAN:
-      hipLaunchKernelGGL((k_hmc_fused<R, AEHMC_T_ISO_GAUSSIAN>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((k_hmc_fused<R, AEHMC_T_ISO_GAUSSIAN, FC>), grid, block, lds, st, a);
       break;
     default:
-      hipLaunchKernelGGL((k_hmc_fused<R, AEHMC_T_DIAG_GAUSSIAN>), grid, block, lds, st, a);
+      hipLaunchKernelGGL((k_hmc_fused<R, AEHMC_T_DIAG_GAUSSIAN, FC>), grid, block, lds, st, a);
   }
   return hipGetLastError();
 }
-inline hipError_t launch_hmc_fused(const HmcFusedArgs &a, hipStream_t st) {
+template <bool FC>
+inline hipError_t launch_hmc_fused_fc(const HmcFusedArgs &a, hipStream_t st) {
   const long long r = (a.D + 63) / 64;
-  if (r <= 1) return launch_hmc_fused_r<1>(a, st);
-  if (r <= 2) return launch_hmc_fused_r<2>(a, st);
-  if (r <= 4) return launch_hmc_fused_r<4>(a, st);
-  if (r <= 8) return launch_hmc_fused_r<8>(a, st);
-  return launch_hmc_fused_r<16>(a, st);
+  if (r <= 1) return launch_hmc_fused_r<1, FC>(a, st);
+  if (r <= 2) return launch_hmc_fused_r<2, FC>(a, st);
+  if (r <= 4) return launch_hmc_fused_r<4, FC>(a, st);
+  if (r <= 8) return launch_hmc_fused_r<8, FC>(a, st);
+  return launch_hmc_fused_r<16, FC>(a, st);
+}
+inline hipError_t launch_hmc_fused(const HmcFusedArgs &a, hipStream_t st) {
+  return a.fc ? launch_hmc_fused_fc<true>(a, st) : launch_hmc_fused_fc<false>(a, st);
 }
 
 }  // namespace aehmc

@@ -1,0 +1,731 @@
+// Block-resident dense NUTS / HMC with the chains' moving state in REGISTERS (gfx950): 64 < D <= 256.
+//
+// nuts_block.cuh runs the lock-step engine's own stage / bookkeeping functions on L2-resident work rows between the
+// in-workgroup MFMA products; counted per leapfrog of a workgroup at D = 200 (tools/debug/block_phases.py), those
+// stages -- a dozen dependent L2 round trips, 200+ bytes of scratch per lane at the 128 registers a 1024-thread
+// workgroup leaves a lane -- cost as much as the two products.  Here the wavefront that owns a chain keeps q, p,
+// dU/dq, the velocity v = imm p, w = imm dU/dq and the sub-trajectory momentum sum in VGPRs, element lane + 64 r in
+// slot r (D <= 64 R), exactly as k_nuts_resident does for diagonal metrics; the products read their operand rows
+// from one LDS buffer and write the result rows to another, which the owners read back -- the chain state touches
+// global memory only where the tree needs it (U-turn checkpoints, trajectory ends at expansion boundaries, the
+// proposal on accept).  Per leapfrog: first stages in registers -> operand row to LDS -> P r -> imm g' (LDS to LDS)
+// -> rows back -> last stage + bookkeeping in registers; three workgroup barriers.
+// Same arithmetic in the same order as engine.cuh's leap_linear / nuts_book / nuts_finalize_expansion / hmc_end_chain
+// (each lane adds its elements in ascending order, sums by wave_sum), same MFMA k-chains: BITWISE the lock-step
+// path's results (tests/test_gpu_block_dense.py).
+// Reference: nuts.py:56-153, trajectory.py:154-374,428-714, termination.py:85-235, proposals.py:19-174,
+// hmc.py:77-204, integrators.py:54-73, metrics.py:44-104.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "nuts_block.cuh"
+
+namespace aehmc {
+
+constexpr int BLK_REG_MAX_D = 256;
+inline bool block_reg_supported(long long D) { return D >= BLK_MIN_D && D <= BLK_REG_MAX_D; }
+// two row buffers [16][S] (operand / result, swapping roles from product to product) + one staging tile per wavefront
+inline size_t blk_reg_lds_bytes(long long D) {
+  return ((size_t)2 * BLK_CHAINS * blk_lds_stride(D) + (size_t)BLK_CHAINS * BLK_TB) * sizeof(double);
+}
+
+// dst[16][S] = src[16][S] * Bp^T, both in LDS; the caller places the barriers
+__device__ __forceinline__ void blk_gemm_lds(const double *src, double *dst, int S, const double *Bp, long long D,
+                                             int wave, int lane, double *tb) {
+  const int NT = (int)((D + 15) / 16);
+  for (int nt = wave; nt < NT; nt += BLK_CHAINS) blk_wave_tile(src, S, Bp, NT * 16, D, nt * 16, dst, S, BLK_CHAINS, lane, tb);
+}
+
+template <int R, bool TDENSE>
+__global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, NutsSampleArgs m) {
+  extern __shared__ __attribute__((aligned(16))) double blk_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long c0 = (long long)blockIdx.x * BLK_CHAINS, c = c0 + wave;
+  const bool valid = c < a.C;
+  const long long D = a.D;
+  const int S = (int)blk_lds_stride(D);
+  double *const xbuf = blk_lds, *const ybuf = blk_lds + BLK_CHAINS * S;
+  double *const tb = blk_lds + 2 * BLK_CHAINS * S + wave * BLK_TB;
+  double *const xrow = xbuf + wave * S, *const yrow = ybuf + wave * S;
+  const size_t row = (size_t)(valid ? c : 0) * D;
+  const bool elem = target_is_elem(a.tkind);
+  for (int k = lane; k < S; k += 64) {  // pads (and the rows of chains past C) stay zero for the whole launch
+    xrow[k] = 0.0;
+    yrow[k] = 0.0;
+  }
+#define EI(r) (lane + 64 * (r))
+#define AT(ptr, r) ((ptr) + row)[EI(r)]
+  bool ok[R];
+  double q[R], p[R], g[R], v[R], w[R], pb[R], mur[TDENSE ? R : 1];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    ok[r] = valid && EI(r) < D;
+    q[r] = p[r] = g[r] = v[r] = w[r] = pb[r] = 0.0;
+    if (TDENSE) mur[TDENSE ? r : 0] = ok[r] ? a.mu[EI(r)] : 0.0;
+  }
+  ChainRng rng = {};
+  ChainCtl ct = {};
+  ct.done = 1;
+  double U_state = 0.0;
+  long long nleap_sum = 0;
+  double eps = 0.0;
+  if (valid) {
+    rng = rng_load(a, c);
+    U_state = a.U[c];
+    eps = a.eps_c ? a.eps_c[c] : a.eps;
+  }
+  BlkTimer tm;
+
+  // first stages of a leapfrog (leap_linear<12>): p_half, v_half, q', the target where it is coordinate-wise, and the
+  // operand row of the next product -- r = q' - mu (dense target) or dU/dq' itself -- into this chain's row of xbuf
+  auto stage12 = [&]() __attribute__((always_inline)) {
+    const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
+    const double b = 0.5 * step_size, aa = 1 * step_size;
+    double usum = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        const double pp = p[r] - b * g[r];
+        const double vv = v[r] - b * w[r];
+        p[r] = pp;
+        v[r] = vv;
+        const double qq = q[r] + aa * vv;
+        q[r] = qq;
+        if (!TDENSE) {
+          double u, gnew;
+          target_elem(a, EI(r), qq, u, gnew);
+          usum += u;
+          g[r] = gnew;
+          xrow[EI(r)] = gnew;
+        } else {
+          xrow[EI(r)] = qq - mur[TDENSE ? r : 0];
+        }
+      }
+    }
+    if (!TDENSE) ct.U_cur = target_finish(a, wave_sum(usum));
+  };
+  // sub-trajectory proposal <- moving end (copy_cur_to_slot)
+  auto take = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        AT(pick2(a.slot_q, slot), r) = q[r];
+        AT(pick2(a.slot_p, slot), r) = p[r];
+        AT(pick2(a.slot_g, slot), r) = g[r];
+      }
+    }
+    put2(ct.U_slot, slot, ct.U_cur);
+  };
+  // expand_once after integrate() returned (nuts_finalize_expansion<true> + nuts_write_outputs / nuts_begin_expansion)
+  auto finalize = [&](bool is_div, bool has_term) __attribute__((always_inline)) {
+    const int dir = ct.dir, oth = 1 - dir;
+    double d_l = 0.0, d_r = 0.0;
+    double pov[R], vov[R], psv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      pov[r] = ok[r] ? AT(pick2(a.end_p, oth), r) : 0.0;
+      vov[r] = ok[r] ? AT(pick2(a.end_v, oth), r) : 0.0;
+      psv[r] = ok[r] ? AT(a.psum, r) : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        const double pc = p[r], po = pov[r], vc = v[r], vo = vov[r];
+        const double s = psv[r] + pb[r];
+        AT(a.psum, r) = s;
+        const double pl = dir ? po : pc, pr = dir ? pc : po;
+        const double vl = dir ? vo : vc, vr = dir ? vc : vo;
+        const double rho = s - (pr + pl) / 2;
+        d_l += vl * rho;
+        d_r += vr * rho;
+        AT(pick2(a.end_q, dir), r) = q[r];
+        AT(pick2(a.end_p, dir), r) = pc;
+        AT(pick2(a.end_g, dir), r) = g[r];
+        AT(pick2(a.end_v, dir), r) = vc;
+        AT(pick2(a.end_w, dir), r) = w[r];
+      }
+    }
+    d_l = wave_sum(d_l);
+    d_r = wave_sum(d_r);
+    const bool turning = (d_l <= 0) | (d_r <= 0);
+    put2(ct.U_end, dir, ct.U_cur);
+    ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;  // trajectory.py:551-553
+    double pbias = exp(ct.sub_w - ct.prop_w);            // proposals.py:130 (always drawn)
+    if (pbias > 1.0) pbias = 1.0;
+    if (pbias < 0.0) pbias = 0.0;
+    const int acc_b = rng_bernoulli(rng.g[3], pbias);
+    if (is_div || has_term) {
+      ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);  // trajectory.py:560-564
+    } else {
+      ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);           // proposals.py:141-144
+      ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
+      if (acc_b) {
+        ct.prop_slot ^= 1;
+        ct.prop_E = ct.sub_E;
+      }
+    }
+    ct.ndoubl = ct.j + 1;
+    ct.out_div = is_div;
+    ct.out_turn = turning;
+    const bool end_transition = is_div || turning || has_term || (ct.j + 1 == a.max_exp);
+    if (end_transition) {  // nuts_write_outputs
+      const int s = ct.prop_slot;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          AT(a.q, r) = AT(pick2(a.slot_q, s), r);
+          AT(a.g, r) = AT(pick2(a.slot_g, s), r);
+          if (a.out.momentum) AT(a.out.momentum, r) = AT(pick2(a.slot_p, s), r);
+        }
+      }
+      if (lane == 0) {
+        a.U[c] = pick2(ct.U_slot, s);
+        a.out.acceptance_probability[c] = ct.acc_prob;
+        if (a.out.num_doublings) a.out.num_doublings[c] = ct.ndoubl;
+        if (a.out.is_turning) a.out.is_turning[c] = ct.out_turn;
+        a.out.is_diverging[c] = ct.out_div;
+        if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
+      }
+      ct.done = 1;  // (the caller keeps the chain alive while a phantom scan is pending)
+    } else {        // nuts_begin_expansion
+      ct.j += 1;
+      const int go_right = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
+      ct.dir = go_right;
+      ct.step = 0;
+      if (dir != go_right) {  // cur <- the other end (trajectory.py:518)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          if (ok[r]) {
+            q[r] = AT(pick2(a.end_q, go_right), r);
+            p[r] = AT(pick2(a.end_p, go_right), r);
+            g[r] = AT(pick2(a.end_g, go_right), r);
+            v[r] = AT(pick2(a.end_v, go_right), r);
+            w[r] = AT(pick2(a.end_w, go_right), r);
+          }
+        }
+        ct.U_cur = pick2(ct.U_end, go_right);
+      }
+    }
+  };
+  // last stage of the leapfrog + one iteration of dynamic_integration's scan (nuts_book<true, 1>)
+  auto book = [&]() __attribute__((always_inline)) {
+    const int step = ct.step;
+    if (!ct.phantom) ct.nleap += 1;
+    int tmin, tmax;
+    if (step == 0) {  // termination.py:109-113: indices inherited from the previous sub-trajectory
+      tmin = ct.tmin;
+      tmax = ct.tmax;
+    } else {          // termination.py:192-235 in closed form
+      const int n1 = __ffs(~step) - 1;
+      tmax = __popc(step >> 1);
+      tmin = tmax - n1 + 1;
+    }
+    const bool even = (step & 1) == 0;
+    const bool f_turn = step >= 1 && tmax >= tmin;
+    const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
+    const double b = 0.5 * step_size;
+    double *const ckp = a.ckp + ((size_t)tmax * a.C + c) * D;
+    double *const cks = a.cks + ((size_t)tmax * a.C + c) * D;
+    double *const ckv = a.ckv + ((size_t)tmax * a.C + c) * D;
+    double kpv[R], kvv[R], ksv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {  // (loaded before this step's pair is stored over them)
+      kpv[r] = (f_turn && ok[r]) ? ckp[EI(r)] : 0.0;
+      kvv[r] = (f_turn && ok[r]) ? ckv[EI(r)] : 0.0;
+      ksv[r] = (f_turn && ok[r]) ? cks[EI(r)] : 0.0;
+    }
+    double usum = 0.0, kd = 0.0, f_dl = 0.0, f_dr = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        if (TDENSE) usum += (q[r] - mur[TDENSE ? r : 0]) * g[r];  // leap_linear<3>
+        const double pn = p[r] - b * g[r];
+        const double vn = v[r] - b * w[r];
+        p[r] = pn;
+        v[r] = vn;
+        kd += vn * pn;                                            // bookkeeping
+        const double s = (step == 0) ? pn : pb[r] + pn;
+        pb[r] = s;
+        if (even) {
+          ckp[EI(r)] = pn;
+          cks[EI(r)] = s;
+          ckv[EI(r)] = vn;
+        }
+        if (f_turn) {                                             // first level of is_iterative_turning
+          const double pl = kpv[r], vl = kvv[r];
+          const double sub = s - ksv[r] + pl;
+          const double rho = sub - (pn + pl) / 2;
+          f_dl += vl * rho;
+          f_dr += vn * rho;
+        }
+      }
+    }
+    if (TDENSE) ct.U_cur = target_finish(a, wave_sum(usum));
+    kd = wave_sum(kd);
+    ct.tmin = tmin;
+    ct.tmax = tmax;
+    const double E = ct.U_cur + 0.5 * kd;  // proposals.py:19-62
+    double delta = ct.H0 - E;
+    if (isnan(delta)) delta = -INFINITY;
+    const bool div = fabs(delta) > a.thr;
+    const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
+    bool term = false;
+    if (step == 0) {
+      ct.sub_E = E;
+      ct.sub_w = np_w;
+      ct.sub_slpa = np_slpa;
+      ct.length = 1;
+      take(ct.prop_slot ^ 1);
+    } else {
+      const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
+      const int acc = rng_bernoulli(rng.g[2], sc.pa);
+      ct.sub_w = sc.sub_w;
+      ct.sub_slpa = sc.sub_slpa;
+      if (acc) {
+        ct.sub_E = E;
+        if (!ct.phantom) take(ct.prop_slot ^ 1);
+      }
+      ct.length += 1;
+      if (tmax >= tmin) {  // termination.py:133-187
+        int idx = tmax;
+        bool crit = false;
+        for (;;) {
+          double d_l = 0.0, d_r = 0.0;
+          if (idx == tmax) {
+            d_l = f_dl;
+            d_r = f_dr;
+          } else {
+            const double *kp = a.ckp + ((size_t)idx * a.C + c) * D;
+            const double *ks = a.cks + ((size_t)idx * a.C + c) * D;
+            const double *kv = a.ckv + ((size_t)idx * a.C + c) * D;
+            double lp[R], lv[R], ls[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              lp[r] = ok[r] ? kp[EI(r)] : 0.0;
+              lv[r] = ok[r] ? kv[EI(r)] : 0.0;
+              ls[r] = ok[r] ? ks[EI(r)] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              if (ok[r]) {
+                const double pl = lp[r], pr = p[r], vl = lv[r], vr = v[r];
+                const double sub = pb[r] - ls[r] + pl;
+                const double rho = sub - (pr + pl) / 2;
+                d_l += vl * rho;
+                d_r += vr * rho;
+              }
+            }
+          }
+          d_l = wave_sum(d_l);
+          d_r = wave_sum(d_r);
+          crit = (d_l <= 0) | (d_r <= 0);
+          const bool reached = (idx - 1) < tmin;
+          idx -= 1;
+          if (crit || reached) break;
+        }
+        term = crit;
+      }
+    }
+    if (step == 0 && div && !ct.phantom) {
+      // trajectory.py:336: integrate() returns the first-step tuple, yet the scan still executes (and draws from
+      // site #3): finalize now, keep stepping as a phantom
+      finalize(true, false);
+      ct.done = 0;
+      ct.phantom = 1;
+      ct.step = 1;
+    } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
+      if (ct.phantom) ct.done = 1;
+      else finalize(div, term);
+    } else {
+      ct.step = step + 1;
+    }
+  };
+
+  __syncthreads();
+  for (long long t_idx = 0; t_idx < m.T; t_idx++) {
+    // ---- momentum: z (site #1) -> p = L^-T z, v = imm p; w = imm dU/dq (metrics.py:65-68, nuts.py:113-125) ----
+    if (valid) {
+      wave_normals(rng.g[0], D, [=](long long i, double z) { xrow[i] = z; });
+      __threadfence_block();
+    }
+    tm.tick(7);
+    __syncthreads();
+    blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (ok[r]) p[r] = yrow[EI(r)];
+    blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        v[r] = xrow[EI(r)];
+        g[r] = AT(a.g, r);
+        q[r] = AT(a.q, r);
+        yrow[EI(r)] = g[r];
+      }
+    }
+    __syncthreads();
+    blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);
+    __syncthreads();
+    tm.tick(2);
+    if (valid) {  // nuts_init_chain<true>
+      double kd = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          w[r] = xrow[EI(r)];
+          kd += v[r] * p[r];
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            AT(a.end_q[e], r) = q[r];
+            AT(a.end_p[e], r) = p[r];
+            AT(a.end_g[e], r) = g[r];
+            AT(a.end_v[e], r) = v[r];
+            AT(a.end_w[e], r) = w[r];
+          }
+          AT(a.slot_q[0], r) = q[r];
+          AT(a.slot_p[0], r) = p[r];
+          AT(a.slot_g[0], r) = g[r];
+          AT(a.psum, r) = p[r];
+        }
+      }
+      kd = wave_sum(kd);
+      const double U = U_state;
+      ct.H0 = U + 0.5 * kd;
+      ct.prop_E = ct.H0;
+      ct.prop_w = 0.0;
+      ct.prop_slpa = -INFINITY;
+      ct.sub_E = ct.sub_w = ct.sub_slpa = 0.0;
+      ct.U_cur = ct.U_end[0] = ct.U_end[1] = ct.U_slot[0] = ct.U_slot[1] = U;
+      ct.acc_prob = 0.0;
+      ct.nleap = 0;
+      ct.j = 0;
+      ct.length = 0;
+      ct.tmin = ct.tmax = 0;
+      ct.done = ct.phantom = 0;
+      ct.prop_slot = 0;
+      ct.ndoubl = ct.out_div = ct.out_turn = 0;
+      ct.dir = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
+      ct.step = 0;
+      stage12();
+    }
+    tm.tick(7);
+    // ---- one leapfrog of every live chain per trip ----
+    for (;;) {
+      const int live = __syncthreads_or(valid && !ct.done);
+      tm.tick(6);  // vote (waits for the slowest chain's bookkeeping)
+      if (!live) break;
+      const bool alive = valid && !ct.done;
+      if (TDENSE) {
+        blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb);  // dU/dq' = P r
+        tm.tick(2);
+        __syncthreads();
+        tm.tick(3);
+        blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);   // w' = imm dU/dq'
+        tm.tick(2);
+        __syncthreads();
+        tm.tick(3);
+        if (alive) {
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            if (ok[r]) {
+              g[r] = yrow[EI(r)];
+              w[r] = xrow[EI(r)];
+            }
+          }
+        }
+      } else {
+        blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);   // w' = imm dU/dq'
+        tm.tick(2);
+        __syncthreads();
+        tm.tick(3);
+        if (alive) {
+#pragma unroll
+          for (int r = 0; r < R; r++)
+            if (ok[r]) w[r] = yrow[EI(r)];
+        }
+      }
+      if (alive) {
+        book();
+        tm.tick(4);
+        if (!ct.done) stage12();
+        tm.tick(5);
+      }
+    }
+    // ---- per-transition records (the outputs themselves were written when the transition ended) ----
+    if (valid) {
+      U_state = pick2(ct.U_slot, ct.prop_slot);
+      nleap_sum += ct.nleap;
+      if (m.samples) {
+        double *dst = m.samples + ((size_t)t_idx * a.C + c) * D;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if (ok[r]) dst[EI(r)] = AT(a.q, r);
+      }
+      if (lane == 0) {
+        if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
+        if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
+      }
+    }
+  }
+  if (valid) {
+    rng_store(a, c, lane, rng, 0, 3);
+    if (lane == 0 && m.nleap_total) m.nleap_total[c] = nleap_sum;
+#ifdef AEHMC_WIDE_TIMING
+    if (lane == 0)
+      for (int k = 0; k < 8; k++) a.linreg_part[c * 8 + k] = (double)tm.acc[k];
+#endif
+  }
+  (void)elem;
+#undef EI
+#undef AT
+}
+
+// HMC: nt transitions x L leapfrogs, the chains' state in registers (hmc_run's lock-step loop: hmc_init_chain,
+// leap_linear<12> / <3>, hmc_end_chain)
+template <int R, bool TDENSE>
+__global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, const double *prec, long long L,
+                                                                long long nt, double *samples, double *acc_hist,
+                                                                int *div_hist) {
+  extern __shared__ __attribute__((aligned(16))) double blk_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long c0 = (long long)blockIdx.x * BLK_CHAINS, c = c0 + wave;
+  const bool valid = c < a.C;
+  const long long D = a.D;
+  const int S = (int)blk_lds_stride(D);
+  double *const xbuf = blk_lds, *const ybuf = blk_lds + BLK_CHAINS * S;
+  double *const tb = blk_lds + 2 * BLK_CHAINS * S + wave * BLK_TB;
+  double *const xrow = xbuf + wave * S, *const yrow = ybuf + wave * S;
+  const size_t row = (size_t)(valid ? c : 0) * D;
+  for (int k = lane; k < S; k += 64) {
+    xrow[k] = 0.0;
+    yrow[k] = 0.0;
+  }
+#define EI(r) (lane + 64 * (r))
+#define AT(ptr, r) ((ptr) + row)[EI(r)]
+  bool ok[R];
+  double q[R], p[R], g[R], v[R], w[R], q0[R], g0[R], p0[R], mur[TDENSE ? R : 1];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    ok[r] = valid && EI(r) < D;
+    q[r] = ok[r] ? AT(a.q, r) : 0.0;
+    g[r] = ok[r] ? AT(a.g, r) : 0.0;
+    p[r] = v[r] = w[r] = q0[r] = g0[r] = p0[r] = 0.0;
+    if (TDENSE) mur[TDENSE ? r : 0] = ok[r] ? a.mu[EI(r)] : 0.0;
+  }
+  Pcg64 g1 = {}, g2 = {};
+  double U = 0.0, eps = 0.0, pa = 0.0;
+  int is_div = 0, acc = 0;
+  if (valid) {
+    g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4);
+    g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
+    U = a.U[c];
+    eps = a.eps_c ? a.eps_c[c] : a.eps;
+  }
+  const double b = 0.5 * (1.0 * eps), aa = 1 * (1.0 * eps);  // direction +1 (launch_leapfrog: ct.dir = 1)
+  __syncthreads();
+  for (long long tt = 0; tt < nt; tt++) {
+    if (valid) {
+      wave_normals(g1, D, [=](long long i, double z) { xrow[i] = z; });
+      __threadfence_block();
+    }
+    __syncthreads();
+    blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb);  // p = L^-T z
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (ok[r]) p[r] = yrow[EI(r)];
+    blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);        // v = imm p
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        v[r] = xrow[EI(r)];
+        yrow[EI(r)] = g[r];
+      }
+    }
+    __syncthreads();
+    blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);        // w = imm dU/dq
+    __syncthreads();
+    double kd = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {  // hmc_init_chain<true>
+      if (ok[r]) {
+        w[r] = xrow[EI(r)];
+        kd += v[r] * p[r];
+        p0[r] = p[r];
+        q0[r] = q[r];
+        g0[r] = g[r];
+      }
+    }
+    kd = wave_sum(kd);
+    const double H0 = U + 0.5 * kd;  // hmc.py:187
+    double U_cur = U;
+    for (long long l = 0; l < L; l++) {  // trajectory.py:86-95: leap_linear<12> | P r | imm g' | leap_linear<3>
+      double usum = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          const double pp = p[r] - b * g[r];
+          const double vv = v[r] - b * w[r];
+          p[r] = pp;
+          v[r] = vv;
+          const double qq = q[r] + aa * vv;
+          q[r] = qq;
+          if (!TDENSE) {
+            double u, gnew;
+            target_elem(a, EI(r), qq, u, gnew);
+            usum += u;
+            g[r] = gnew;
+            xrow[EI(r)] = gnew;
+          } else {
+            xrow[EI(r)] = qq - mur[TDENSE ? r : 0];
+          }
+        }
+      }
+      if (!TDENSE && valid) U_cur = target_finish(a, wave_sum(usum));
+      __syncthreads();
+      if (TDENSE) {
+        blk_gemm_lds(xbuf, ybuf, S, prec, D, wave, lane, tb);
+        __syncthreads();
+        blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);
+        __syncthreads();
+      } else {
+        blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);
+        __syncthreads();
+      }
+      usum = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          if (TDENSE) {
+            g[r] = yrow[EI(r)];
+            w[r] = xrow[EI(r)];
+            usum += (q[r] - mur[TDENSE ? r : 0]) * g[r];
+          } else {
+            w[r] = yrow[EI(r)];
+          }
+          p[r] = p[r] - b * g[r];
+          v[r] = v[r] - b * w[r];
+        }
+      }
+      if (TDENSE && valid) U_cur = target_finish(a, wave_sum(usum));
+    }
+    if (valid) {  // hmc_end_chain<true>
+      kd = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          const double pf = -1.0 * p[r];  // hmc.py:185 momentum flip
+          const double vf = -1.0 * v[r];
+          kd += vf * pf;
+        }
+      }
+      kd = wave_sum(kd);
+      const double new_energy = U_cur + 0.5 * kd;
+      double delta = H0 - new_energy;
+      if (isnan(delta)) delta = -INFINITY;
+      is_div = fabs(delta) > a.thr;
+      pa = exp(delta);
+      if (pa > 1.0) pa = 1.0;
+      if (pa < 0.0) pa = 0.0;
+      acc = rng_bernoulli(g2, pa);  // hmc.py:193-194
+      if (acc) {
+        U = U_cur;
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          q[r] = q0[r];
+          g[r] = g0[r];
+        }
+      }
+      if (samples) {
+        double *dst = samples + ((size_t)tt * a.C + c) * D;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if (ok[r]) dst[EI(r)] = q[r];
+      }
+      if (lane == 0) {
+        if (acc_hist) acc_hist[(size_t)tt * a.C + c] = pa;
+        if (div_hist) div_hist[(size_t)tt * a.C + c] = is_div;
+      }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        AT(a.q, r) = q[r];
+        AT(a.g, r) = g[r];
+        if (a.out.momentum) AT(a.out.momentum, r) = acc ? -1.0 * p[r] : p0[r];
+      }
+    }
+    if (lane == 0) {
+      pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
+      pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
+      a.U[c] = U;
+      a.out.acceptance_probability[c] = pa;
+      a.out.is_diverging[c] = is_div;
+      if (a.out.n_leapfrog) a.out.n_leapfrog[c] = L;
+      if (a.out.is_turning) a.out.is_turning[c] = acc;  // HMC: reused as the accept flag
+    }
+  }
+#undef EI
+#undef AT
+}
+
+template <int R>
+inline hipError_t launch_nuts_block_reg_r(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
+  const size_t dyn = blk_reg_lds_bytes(a.D);
+  const dim3 grid((unsigned)((a.C + BLK_CHAINS - 1) / BLK_CHAINS)), block(BLK_THREADS);
+#define AEHMC_BLK(TDV)                                                                                       \
+  do {                                                                                                       \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_block_reg<R, TDV>),            \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                \
+    if (e != hipSuccess) return e;                                                                           \
+    hipLaunchKernelGGL((k_nuts_block_reg<R, TDV>), grid, block, dyn, st, a, m);                              \
+  } while (0)
+  if (a.tkind == AEHMC_T_DENSE_MVN) AEHMC_BLK(true);
+  else AEHMC_BLK(false);
+#undef AEHMC_BLK
+  return hipGetLastError();
+}
+inline hipError_t launch_nuts_block_reg(EngineArgs a, NutsSampleArgs m, double *bp, hipStream_t st) {
+  BlkMats mats;
+  if (hipError_t e = blk_pack_matrices(a, m.prec, bp, mats, st)) return e;
+  a.imm = mats.imm; a.sqrt_mass = mats.sqrt_mass; m.prec = mats.prec;
+  return a.D <= 128 ? launch_nuts_block_reg_r<2>(a, m, st) : launch_nuts_block_reg_r<4>(a, m, st);
+}
+
+template <int R>
+inline hipError_t launch_hmc_block_reg_r(const EngineArgs &a, const double *prec, long long L, long long nt,
+                                         double *samples, double *acc_hist, int *div_hist, hipStream_t st) {
+  const size_t dyn = blk_reg_lds_bytes(a.D);
+  const dim3 grid((unsigned)((a.C + BLK_CHAINS - 1) / BLK_CHAINS)), block(BLK_THREADS);
+#define AEHMC_BLK(TDV)                                                                                       \
+  do {                                                                                                       \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hmc_block_reg<R, TDV>),             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                \
+    if (e != hipSuccess) return e;                                                                           \
+    hipLaunchKernelGGL((k_hmc_block_reg<R, TDV>), grid, block, dyn, st, a, prec, L, nt, samples, acc_hist,   \
+                       div_hist);                                                                            \
+  } while (0)
+  if (a.tkind == AEHMC_T_DENSE_MVN) AEHMC_BLK(true);
+  else AEHMC_BLK(false);
+#undef AEHMC_BLK
+  return hipGetLastError();
+}
+inline hipError_t launch_hmc_block_reg(EngineArgs a, const double *prec, long long L, long long nt, double *samples,
+                                       double *acc_hist, int *div_hist, double *bp, hipStream_t st) {
+  BlkMats mats;
+  if (hipError_t e = blk_pack_matrices(a, prec, bp, mats, st)) return e;
+  a.imm = mats.imm; a.sqrt_mass = mats.sqrt_mass;
+  return a.D <= 128 ? launch_hmc_block_reg_r<2>(a, mats.prec, L, nt, samples, acc_hist, div_hist, st)
+                    : launch_hmc_block_reg_r<4>(a, mats.prec, L, nt, samples, acc_hist, div_hist, st);
+}
+
+}  // namespace aehmc

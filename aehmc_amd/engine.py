@@ -449,6 +449,21 @@ class Engine:
             step_size_out.data_ptr() if step_size_out is not None else None, self.stream),
             "aehmc_dual_averaging_update")
 
+    def welford_update(self, value, mean, m2, n, full):
+        """algorithms.welford_covariance's update for C estimators, in place (value, mean [C,D]; m2 [C,D] | [C,D,D];
+        n [C] int64)."""
+        C, D = mean.shape
+        self._check(self.lib.aehmc_welford_update(self.ctx, C, D, int(bool(full)), value.data_ptr(), mean.data_ptr(),
+                                                  m2.data_ptr(), n.data_ptr(), self.stream), "aehmc_welford_update")
+
+    def covariance_final(self, m2, n, D, full, shrink):
+        """m2 / (n - 1) (algorithms.py:199-202), with ``shrink`` Stan's regularisation on top (mass_matrix.py:83-118)."""
+        out = torch.empty_like(m2)
+        self._check(self.lib.aehmc_covariance_final(self.ctx, n.numel(), int(D), int(bool(full)), int(bool(shrink)),
+                                                    m2.data_ptr(), n.data_ptr(), out.data_ptr(), self.stream),
+                    "aehmc_covariance_final")
+        return out
+
     def profile_enable(self, on=True):
         self._check(self.lib.aehmc_profile_enable(self.ctx, int(on)), "aehmc_profile_enable")
 

@@ -4,11 +4,14 @@ mass_matrix.py, algorithms.py).  The schedule is host logic; the per-chain dual-
 Welford updates run in one HIP kernel per warm-up step (`aehmc_adapt_update`)."""
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from typing import Dict, List, NamedTuple, Optional, Tuple
+
+import torch
 
 from ._common import Layout
-from .engine import PerChain, get_engine
+from .engine import PerChain, _dev_f64, get_engine
 from .integrators import IntegratorState
+from .step_size import DualAveragingState
 
 
 def build_schedule(num_steps: int, initial_buffer_size: int = 75, final_buffer_size: int = 50,
@@ -112,3 +115,98 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     imm, sqrt_mass = st["imm"].clone(), st["sqrt_mass"].clone()
     return state, (PerChain(layout.per_chain(step_size)),
                    PerChain(imm.reshape(C) if scalar_position else imm, sqrt_mass)), updates
+
+
+class WarmupState(NamedTuple):
+    """window_adaptation.py:119-227's ``warmup_state = (da_state, mm_state)`` (DualAveragingState,
+    algorithms.py:9-14; Welford state ``(mean, m2, sample_size)``, algorithms.py:141-165) plus the current
+    parameters' device arrays the update kernel rewrites (step size, inverse mass matrix, its square root)."""
+    da_state: DualAveragingState
+    mm_state: Tuple
+    step_size: torch.Tensor
+    imm: torch.Tensor
+    sqrt_mass: torch.Tensor
+    work: Optional[torch.Tensor] = None
+    position_shape: Tuple = ()   # user-facing shape of the chain position and whether it has a leading chain axis
+    batched: bool = False
+
+
+def window_adaptation(num_steps: int, is_mass_matrix_full: bool = False, initial_step_size=1.0,
+                      target_acceptance_rate=0.80):
+    """The warm-up as ``(init, update)`` for callers that drive the loop themselves (reference:
+    aehmc/window_adaptation.py:119-227 -- ``run`` above is that loop in one engine call):
+
+        init, update = window_adaptation(num_steps)
+        warmup_state, parameters = init(state)              # parameters = (step_size, inverse_mass_matrix)
+        for i in range(num_steps):
+            info, _ = kernel(state, *parameters)
+            state = info.state._replace(momentum=None)
+            warmup_state, parameters = update(i, warmup_state, parameters, info)
+
+    ``update`` is one launch of the warm-up kernel (``aehmc_adapt_update``: dual averaging in every stage, Welford in
+    the slow windows, new metric + restart at a window end, the averaged step size after the last step) on COPIES of
+    the state arrays -- states are values, as in the reference; the parameters are ``PerChain`` values (one
+    adaptation per chain)."""
+    schedule = build_schedule(int(num_steps))
+
+    def _layout(position, num_chains):
+        shape = tuple(position.shape)
+        batched = num_chains is not None or len(shape) == 2
+        C = (num_chains if num_chains is not None else shape[0]) if batched else 1
+        layout = Layout(shape, batched, C)
+        scalar_position = (len(shape) - (1 if batched else 0)) == 0
+        return layout, scalar_position
+
+    def _params(layout, scalar_position, ws: WarmupState):
+        C = layout.C
+        return (PerChain(layout.per_chain(ws.step_size)),
+                PerChain(ws.imm.reshape(C) if scalar_position else ws.imm, ws.sqrt_mass))
+
+    def _cstate(eng, ws: WarmupState, full):
+        from . import _lib
+        da, (mean, m2, n) = ws.da_state, ws.mm_state
+        ptr = dict(da_step=da.step, da_x=da.iterates, da_x_avg=da.iterates_avg, da_g_avg=da.gradient_avg,
+                   da_mu=da.shrinkage_pts, wc_mean=mean, wc_m2=m2, wc_n=n, step_size=ws.step_size, imm=ws.imm,
+                   sqrt_mass=ws.sqrt_mass)
+        if ws.work is not None:
+            ptr["work"] = ws.work
+        return _lib.CAdaptState(full=int(bool(full)), **{k: v.data_ptr() for k, v in ptr.items()})
+
+    def init(initial_chain_state: IntegratorState, num_chains: Optional[int] = None):
+        """window_adaptation.py:130-143: identity metric, dual averaging started at ``initial_step_size`` (so the
+        first step size is exp(0) = 1, algorithms.py:56-76)."""
+        eng = get_engine()
+        layout, scalar_position = _layout(initial_chain_state.position, num_chains)
+        C, D = layout.C, layout.D
+        full = bool(is_mass_matrix_full) and not scalar_position
+        st, cst = eng.adapt_alloc(C, D, full)
+        eng.adapt_init(C, D, float(initial_step_size), cst)
+        ws = WarmupState(DualAveragingState(st["da_step"], st["da_x"], st["da_x_avg"], st["da_g_avg"], st["da_mu"]),
+                         (st["wc_mean"], st["wc_m2"], st["wc_n"]), st["step_size"], st["imm"], st["sqrt_mass"],
+                         st.get("work"), layout.user_shape, layout.C > 1 or num_chains is not None or
+                         len(layout.user_shape) == 2)
+        return ws, _params(layout, scalar_position, ws)
+
+    def update(step: int, warmup_state: WarmupState, parameters, chain_state):
+        """window_adaptation.py:192-214 for warm-up step ``step`` (0-based) after the transition ``chain_state``."""
+        del parameters  # (the arrays in warmup_state ARE the current parameters)
+        eng = get_engine()
+        position = chain_state.state.position
+        C = warmup_state.step_size.numel()
+        if tuple(position.shape) != tuple(warmup_state.position_shape):
+            raise ValueError(f"position has shape {tuple(position.shape)}, the warm-up was initialised with "
+                             f"{tuple(warmup_state.position_shape)}")
+        layout, scalar_position = _layout(position, C if warmup_state.batched else None)
+        D = layout.D
+        full = warmup_state.imm.ndim == 3
+        da, (mean, m2, n) = warmup_state.da_state, warmup_state.mm_state
+        ws = WarmupState(DualAveragingState(*(t.clone() for t in da)), (mean.clone(), m2.clone(), n.clone()),
+                         warmup_state.step_size.clone(), warmup_state.imm.clone(), warmup_state.sqrt_mass.clone(),
+                         warmup_state.work, warmup_state.position_shape, warmup_state.batched)
+        stage, window_end = schedule[int(step)]
+        eng.adapt_update(C, D, stage, window_end, int(step) == len(schedule) - 1, float(target_acceptance_rate),
+                         _dev_f64(chain_state.acceptance_probability, eng.device).reshape(C).contiguous(),
+                         _dev_f64(position, eng.device).reshape(C, D).contiguous(), _cstate(eng, ws, full))
+        return ws, _params(layout, scalar_position, ws)
+
+    return init, update

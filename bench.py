@@ -36,14 +36,38 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s
 PEAK_FP64_VALU_TFLOPS = 78.6  # fp64 vector peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (datasheet)
 
 
+_LIB_SHA = None
+
+
+def lib_sha256():
+    """sha256 of the libaehmc_hip.so this process loads: counter summaries are tied to the binary they measured."""
+    global _LIB_SHA
+    if _LIB_SHA is None:
+        from aehmc_amd import _build, _lib
+        _LIB_SHA = _build.library_hash(_lib.LIB_PATH)
+    return _LIB_SHA
+
+
+PMC_STALE = {}  # summary name -> why its counters were NOT used in this run's line
+
+
 def pmc_summary(name):
-    """Counter summaries are collected OFFLINE (rocprofv3 --pmc cannot run inside the bench): the newest
-    committed profiles/rN/<name> and its path, so that every roofline entry that divides offline counters
-    by this run's timings says where they came from (`traffic_source`)."""
-    for rnd in ("r3", "r2", "r1"):
+    """Counter summaries are collected OFFLINE (rocprofv3 --pmc cannot run inside the bench): the newest committed
+    profiles/rN/<name>, and only if it was measured on the very binary this run loads -- every summary stores the
+    sha256 of the libaehmc_hip.so it profiled (`lib_sha256`); one without it, or with another hash, is NOT used:
+    peak / frac / traffic derived from it are dropped from the line and `counters_dropped` says why."""
+    for rnd in ("r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(path):
-            return json.load(open(path)), f"profiles/{rnd}/{name} (separate rocprofv3 --pmc passes of the same workload)"
+            summ = json.load(open(path))
+            have = summ.get("lib_sha256")
+            if have != lib_sha256():
+                PMC_STALE[name] = (f"profiles/{rnd}/{name} was measured on another build of libaehmc_hip.so "
+                                   f"(summary: {str(have)[:16]}, loaded: {lib_sha256()[:16]}): counter-derived "
+                                   "peak / frac / traffic dropped")
+                return None, None
+            return summ, f"profiles/{rnd}/{name} (separate rocprofv3 --pmc passes of the same workload, lib_sha256 {have[:16]})"
+    PMC_STALE[name] = f"no profiles/rN/{name}"
     return None, None
 
 
@@ -71,15 +95,16 @@ def other_configs():
     line, so that their numbers are in the driver's record too: each runs in a child process of its own
     (`bench.py --config cN --no-cpu-baseline`, default steps), after this process's own measurements."""
     out = []
-    for cfg in ("c2", "c5", "c1"):
+    for cfg, extra in (("c2", []), ("c2", ["--fp-contract"]), ("c5", []), ("c1", [])):
         try:
             env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK",
                                                                      "TORCHELASTIC_RUN_ID")}
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--no-cpu-baseline"],
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--no-cpu-baseline"] + extra,
                                capture_output=True, text=True, timeout=300, env=env)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             d = json.loads(line[-1])
-            out.append({"config": cfg, "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"],
+            out.append({"config": cfg + ("-fp_contract" if extra else ""), "workload": d["config"]["workload"],
+                        "value": d["value"], "unit": d["unit"],
                         "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
                         "roofline": d.get("roofline")})
         except Exception as e:  # a failing side measurement must not cost the main line
@@ -116,7 +141,9 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
     time measured here with HIP events on the launch stream."""
     pmc, pmc_src = pmc_summary("diag_pmc_summary.json") if (D, C) == (10_000, 4096) else (None, None)
     out = []
-    for kind, main_kernel in (("nuts", "k_nuts_wide"), ("hmc", "k_hmc_wide")):
+    for kind, main_kernel, fc in (("nuts", "k_nuts_wide", 0), ("hmc", "k_hmc_wide", 0), ("hmc", "k_hmc_wide", 1)):
+        eng.set_option("fp_contract", fc)
+        pkey = kind + ("_fp_contract" if fc else "")  # section of the counter summary
         state, step = diag_case(kind, D, C, device)
         for _ in range(warmup):
             info, _ = step(state)
@@ -136,8 +163,8 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
         nl = int(nl.item())
         per_call = HMC_PER_CALL if kind == "hmc" else 1  # transitions per engine call (= per HIP-event pair)
         traffic = None
-        if pmc and kind in pmc:
-            traffic = pmc[kind]["hbm_bytes_per_transition"]
+        if pmc and pkey in pmc:
+            traffic = pmc[pkey]["hbm_bytes_per_transition"]
         avg_ms = kern_ms / max(kern_n, 1) / per_call
         alg = (48.0 if kind == "hmc" else 88.0) * D * nl / (steps * per_call)  # SURVEY 8d streaming figure, for reference only
         hbm = {"unit": "GB/s", "peak": PEAK_HBM_GBS, "traffic": traffic,
@@ -148,22 +175,30 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
         hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS if traffic else None
         if kind == "nuts":  # bound by HBM on its counted bytes (checkpoints, proposal copies, parked trajectory ends)
             roof = dict(hbm, bound="hbm", kernel=main_kernel + " (+ k_draw_momentum)", avg_launch_ms=avg_ms,
-                        launches=kern_n * per_call, traffic_source=pmc_src if traffic else None)
+                        launches=kern_n * per_call, traffic_source=pmc_src if traffic else None,
+                        counters_dropped=PMC_STALE.get("diag_pmc_summary.json"))
         else:
             # the position stays in registers for the transitions of a call: HBM sees the normals in and little else, and
             # the bound is fp64 VALU issue -- 6 UNFUSED operations per element and leapfrog (the reference rounds every
             # product and sum), against 16 lanes x 4 SIMDs x 256 CUs x 2.4 GHz lane-operations per second
+            # (fp_contract = 1: 2 fused operations per element and leapfrog -- the same trajectory in a third of the
+            #  issue slots; `achieved` then counts the operations that mode executes)
             peak_ops = 256 * 4 * 16 * 2.4e9 / 1e12
-            ops = nl / dt * 6.0 * D / 1e12
-            roof = {"bound": "valu", "unit": "Tlane-op/s (fp64, unfused)", "achieved": ops, "peak": peak_ops, "frac": ops / peak_ops,
+            per_elem = 2.0 if fc else 6.0
+            ops = nl / dt * per_elem * D / 1e12
+            roof = {"bound": "valu", "unit": "Tlane-op/s (fp64, " + ("fused" if fc else "unfused") + ")", "achieved": ops,
+                    "peak": peak_ops, "frac": ops / peak_ops,
                     "kernel": main_kernel + " (+ k_draw_momentum)", "avg_launch_ms": avg_ms, "launches": kern_n * per_call,
                     "traffic": traffic, "traffic_source": pmc_src if traffic else None, "hbm": hbm,
-                    "note": "6 D fp64 operations per leapfrog in the integration; the momentum draw (PCG64 + ziggurat, one "
-                            "wavefront per chain) takes a third of a transition and is VALU-bound as well"}
-        out.append({"config": f"diag-{kind}",
+                    "counters_dropped": PMC_STALE.get("diag_pmc_summary.json"),
+                    "note": f"{per_elem:.0f} D fp64 operations per leapfrog in the integration; the momentum draw (PCG64 + "
+                            "ziggurat, one wavefront per chain) is VALU-bound as well and is not counted in `achieved`"}
+        out.append({"config": f"diag-{kind}" + ("-fp_contract" if fc else ""),
                     "workload": f"{D}-dim isotropic Gaussian, diagonal mass, {'NUTS depth 10' if kind == 'nuts' else 'HMC L=32'}, "
-                                f"{C} chains", "value": nl / dt, "unit": "leapfrog-steps/s", "ms_per_transition": dt / (steps * per_call) * 1e3,
+                                f"{C} chains" + (", engine option fp_contract=1 (1e-6 relative, not bit parity)" if fc else ""),
+                    "value": nl / dt, "unit": "leapfrog-steps/s", "ms_per_transition": dt / (steps * per_call) * 1e3,
                     "leapfrogs_per_transition": nl / (steps * per_call), "roofline": roof})
+    eng.set_option("fp_contract", 0)
     return out
 
 
@@ -248,6 +283,9 @@ def main():
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the diagonal-mass secondary lines")
+    ap.add_argument("--fp-contract", action="store_true",
+                    help="engine option fp_contract=1: fast arithmetic in the leapfrog bodies of the register-resident HMC "
+                         "kernels (1e-6 relative instead of bit parity with the oracle; c2 and the diagonal-mass HMC line)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {"c1": 20, "c2": 20, "c5": 1000}.get(args.config, 5)
@@ -301,6 +339,7 @@ def main():
         return bench_c5(args, rank, world, device)
     C = args.chains
     eng = get_engine(device)
+    eng.set_option("fp_contract", 1 if args.fp_contract else 0)
     if os.environ.get("AEHMC_BENCH_ONE_DEVICE") == "1" and world > 1:
         eng.set_option("streamk", 0)  # ranks share the device: the persistent stream-K grid is not co-resident
     seeds = [1000 + rank * C + c for c in range(C)]
@@ -327,7 +366,9 @@ def main():
         NT = 100  # transitions per engine call (100 transitions; one launch on the fused path)
         step = lambda st: (kernel.sample(st, eps, imm, L, NT, keep_samples=False)[1], None)
         workload = (f"c2: {D}-dim isotropic Gaussian, HMC L={L}, diagonal mass, {C} chains/GPU, eps={eps}; "
-                    f"one step = {NT} transitions of every chain")
+                    f"one step = {NT} transitions of every chain"
+                    + ("; engine option fp_contract=1 (fused multiply-adds and merged half kicks in the leapfrog loop: "
+                       "1e-6 relative, not bit parity)" if args.fp_contract else ""))
 
     # warm-up runs exactly what a timed step runs (including the leapfrog tally and one gather), so
     # that no lazily loaded code object lands inside the timed region
@@ -378,6 +419,7 @@ def main():
             traffic_src = src + "; FETCH_SIZE x 2 + WRITE_SIZE"
         roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                    "counters_dropped": PMC_STALE.get("c3_pmc_summary.json"),
                     "algorithmic_bytes_per_launch": (2.0 * flops / (2.0 * D * D) * D + D * D) * 8,
                     "kernel": "gemm_nt_f64_streamk_kernel", "avg_launch_ms": avg_s * 1e3, "launches": kern_n,
                     "avg_rows_per_launch": flops / (2.0 * D * D), "gemm_share_of_step_time": kern_ms / 1e3 / elapsed,
@@ -390,13 +432,14 @@ def main():
         # kernel's COUNTED instructions per transition (rocprofv3 SQ_INSTS_VALU), 1024 SIMDs x 2.4 GHz /
         # (4 waves x 4 cycles x instructions per wave and transition).
         avg_s = kern_ms / 1e3 / max(kern_n, 1)
-        pj, src = pmc_summary("c2_pmc_summary.json")
+        c2_name = "c2_fc_pmc_summary.json" if args.fp_contract else "c2_pmc_summary.json"
+        pj, src = pmc_summary(c2_name)
         if not (pj and D == 100 and C == 4096):
             pj, src = None, None
         flop_rate = value / world * 9.0 * D / 1e12  # ~9 D flop per leapfrog
         roofline = {"bound": "valu", "unit": "leapfrog-steps/s", "kernel": "k_hmc_fused", "avg_launch_ms": avg_s * 1e3,
                     "launches": kern_n, "achieved": value / world, "peak": None, "frac": None, "traffic": None,
-                    "traffic_source": src,
+                    "traffic_source": src, "counters_dropped": PMC_STALE.get(c2_name),
                     "fp64_flops": {"achieved": flop_rate, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                                    "frac": flop_rate / PEAK_FP64_VALU_TFLOPS,
                                    "note": "9 D flop per leapfrog (SURVEY.md 8d) against the fp64 vector peak"}}
@@ -430,7 +473,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload, "chains_total": C * world, "dim": D,
+        "config": {"workload": workload, "chains_total": C * world, "dim": D, "fp_contract": int(args.fp_contract),
+                   "lib_sha256": lib_sha256(),
                    "leapfrogs_per_step": total_leap / args.steps, "ranks_seen": ranks_seen,
                    "gather": {"to": "rank 0", "bytes": (world - 1) * C * D * 8, "ms": t_g * 1e3,
                               "backend": dist_backend}},
@@ -517,7 +561,7 @@ def bench_c5(args, rank, world, device):
                     "launches": kern_n, "algorithmic_flops_per_launch": flops,
                     "algorithmic_l2_bytes_per_launch": 16.0 * N * total_rank / 4 / max(kern_n, 1),
                     "traffic": pj["derived"]["hbm_bytes_per_launch"] if pj else None, "traffic_source": src,
-                    "counters": pj["derived"] if pj else None,
+                    "counters": pj["derived"] if pj else None, "counters_dropped": PMC_STALE.get("c5_pmc_summary.json"),
                     "note": "3 FMAs per row, chain and leapfrog against the fp64 vector peak; the sweep of a 4-chain "
                             "workgroup also pulls 16 B per row through its CU's 64 B/clk vector-memory path (rows beyond "
                             "the 10176 kept in LDS), which bounds a sweep at about the same time as the FMAs: DESIGN.md"}

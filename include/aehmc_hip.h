@@ -145,7 +145,20 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   accumulated in k order (bitwise equal to 0).  2: 128 x 256 tiles, one
  *                   workgroup per CU, software-pipelined K loop (default); 1: 128 x 128 tiles,
  *                   two workgroups per CU; 0: one tile per workgroup
- *  "compact" 1      NUTS: chains whose transition has finished drop out of the GEMMs */
+ *  "compact" 1      NUTS: chains whose transition has finished drop out of the GEMMs
+ *  "block_dense" 1  mid-size dense problems (shared dense inverse mass matrix, 64 < D <= 512, "dense_linear" = 1,
+ *                   coordinate-wise or dense-precision target): NUTS ("resident_nuts" != 0) and HMC ("fused_hmc" = 1)
+ *                   run the whole call in ONE launch, a workgroup per 16 chains -- stages at a wavefront per chain,
+ *                   products on fp64 MFMA inside the workgroup, same k-order as the chain-batched GEMM (bitwise
+ *                   the lock-step path's results).  1: the chains' moving state in registers up to D = 256, in
+ *                   L2-resident work rows above; 2: work rows at every D; 0 = the lock-step path
+ *  "fp_contract" 0  1: fast arithmetic in the leapfrog bodies of the register-resident HMC kernels
+ *                   (diagonal / scalar metric, coordinate-wise target): every a*b+c one fused multiply-add,
+ *                   eps*imm and 1/sigma^2 formed once, the half kicks between consecutive leapfrogs of a
+ *                   static trajectory merged -- 2 fp64 operations per element and leapfrog instead of 6.
+ *                   The integrator of integrators.py:54-73 within 1e-6 relative (the north star's bar);
+ *                   0 (default) rounds every product and sum as the reference does and is bit-identical
+ *                   to the oracle.  Momentum draw, energies and accept step are the same code in both modes */
 int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value);
 
 /* workspace the caller must provide to the step calls for C chains */
@@ -206,6 +219,18 @@ int aehmc_dual_averaging_update(aehmc_ctx *ctx, int64_t C, double target_accepta
                                 double t0, double kappa, const double *acceptance_probability,
                                 int64_t *step, double *iterates, double *iterates_avg, double *gradient_avg,
                                 const double *shrinkage_pts, double *step_size_out, void *stream);
+
+/* algorithms.welford_covariance(compute_covariance) -> update / final (algorithms.py:120-204) and
+ * mass_matrix.covariance_adaptation -> final (mass_matrix.py:83-118) as stand-alone building blocks, C independent
+ * estimators (tests/test_algorithms.py:60-133, tests/test_mass_matrix.py:11-60 drive them directly): `update` takes
+ * one new value [C,D] per estimator (mean [C,D], m2 [C,D] -- or [C,D,D] with `full`, grown by
+ * outer(updated_delta, delta) --, sample_size [C], all in place); `final` writes m2 / (sample_size - 1) and, with
+ * `shrink`, Stan's regularisation (n / (n + 5)) cov + 1e-3 (5 / (n + 5)) (on the diagonal only when `full`) -- the
+ * arithmetic of the warm-up kernels, bit for bit. */
+int aehmc_welford_update(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t full, const double *value, double *mean,
+                         double *m2, int64_t *sample_size, void *stream);
+int aehmc_covariance_final(aehmc_ctx *ctx, int64_t C, int64_t D, int32_t full, int32_t shrink, const double *m2,
+                           const int64_t *sample_size, double *out, void *stream);
 
 /* window_adaptation.run (window_adaptation.py:17-116) for a NUTS kernel: num_steps x (one transition
  * with the current per-chain parameters, then aehmc_adapt_update), enqueued in one call.  `stage` /

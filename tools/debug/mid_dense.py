@@ -16,6 +16,9 @@ P, imm = spd(D), torch.as_tensor(spd(D), device="cuda")
 tgt = targets.DenseMVN(torch.zeros(D, dtype=torch.float64, device="cuda"), torch.as_tensor(P, device="cuda"))
 q0 = torch.as_tensor(r.standard_normal((C, D)), device="cuda")
 mod, extra = (hmc, (HMC_L,)) if HMC_L else (nuts, ())
+if os.environ.get("BLOCK_DENSE"):
+    from aehmc_amd.engine import get_engine
+    get_engine().set_option("block_dense", int(os.environ["BLOCK_DENSE"]))
 kernel = mod.new_kernel(RandomStream(seeds=list(range(C))), tgt)
 state = mod.new_state(q0, tgt)
 samples, info = kernel.sample(state, 0.3 * D ** -0.25, imm, *extra, 3)[:2]
