@@ -24,9 +24,34 @@ namespace aehmc {
 
 constexpr int BLK_REG_MAX_D = 256;
 inline bool block_reg_supported(long long D) { return D >= BLK_MIN_D && D <= BLK_REG_MAX_D; }
+constexpr int BLK_PARK = 16;  // doubles per wavefront: the chain's four generators (see k_nuts_block_reg)
 // two row buffers [16][S] (operand / result, swapping roles from product to product) + one staging tile per wavefront
+// + the target's mean [S] + the parking areas
 inline size_t blk_reg_lds_bytes(long long D) {
-  return ((size_t)2 * BLK_CHAINS * blk_lds_stride(D) + (size_t)BLK_CHAINS * BLK_TB) * sizeof(double);
+  return ((size_t)(2 * BLK_CHAINS + 1) * blk_lds_stride(D) + (size_t)BLK_CHAINS * (BLK_TB + BLK_PARK)) * sizeof(double);
+}
+
+// the chain's four generators have their home in LDS (d + 4 k): a draw loads ONE of them, advances it and puts it
+// back -- 8 registers for the duration of the draw instead of 32 for the duration of the launch
+__device__ __forceinline__ Pcg64 blk_gen_load(const double *d, int k) {
+  const unsigned long long *u = reinterpret_cast<const unsigned long long *>(d) + 4 * k;
+  Pcg64 g;
+  g.state = mk128(u[0], u[1]);
+  g.inc = mk128(u[2], u[3]);
+  return g;
+}
+__device__ __forceinline__ void blk_gen_store(double *d, int k, const Pcg64 &g, int lane) {
+  unsigned long long *u = reinterpret_cast<unsigned long long *>(d) + 4 * k;
+  if (lane == 0) {  // (every lane holds the same state)
+    u[0] = g.state.hi; u[1] = g.state.lo;
+    u[2] = g.inc.hi; u[3] = g.inc.lo;
+  }
+}
+__device__ __forceinline__ int blk_bernoulli(double *d, int k, double p, int lane) {
+  Pcg64 g = blk_gen_load(d, k);
+  const int r = rng_bernoulli(g, p);
+  blk_gen_store(d, k, g, lane);
+  return r;
 }
 
 // dst[16][S] = src[16][S] * Bp^T, both in LDS; the caller places the barriers
@@ -47,6 +72,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
   const int S = (int)blk_lds_stride(D);
   double *const xbuf = blk_lds, *const ybuf = blk_lds + BLK_CHAINS * S;
   double *const tb = blk_lds + 2 * BLK_CHAINS * S + wave * BLK_TB;
+  double *const mus = blk_lds + 2 * BLK_CHAINS * S + BLK_CHAINS * BLK_TB;  // the dense target's mean
+  // Register budget: 16 wavefronts per workgroup leave a lane 128 registers.  The chain's q, p, v and momentum sum
+  // (8 R registers), its tree state (wave-uniform, but the product of fp64 VALU arithmetic: ~26 VGPRs) and the
+  // product's ~45 fit; dU/dq and w do not have to be in registers (they stay in the LDS rows the products write), and
+  // the four generators (32 more: 64-bit integer VALU arithmetic) have their home in LDS, a draw holding one of them
+  // for its own duration.  A first version with q, p, g, v, w and the generators in registers spilled 270-450 bytes
+  // per lane: the spill code alone moved 2.9 TB/s through HBM and the kernel waited on it (profiles/r4/INDEX.md);
+  // now the per-leapfrog loop has no scratch access.
+  double *const park = mus + S + wave * BLK_PARK;
   double *const xrow = xbuf + wave * S, *const yrow = ybuf + wave * S;
   const size_t row = (size_t)(valid ? c : 0) * D;
   const bool elem = target_is_elem(a.tkind);
@@ -54,24 +88,30 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
     xrow[k] = 0.0;
     yrow[k] = 0.0;
   }
+  if (TDENSE)
+    for (int k = threadIdx.x; k < S; k += BLK_THREADS) mus[k] = k < D ? a.mu[k] : 0.0;
 #define EI(r) (lane + 64 * (r))
 #define AT(ptr, r) ((ptr) + row)[EI(r)]
   bool ok[R];
-  double q[R], p[R], g[R], v[R], w[R], pb[R], mur[TDENSE ? R : 1];
+  // q, p, v and the sub-trajectory momentum sum in registers; dU/dq and w = imm dU/dq stay where the products leave
+  // them, in the chain's rows of the two LDS buffers (dense target: P r lands in ybuf, imm g' in xbuf; coordinate-wise
+  // target: g' is written to xbuf as the operand, imm g' lands in ybuf) -- 16 registers less at R = 4
+  double q[R], p[R], v[R], pb[R];
+  double *const grow = TDENSE ? yrow : xrow, *const wrow = TDENSE ? xrow : yrow;
 #pragma unroll
   for (int r = 0; r < R; r++) {
     ok[r] = valid && EI(r) < D;
-    q[r] = p[r] = g[r] = v[r] = w[r] = pb[r] = 0.0;
-    if (TDENSE) mur[TDENSE ? r : 0] = ok[r] ? a.mu[EI(r)] : 0.0;
+    q[r] = p[r] = v[r] = pb[r] = 0.0;
   }
-  ChainRng rng = {};
   ChainCtl ct = {};
   ct.done = 1;
   double U_state = 0.0;
   long long nleap_sum = 0;
   double eps = 0.0;
   if (valid) {
-    rng = rng_load(a, c);
+    const ChainRng rng0 = rng_load(a, c);
+#pragma unroll
+    for (int k = 0; k < 4; k++) blk_gen_store(park, k, rng0.g[k], lane);
     U_state = a.U[c];
     eps = a.eps_c ? a.eps_c[c] : a.eps;
   }
@@ -86,8 +126,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (ok[r]) {
-        const double pp = p[r] - b * g[r];
-        const double vv = v[r] - b * w[r];
+        const double pp = p[r] - b * grow[EI(r)];
+        const double vv = v[r] - b * wrow[EI(r)];
         p[r] = pp;
         v[r] = vv;
         const double qq = q[r] + aa * vv;
@@ -96,10 +136,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
           double u, gnew;
           target_elem(a, EI(r), qq, u, gnew);
           usum += u;
-          g[r] = gnew;
-          xrow[EI(r)] = gnew;
+          xrow[EI(r)] = gnew;  // (= grow: the new gradient over the old one, and the next product's operand)
         } else {
-          xrow[EI(r)] = qq - mur[TDENSE ? r : 0];
+          xrow[EI(r)] = qq - mus[EI(r)];
         }
       }
     }
@@ -112,7 +151,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
       if (ok[r]) {
         AT(pick2(a.slot_q, slot), r) = q[r];
         AT(pick2(a.slot_p, slot), r) = p[r];
-        AT(pick2(a.slot_g, slot), r) = g[r];
+        AT(pick2(a.slot_g, slot), r) = grow[EI(r)];
       }
     }
     put2(ct.U_slot, slot, ct.U_cur);
@@ -141,9 +180,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
         d_r += vr * rho;
         AT(pick2(a.end_q, dir), r) = q[r];
         AT(pick2(a.end_p, dir), r) = pc;
-        AT(pick2(a.end_g, dir), r) = g[r];
+        AT(pick2(a.end_g, dir), r) = grow[EI(r)];
         AT(pick2(a.end_v, dir), r) = vc;
-        AT(pick2(a.end_w, dir), r) = w[r];
+        AT(pick2(a.end_w, dir), r) = wrow[EI(r)];
       }
     }
     d_l = wave_sum(d_l);
@@ -154,7 +193,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
     double pbias = exp(ct.sub_w - ct.prop_w);            // proposals.py:130 (always drawn)
     if (pbias > 1.0) pbias = 1.0;
     if (pbias < 0.0) pbias = 0.0;
-    const int acc_b = rng_bernoulli(rng.g[3], pbias);
+    const int acc_b = blk_bernoulli(park, 3, pbias, lane);
     if (is_div || has_term) {
       ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);  // trajectory.py:560-564
     } else {
@@ -190,7 +229,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
       ct.done = 1;  // (the caller keeps the chain alive while a phantom scan is pending)
     } else {        // nuts_begin_expansion
       ct.j += 1;
-      const int go_right = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
+      const int go_right = blk_bernoulli(park, 1, 0.5, lane);  // trajectory.py:516
       ct.dir = go_right;
       ct.step = 0;
       if (dir != go_right) {  // cur <- the other end (trajectory.py:518)
@@ -199,9 +238,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
           if (ok[r]) {
             q[r] = AT(pick2(a.end_q, go_right), r);
             p[r] = AT(pick2(a.end_p, go_right), r);
-            g[r] = AT(pick2(a.end_g, go_right), r);
+            grow[EI(r)] = AT(pick2(a.end_g, go_right), r);
             v[r] = AT(pick2(a.end_v, go_right), r);
-            w[r] = AT(pick2(a.end_w, go_right), r);
+            wrow[EI(r)] = AT(pick2(a.end_w, go_right), r);
           }
         }
         ct.U_cur = pick2(ct.U_end, go_right);
@@ -239,9 +278,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (ok[r]) {
-        if (TDENSE) usum += (q[r] - mur[TDENSE ? r : 0]) * g[r];  // leap_linear<3>
-        const double pn = p[r] - b * g[r];
-        const double vn = v[r] - b * w[r];
+        const double gr = grow[EI(r)], wr = wrow[EI(r)];
+        if (TDENSE) usum += (q[r] - mus[EI(r)]) * gr;  // leap_linear<3>
+        const double pn = p[r] - b * gr;
+        const double vn = v[r] - b * wr;
         p[r] = pn;
         v[r] = vn;
         kd += vn * pn;                                            // bookkeeping
@@ -261,6 +301,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
         }
       }
     }
+    tm.tick(0);  // (timing build) vector pass incl. the first-level checkpoint loads
     if (TDENSE) ct.U_cur = target_finish(a, wave_sum(usum));
     kd = wave_sum(kd);
     ct.tmin = tmin;
@@ -270,23 +311,27 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
     if (isnan(delta)) delta = -INFINITY;
     const bool div = fabs(delta) > a.thr;
     const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
-    bool term = false;
+    bool term = false, do_take = false;
     if (step == 0) {
       ct.sub_E = E;
       ct.sub_w = np_w;
       ct.sub_slpa = np_slpa;
       ct.length = 1;
-      take(ct.prop_slot ^ 1);
+      do_take = true;
     } else {
       const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
-      const int acc = rng_bernoulli(rng.g[2], sc.pa);
+      const int acc = blk_bernoulli(park, 2, sc.pa, lane);
       ct.sub_w = sc.sub_w;
       ct.sub_slpa = sc.sub_slpa;
       if (acc) {
         ct.sub_E = E;
-        if (!ct.phantom) take(ct.prop_slot ^ 1);
+        do_take = !ct.phantom;
       }
       ct.length += 1;
+    }
+    if (do_take) take(ct.prop_slot ^ 1);  // sub-trajectory proposal <- moving end (one call site: the copy is inlined once)
+    tm.tick(1);  // (timing build) reductions, step scalars, accept draw, proposal copy
+    if (step >= 1) {
       if (tmax >= tmin) {  // termination.py:133-187
         int idx = tmax;
         bool crit = false;
@@ -327,18 +372,28 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
         term = crit;
       }
     }
+    bool fin = false, fin_div = false, fin_term = false, to_phantom = false;
     if (step == 0 && div && !ct.phantom) {
       // trajectory.py:336: integrate() returns the first-step tuple, yet the scan still executes (and draws from
       // site #3): finalize now, keep stepping as a phantom
-      finalize(true, false);
-      ct.done = 0;
-      ct.phantom = 1;
-      ct.step = 1;
+      fin = fin_div = to_phantom = true;
     } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
       if (ct.phantom) ct.done = 1;
-      else finalize(div, term);
+      else {
+        fin = true;
+        fin_div = div;
+        fin_term = term;
+      }
     } else {
       ct.step = step + 1;
+    }
+    if (fin) {  // (one call site: the expansion code is inlined once)
+      finalize(fin_div, fin_term);
+      if (to_phantom) {
+        ct.done = 0;
+        ct.phantom = 1;
+        ct.step = 1;
+      }
     }
   };
 
@@ -346,7 +401,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
   for (long long t_idx = 0; t_idx < m.T; t_idx++) {
     // ---- momentum: z (site #1) -> p = L^-T z, v = imm p; w = imm dU/dq (metrics.py:65-68, nuts.py:113-125) ----
     if (valid) {
-      wave_normals(rng.g[0], D, [=](long long i, double z) { xrow[i] = z; });
+      Pcg64 g0 = blk_gen_load(park, 0);
+      wave_normals(g0, D, [=](long long i, double z) { xrow[i] = z; });
+      blk_gen_store(park, 0, g0, lane);
       __threadfence_block();
     }
     tm.tick(7);
@@ -354,21 +411,19 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
     blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb);
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; r++)
-      if (ok[r]) p[r] = yrow[EI(r)];
+    for (int r = 0; r < R; r++) p[r] = ok[r] ? yrow[EI(r)] : 0.0;
     blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      if (ok[r]) {
-        v[r] = xrow[EI(r)];
-        g[r] = AT(a.g, r);
-        q[r] = AT(a.q, r);
-        yrow[EI(r)] = g[r];
-      }
+      v[r] = ok[r] ? xrow[EI(r)] : 0.0;
+      q[r] = ok[r] ? AT(a.q, r) : 0.0;
+      pb[r] = 0.0;
+      if (ok[r]) grow[EI(r)] = AT(a.g, r);  // the operand row of w = imm dU/dq, and dU/dq's home from here on
     }
     __syncthreads();
-    blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);
+    if (TDENSE) blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);
+    else blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);
     __syncthreads();
     tm.tick(2);
     if (valid) {  // nuts_init_chain<true>
@@ -376,19 +431,19 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
 #pragma unroll
       for (int r = 0; r < R; r++) {
         if (ok[r]) {
-          w[r] = xrow[EI(r)];
+          const double gr = grow[EI(r)], wr = wrow[EI(r)];
           kd += v[r] * p[r];
 #pragma unroll
           for (int e = 0; e < 2; e++) {
             AT(a.end_q[e], r) = q[r];
             AT(a.end_p[e], r) = p[r];
-            AT(a.end_g[e], r) = g[r];
+            AT(a.end_g[e], r) = gr;
             AT(a.end_v[e], r) = v[r];
-            AT(a.end_w[e], r) = w[r];
+            AT(a.end_w[e], r) = wr;
           }
           AT(a.slot_q[0], r) = q[r];
           AT(a.slot_p[0], r) = p[r];
-          AT(a.slot_g[0], r) = g[r];
+          AT(a.slot_g[0], r) = gr;
           AT(a.psum, r) = p[r];
         }
       }
@@ -408,17 +463,18 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
       ct.done = ct.phantom = 0;
       ct.prop_slot = 0;
       ct.ndoubl = ct.out_div = ct.out_turn = 0;
-      ct.dir = rng_bernoulli(rng.g[1], 0.5);  // trajectory.py:516
+      ct.dir = blk_bernoulli(park, 1, 0.5, lane);  // trajectory.py:516
       ct.step = 0;
-      stage12();
     }
     tm.tick(7);
-    // ---- one leapfrog of every live chain per trip ----
+    // ---- one leapfrog of every live chain per trip: first stages | P r | imm g' | last stage + bookkeeping ----
     for (;;) {
-      const int live = __syncthreads_or(valid && !ct.done);
+      if (valid && !ct.done) stage12();
+      tm.tick(5);
+      const bool alive = valid && !ct.done;
+      const int live = __syncthreads_or(alive);
       tm.tick(6);  // vote (waits for the slowest chain's bookkeeping)
       if (!live) break;
-      const bool alive = valid && !ct.done;
       if (TDENSE) {
         blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb);  // dU/dq' = P r
         tm.tick(2);
@@ -428,31 +484,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
         tm.tick(2);
         __syncthreads();
         tm.tick(3);
-        if (alive) {
-#pragma unroll
-          for (int r = 0; r < R; r++) {
-            if (ok[r]) {
-              g[r] = yrow[EI(r)];
-              w[r] = xrow[EI(r)];
-            }
-          }
-        }
       } else {
         blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);   // w' = imm dU/dq'
         tm.tick(2);
         __syncthreads();
         tm.tick(3);
-        if (alive) {
-#pragma unroll
-          for (int r = 0; r < R; r++)
-            if (ok[r]) w[r] = yrow[EI(r)];
-        }
       }
       if (alive) {
         book();
         tm.tick(4);
-        if (!ct.done) stage12();
-        tm.tick(5);
       }
     }
     // ---- per-transition records (the outputs themselves were written when the transition ended) ----
@@ -472,7 +512,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
     }
   }
   if (valid) {
-    rng_store(a, c, lane, rng, 0, 3);
+    ChainRng rng1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) rng1.g[k] = blk_gen_load(park, k);
+    rng_store(a, c, lane, rng1, 0, 3);
     if (lane == 0 && m.nleap_total) m.nleap_total[c] = nleap_sum;
 #ifdef AEHMC_WIDE_TIMING
     if (lane == 0)
@@ -484,8 +527,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
 #undef AT
 }
 
-// HMC: nt transitions x L leapfrogs, the chains' state in registers (hmc_run's lock-step loop: hmc_init_chain,
-// leap_linear<12> / <3>, hmc_end_chain)
+// HMC: nt transitions x L leapfrogs, the chains' q, p, v in registers, dU/dq and w = imm dU/dq in the LDS rows the
+// products write (as above) -- hmc_run's lock-step loop: hmc_init_chain, leap_linear<12> / <3>, hmc_end_chain.  The
+// state a rejection falls back to is the caller's q / dU/dq, rewritten at every accepted transition.
 template <int R, bool TDENSE>
 __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, const double *prec, long long L,
                                                                 long long nt, double *samples, double *acc_hist,
@@ -499,23 +543,25 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
   const int S = (int)blk_lds_stride(D);
   double *const xbuf = blk_lds, *const ybuf = blk_lds + BLK_CHAINS * S;
   double *const tb = blk_lds + 2 * BLK_CHAINS * S + wave * BLK_TB;
+  double *const mus = blk_lds + 2 * BLK_CHAINS * S + BLK_CHAINS * BLK_TB;
   double *const xrow = xbuf + wave * S, *const yrow = ybuf + wave * S;
+  double *const grow = TDENSE ? yrow : xrow, *const wrow = TDENSE ? xrow : yrow;
   const size_t row = (size_t)(valid ? c : 0) * D;
   for (int k = lane; k < S; k += 64) {
     xrow[k] = 0.0;
     yrow[k] = 0.0;
   }
+  if (TDENSE)
+    for (int k = threadIdx.x; k < S; k += BLK_THREADS) mus[k] = k < D ? a.mu[k] : 0.0;
 #define EI(r) (lane + 64 * (r))
 #define AT(ptr, r) ((ptr) + row)[EI(r)]
   bool ok[R];
-  double q[R], p[R], g[R], v[R], w[R], q0[R], g0[R], p0[R], mur[TDENSE ? R : 1];
+  double q[R], p[R], v[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     ok[r] = valid && EI(r) < D;
     q[r] = ok[r] ? AT(a.q, r) : 0.0;
-    g[r] = ok[r] ? AT(a.g, r) : 0.0;
-    p[r] = v[r] = w[r] = q0[r] = g0[r] = p0[r] = 0.0;
-    if (TDENSE) mur[TDENSE ? r : 0] = ok[r] ? a.mu[EI(r)] : 0.0;
+    p[r] = v[r] = 0.0;
   }
   Pcg64 g1 = {}, g2 = {};
   double U = 0.0, eps = 0.0, pa = 0.0;
@@ -529,6 +575,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
   const double b = 0.5 * (1.0 * eps), aa = 1 * (1.0 * eps);  // direction +1 (launch_leapfrog: ct.dir = 1)
   __syncthreads();
   for (long long tt = 0; tt < nt; tt++) {
+    const bool last_t = tt == nt - 1;
     if (valid) {
       wave_normals(g1, D, [=](long long i, double z) { xrow[i] = z; });
       __threadfence_block();
@@ -537,31 +584,26 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
     blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb);  // p = L^-T z
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; r++)
-      if (ok[r]) p[r] = yrow[EI(r)];
+    for (int r = 0; r < R; r++) p[r] = ok[r] ? yrow[EI(r)] : 0.0;
     blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);        // v = imm p
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; r++) {
+      v[r] = ok[r] ? xrow[EI(r)] : 0.0;
       if (ok[r]) {
-        v[r] = xrow[EI(r)];
-        yrow[EI(r)] = g[r];
+        grow[EI(r)] = AT(a.g, r);  // the operand row of w = imm dU/dq, and dU/dq's home during the trajectory
+        // only the last transition's momentum is observable: the initial one is kept on rejection
+        if (last_t && a.out.momentum) AT(a.out.momentum, r) = p[r];
       }
     }
     __syncthreads();
-    blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);        // w = imm dU/dq
+    if (TDENSE) blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);  // w = imm dU/dq
+    else blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);
     __syncthreads();
     double kd = 0.0;
 #pragma unroll
-    for (int r = 0; r < R; r++) {  // hmc_init_chain<true>
-      if (ok[r]) {
-        w[r] = xrow[EI(r)];
-        kd += v[r] * p[r];
-        p0[r] = p[r];
-        q0[r] = q[r];
-        g0[r] = g[r];
-      }
-    }
+    for (int r = 0; r < R; r++)  // hmc_init_chain<true>
+      if (ok[r]) kd += v[r] * p[r];
     kd = wave_sum(kd);
     const double H0 = U + 0.5 * kd;  // hmc.py:187
     double U_cur = U;
@@ -570,8 +612,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
 #pragma unroll
       for (int r = 0; r < R; r++) {
         if (ok[r]) {
-          const double pp = p[r] - b * g[r];
-          const double vv = v[r] - b * w[r];
+          const double pp = p[r] - b * grow[EI(r)];
+          const double vv = v[r] - b * wrow[EI(r)];
           p[r] = pp;
           v[r] = vv;
           const double qq = q[r] + aa * vv;
@@ -580,10 +622,9 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
             double u, gnew;
             target_elem(a, EI(r), qq, u, gnew);
             usum += u;
-            g[r] = gnew;
             xrow[EI(r)] = gnew;
           } else {
-            xrow[EI(r)] = qq - mur[TDENSE ? r : 0];
+            xrow[EI(r)] = qq - mus[EI(r)];
           }
         }
       }
@@ -602,15 +643,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
 #pragma unroll
       for (int r = 0; r < R; r++) {
         if (ok[r]) {
-          if (TDENSE) {
-            g[r] = yrow[EI(r)];
-            w[r] = xrow[EI(r)];
-            usum += (q[r] - mur[TDENSE ? r : 0]) * g[r];
-          } else {
-            w[r] = yrow[EI(r)];
-          }
-          p[r] = p[r] - b * g[r];
-          v[r] = v[r] - b * w[r];
+          const double gr = grow[EI(r)], wr = wrow[EI(r)];
+          if (TDENSE) usum += (q[r] - mus[EI(r)]) * gr;
+          p[r] = p[r] - b * gr;
+          v[r] = v[r] - b * wr;
         }
       }
       if (TDENSE && valid) U_cur = target_finish(a, wave_sum(usum));
@@ -634,14 +670,19 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
       if (pa > 1.0) pa = 1.0;
       if (pa < 0.0) pa = 0.0;
       acc = rng_bernoulli(g2, pa);  // hmc.py:193-194
-      if (acc) {
+      if (acc) {  // the caller's arrays follow every accepted transition (they are the state a rejection falls back to)
         U = U_cur;
-      } else {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          q[r] = q0[r];
-          g[r] = g0[r];
+          if (ok[r]) {
+            AT(a.q, r) = q[r];
+            AT(a.g, r) = grow[EI(r)];
+            if (last_t && a.out.momentum) AT(a.out.momentum, r) = -1.0 * p[r];
+          }
         }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) q[r] = ok[r] ? AT(a.q, r) : 0.0;
       }
       if (samples) {
         double *dst = samples + ((size_t)tt * a.C + c) * D;
@@ -655,24 +696,14 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
       }
     }
   }
-  if (valid) {
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (ok[r]) {
-        AT(a.q, r) = q[r];
-        AT(a.g, r) = g[r];
-        if (a.out.momentum) AT(a.out.momentum, r) = acc ? -1.0 * p[r] : p0[r];
-      }
-    }
-    if (lane == 0) {
-      pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
-      pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
-      a.U[c] = U;
-      a.out.acceptance_probability[c] = pa;
-      a.out.is_diverging[c] = is_div;
-      if (a.out.n_leapfrog) a.out.n_leapfrog[c] = L;
-      if (a.out.is_turning) a.out.is_turning[c] = acc;  // HMC: reused as the accept flag
-    }
+  if (valid && lane == 0) {
+    pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
+    pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
+    a.U[c] = U;
+    a.out.acceptance_probability[c] = pa;
+    a.out.is_diverging[c] = is_div;
+    if (a.out.n_leapfrog) a.out.n_leapfrog[c] = L;
+    if (a.out.is_turning) a.out.is_turning[c] = acc;  // HMC: reused as the accept flag
   }
 #undef EI
 #undef AT

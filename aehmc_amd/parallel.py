@@ -85,6 +85,24 @@ def gather_samples(x: torch.Tensor, dst: int = 0):
     return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
 
 
+def shard_checksums(x: torch.Tensor):
+    """One int64 per rank: the wrap-around sum of the BIT PATTERNS of the rank's rows -- rank 0 compares them with the
+    same sum over each shard of the gathered array (the gather must move the rows bit for bit).  Returns a [world]
+    int64 tensor on every rank."""
+    own = x.contiguous().view(torch.int64).sum().reshape(1)
+    if not _on():
+        return own
+    if _cpu_backend() and own.is_cuda:
+        return shard_checksums_cpu(own.cpu()).to(x.device)
+    return shard_checksums_cpu(own)
+
+
+def shard_checksums_cpu(own: torch.Tensor):
+    parts = [torch.zeros_like(own) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, own)
+    return torch.cat(parts)
+
+
 def max_over_ranks(v: float, device=None) -> float:
     if not _on():
         return v

@@ -51,13 +51,16 @@ def lib_sha256():
 PMC_STALE = {}  # summary name -> why its counters were NOT used in this run's line
 
 
+PROFILES_DIR = os.environ.get("AEHMC_PROFILES_DIR") or os.path.join(ROOT, "profiles")  # where the summaries are looked up
+
+
 def pmc_summary(name):
     """Counter summaries are collected OFFLINE (rocprofv3 --pmc cannot run inside the bench): the newest committed
     profiles/rN/<name>, and only if it was measured on the very binary this run loads -- every summary stores the
     sha256 of the libaehmc_hip.so it profiled (`lib_sha256`); one without it, or with another hash, is NOT used:
     peak / frac / traffic derived from it are dropped from the line and `counters_dropped` says why."""
     for rnd in ("r4", "r3", "r2", "r1"):
-        path = os.path.join(ROOT, "profiles", rnd, name)
+        path = os.path.join(PROFILES_DIR, rnd, name)
         if os.path.exists(path):
             summ = json.load(open(path))
             have = summ.get("lib_sha256")
@@ -328,7 +331,7 @@ def main():
 
     from aehmc_amd import RandomStream, hmc, nuts, targets
     from aehmc_amd.engine import get_engine
-    from aehmc_amd.parallel import barrier, gather_samples, max_over_ranks, sum_over_ranks
+    from aehmc_amd.parallel import barrier, gather_samples, max_over_ranks, shard_checksums, sum_over_ranks
 
     strong = args.config == "c4"
     if strong:  # config 4: 32768 chains sharded across the GPUs of the node
@@ -402,6 +405,13 @@ def main():
     kern_ms, kern_n, kern_flops = eng.profile_read()
     eng.profile_enable(False)
     assert rank != 0 or gathered.shape[0] == C * world
+    # the gather moved every rank's rows bit for bit: per-rank checksums of the bit patterns against the same sums
+    # over the shards of the gathered array (outside the timed region)
+    sums = shard_checksums(state.position)
+    rows_match = None
+    if rank == 0:
+        got = torch.stack([gathered[r * C:(r + 1) * C].contiguous().view(torch.int64).sum() for r in range(world)])
+        rows_match = bool(torch.equal(got.cpu(), sums.cpu()))
 
     if rank != 0:
         return
@@ -477,7 +487,7 @@ def main():
                    "lib_sha256": lib_sha256(),
                    "leapfrogs_per_step": total_leap / args.steps, "ranks_seen": ranks_seen,
                    "gather": {"to": "rank 0", "bytes": (world - 1) * C * D * 8, "ms": t_g * 1e3,
-                              "backend": dist_backend}},
+                              "backend": dist_backend, "rows_match_ranks_bitwise": rows_match}},
         "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))
 
 
@@ -485,9 +495,13 @@ def bench_c1(args):
     """Config c1 (plumbing check): README example, one chain, NUTS, eps=1e-2 -- the reference
     runtime (Aesara C backend) is unavailable; the value must equal README.md:53-54."""
     from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
     target = targets.StdNormal()
     times, pos, nl = [], None, 0
-    for _ in range(args.warmup + args.steps):
+    for i in range(args.warmup + args.steps):
+        if i == args.warmup:
+            eng.profile_enable(True)
         kernel = nuts.new_kernel(RandomStream(seed=0), target)
         state = nuts.new_state(0.0, target)
         torch.cuda.synchronize()
@@ -496,14 +510,39 @@ def bench_c1(args):
         pos = info.state.position.item()
         times.append(time.perf_counter() - t0)
         nl = int(info.n_leapfrog.item())
+    kern_ms, kern_n, _ = eng.profile_read()
+    eng.profile_enable(False)
     dt = sum(times[args.warmup:]) / max(args.steps, 1)
+    # One wavefront walks the 136 leapfrogs of the tree one dependent instruction after the other: neither HBM nor the
+    # matrix cores bound it, the ISSUE LATENCY of a lone wavefront does.  peak = clock / (issue cycles per leapfrog at
+    # the COUNTED instruction mix: 4 cycles per 64-lane VALU instruction on its 16-lane SIMD, one per scalar / LDS /
+    # memory / branch instruction; rocprofv3 counters of this very launch, profiles/r4/c1_pmc_summary.json);
+    # achieved = leapfrogs / the kernel's launch duration (HIP events on the launch stream).
+    avg_s = kern_ms / 1e3 / max(kern_n, 1)
+    pj, src = pmc_summary("c1_pmc_summary.json")
+    roofline = {"bound": "latency", "unit": "leapfrog-steps/s", "kernel": "k_nuts_resident<64, 1> (one wavefront)",
+                "avg_launch_ms": avg_s * 1e3, "launches": kern_n, "achieved": nl / avg_s if avg_s > 0 else None,
+                "peak": None, "frac": None, "traffic": None, "traffic_source": src,
+                "counters_dropped": PMC_STALE.get("c1_pmc_summary.json"),
+                "whole_call_leapfrogs_per_s": nl / dt,
+                "note": "latency roofline of a single wavefront: issue cycles per leapfrog at the counted instruction mix; the "
+                        "whole call adds ~0.06 ms of host work and the read-back to the kernel"}
+    if pj and roofline["achieved"]:
+        d = pj["derived"]
+        roofline.update({"peak": d["latency_roofline_leapfrogs_per_s_at_2.4GHz"],
+                         "frac": roofline["achieved"] / d["latency_roofline_leapfrogs_per_s_at_2.4GHz"],
+                         "issue_cycles_per_leapfrog": d["issue_cycles_per_leapfrog_lower_bound"],
+                         "valu_instructions_per_leapfrog": d["valu_instructions_per_leapfrog"],
+                         "salu_instructions_per_leapfrog": d["salu_instructions_per_leapfrog"],
+                         "clock_GHz_during_the_profiled_launch": d.get("clock_GHz_grbm")})
     print(json.dumps({
         "metric": "leapfrog-steps/sec across all chains", "value": nl / dt, "unit": "leapfrog-steps/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "c1: README example, 1-D standard normal, NUTS, step_size=1e-2, single chain",
-                   "position": pos, "matches_readme_value": pos == 1.1034719409361107, "leapfrogs": nl},
-        "roofline": None, "cpu_baseline": None}))
+                   "position": pos, "matches_readme_value": pos == 1.1034719409361107, "leapfrogs": nl,
+                   "lib_sha256": lib_sha256()},
+        "roofline": roofline, "cpu_baseline": None}))
 
 
 def bench_c5(args, rank, world, device):

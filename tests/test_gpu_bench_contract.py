@@ -38,11 +38,37 @@ def test_bench_c2_line():
     assert "workload" in d["config"] and d["value"] > 1e8
     r, c = d["roofline"], d["cpu_baseline"]
     # the kernel is bound by fp64 VALU issue: `frac` is the fraction of the issue ceiling at the counted
-    # instructions per transition (offline rocprofv3 counters, labelled), HBM is reported beside it
-    assert r["bound"] == "valu" and r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac"] < 1
-    assert r["traffic_source"].startswith("profiles/") and r["hbm"]["frac"] < 0.05
+    # instructions per transition (offline rocprofv3 counters of THIS build of the library, labelled with its hash),
+    # HBM is reported beside it; counters of another build are dropped and the line says why
+    assert r["bound"] == "valu" and len(d["config"]["lib_sha256"]) == 64
+    if r["counters_dropped"]:
+        assert r["peak"] is None and r["frac"] is None and r["traffic"] is None and r["traffic_source"] is None
+    else:
+        assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac"] < 1
+        assert r["traffic_source"].startswith("profiles/") and d["config"]["lib_sha256"][:16] in r["traffic_source"]
+        assert r["hbm"]["frac"] < 0.05
     assert 0 < r["fp64_flops"]["frac"] < 1
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_counters_of_another_build_are_dropped(tmp_path):
+    """Every counter summary under profiles/ carries the sha256 of the libaehmc_hip.so it was measured on; bench.py uses
+    it only when that is the library it has loaded.  A summary with another hash: peak / frac / traffic are blanked and
+    `counters_dropped` says why; the same summary with the right hash: the fraction is back."""
+    from aehmc_amd import _build
+    derived = {"valu_issue_ceiling_leapfrogs_per_s_at_this_instruction_count": 2.2e10, "hbm_bytes_per_launch": 2.4e7,
+               "valu_instructions_per_wave_per_transition": 870.0, "leapfrog_fp64_instructions_per_transition": 384,
+               "valu_busy_fraction_of_kernel_time_at_2.4GHz": 0.7}
+    (tmp_path / "r4").mkdir()
+    env = dict(os.environ, AEHMC_PROFILES_DIR=str(tmp_path))
+    (tmp_path / "r4" / "c2_pmc_summary.json").write_text(json.dumps({"lib_sha256": "0" * 64, "derived": derived}))
+    r = _run("--config", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", env=env)["roofline"]
+    assert r["frac"] is None and r["peak"] is None and r["traffic"] is None
+    assert "another build" in r["counters_dropped"] and "0000000000000000" in r["counters_dropped"]
+    (tmp_path / "r4" / "c2_pmc_summary.json").write_text(json.dumps({"lib_sha256": _build.library_hash(), "derived": derived}))
+    r = _run("--config", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", env=env)["roofline"]
+    assert r["counters_dropped"] is None and r["peak"] == 2.2e10 and r["frac"] == pytest.approx(r["achieved"] / 2.2e10)
+    assert r["traffic"] == 2.4e7 and _build.library_hash()[:16] in r["traffic_source"]
 
 
 def test_bench_c3_small_line():
@@ -64,6 +90,23 @@ def test_bench_gpus2_starts_two_ranks():
              "--no-cpu-baseline", env=env)
     assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["chains_total"] == 128
     assert d["config"]["gather"]["bytes"] == 64 * 256 * 8 and d["value"] > 0
+    assert d["config"]["gather"]["rows_match_ranks_bitwise"] is True
+
+
+def test_bench_two_gpus_over_rccl():
+    """Self-skipping: on a box with >= 2 GPUs `bench.py --gpus 2 --config c4` runs one rank per GPU over the REAL
+    backend (RCCL over xGMI): both ranks seen, the gather moves the second rank's rows to rank 0 bit for bit, its time
+    is reported.  (The pool's 1-GPU boxes skip it; the driver's multi-GPU node exercises the N > 1 path.)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AEHMC_BENCH_ONE_DEVICE",
+                                                            "AEHMC_DIST_BACKEND")}
+    d = _run("--gpus", "2", "--config", "c4", "--dim", "2048", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", env=env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["ranks_seen"] == 2
+    g = d["config"]["gather"]
+    assert g["backend"] == "nccl" and g["rows_match_ranks_bitwise"] is True and g["ms"] > 0
+    assert g["bytes"] == 16384 * 2048 * 8 and d["value"] > 0
 
 
 def test_bench_c4_and_c5_two_rank_dry_runs():
@@ -90,10 +133,15 @@ def test_bench_default_line_has_five_good_secondary_entries():
     assert all(k in d for k in REQUIRED) and d["roofline"]["bound"] == "mfma"
     assert d["config"]["dim"] == 10_000 and d["config"]["chains_total"] == 4096
     sec = d["secondary"]
-    assert [e["config"] for e in sec] == ["diag-nuts", "diag-hmc", "c2", "c5", "c1"]
+    assert [e["config"] for e in sec] == ["diag-nuts", "diag-hmc", "diag-hmc-fp_contract", "c2", "c2-fp_contract", "c5", "c1"]
     for e in sec:
         assert "error" not in e and e["value"] > 0, e
-    assert sec[3]["roofline"]["bound"] == "valu" and sec[2]["roofline"]["bound"] == "valu"
+    by = {e["config"]: e for e in sec}
+    assert by["c5"]["roofline"]["bound"] == "valu" and by["c2"]["roofline"]["bound"] == "valu"
+    assert by["c1"]["roofline"]["bound"] == "latency"
+    # the fast-arithmetic mode is faster where the leapfrog loop dominates, and says that it is not the bit-exact mode
+    assert by["diag-hmc-fp_contract"]["value"] > 1.15 * by["diag-hmc"]["value"]
+    assert "fp_contract=1" in by["c2-fp_contract"]["workload"] and "fp_contract" not in by["c2"]["workload"]
 
 
 def test_parallel_collectives_on_rccl_one_rank():

@@ -42,6 +42,12 @@ def _worker(rank, world, port, total, tmp):
         assert torch.equal(g, ga)
     assert parallel.max_over_ranks(float(rank)) == world - 1
     assert parallel.sum_over_ranks(hi - lo) == total
+    # per-rank checksums of the rows' bit patterns (bench.py checks the gather with them)
+    sums = parallel.shard_checksums(x)
+    assert sums.shape == (world,) and sums[rank] == x.view(torch.int64).sum()
+    if rank == 0:
+        bounds = [parallel.shard_chains(total, r, world) for r in range(world)]
+        assert [int(g[a:b].contiguous().view(torch.int64).sum()) for a, b in bounds] == sums.tolist()
     if rank == 0:
         np.save(os.path.join(tmp, "gathered.npy"), g.numpy())
     dist.destroy_process_group()

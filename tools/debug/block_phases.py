@@ -36,7 +36,9 @@ off = (26 + 3 * E) * vec
 tim = ws[off: off + C * 8 * 8].view(torch.float64).reshape(C, 8).cpu().numpy()
 nl = info.n_leapfrog.cpu().numpy()
 blocks = nl[: C // 16 * 16].reshape(-1, 16).max(axis=1)
-names = ["rows->LDS", "barrier A", "MFMA", "barrier B", "book", "leap12", "vote", "begin"]  # (register kernel: 0, 1 unused)
+names = ["rows->LDS", "barrier A", "MFMA", "barrier B", "book", "leap12", "vote", "begin"]
+if D <= 256 and os.environ.get("BLOCK_DENSE", "1") == "1":  # the register kernel's phases
+    names = ["book: pass", "book: scal", "MFMA", "barriers", "book: rest", "stage12", "vote", "begin"]
 if os.environ.get("BLOCK_DENSE"):
     pass
 tot = tim.sum(axis=1)
