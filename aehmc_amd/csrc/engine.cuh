@@ -16,9 +16,11 @@
 //   expansion loop            trajectory.py:428-714, nuts.py:56-153
 //   HMC accept/reject         hmc.py:157-204
 #pragma once
+#ifndef __HIPCC_RTC__  /* (hipRTC supplies the runtime, the math functions and the fixed-width integers itself) */
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#endif
 
 #include "../../include/aehmc_hip.h"
 #include "linreg_rows.cuh"
@@ -57,6 +59,7 @@ struct EngineArgs {
   const double *mu, *sigma, *log_sigma;
   const double *X, *y;  // linreg data [N]
   long long N;
+  const double *const *cparams;  // user-defined target (AEHMC_T_CUSTOM): device array of its parameter arrays
   // per-chain RNG [C, nsites, 4]
   uint64_t *rng;
   int nsites;
@@ -206,6 +209,11 @@ __device__ __forceinline__ void target_elem(const EngineArgs &a, long long i, do
       u = q * q;  // U = 0.5 * sum
       g = q;
       break;
+#ifdef AEHMC_CUSTOM_TARGET  // run-time compiled copy of these kernels (aehmc_set_custom_target): the user's function
+    case AEHMC_T_CUSTOM:
+      aehmc_custom_elem(q, i, a.cparams, u, g);
+      break;
+#endif
     default: {  // AEHMC_T_DIAG_GAUSSIAN
       double s = a.sigma[i];
       double z = (q - a.mu[i]) / s;
@@ -218,7 +226,7 @@ __device__ __forceinline__ double target_finish(const EngineArgs &a, double usum
   return (a.tkind == AEHMC_T_ISO_GAUSSIAN || a.tkind == AEHMC_T_DENSE_MVN) ? 0.5 * usum : usum;
 }
 __device__ __forceinline__ bool target_is_elem(int k) {
-  return k == AEHMC_T_STD_NORMAL || k == AEHMC_T_ISO_GAUSSIAN || k == AEHMC_T_DIAG_GAUSSIAN;
+  return k == AEHMC_T_STD_NORMAL || k == AEHMC_T_ISO_GAUSSIAN || k == AEHMC_T_DIAG_GAUSSIAN || k == AEHMC_T_CUSTOM;
 }
 // diagonal / scalar velocity imm o p (metrics.py:47,51,71)
 __device__ __forceinline__ double vel_diag(const EngineArgs &a, long long c, long long i, double p) {

@@ -2,9 +2,11 @@
 // in engine.cuh / gemm_f64.cuh / hmc_fused.cuh.  No torch types, no CPU fallback: every
 // entry point launches HIP kernels or fails with an error code.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -81,6 +83,17 @@ struct aehmc_ctx {
   size_t fd_ws_bytes = 0;
   double *blk_pack = nullptr;  // block-resident dense kernels: the launch's matrices zero-padded to [Dp][Dp] (kept, grown)
   size_t blk_pack_bytes = 0;
+  // user-defined target (aehmc_set_custom_target): its source, the kernels compiled against it (hipRTC code objects
+  // keyed by program + source, kept for the life of the ctx) and the device array of its parameter arrays
+  std::string custom_src, custom_inc;
+  const double **d_cparams = nullptr;
+  int n_cparams = 0;
+  uint64_t pcg_jump[64][4] = {};  // the LCG jump-ahead table (every code object has its own __constant__ copy)
+  struct RtcProgram {
+    hipModule_t mod = nullptr;
+    std::map<std::string, hipFunction_t> fn;
+  };
+  std::map<std::string, RtcProgram> rtc;
 };
 
 #define HIPCHK(expr)                                                                     \
@@ -137,6 +150,7 @@ extern "C" int aehmc_create(aehmc_ctx **out, int device) {
     jump[k][3] = (uint64_t)G;
   }
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_pcg_jump), jump, sizeof(jump)));
+  memcpy(ctx->pcg_jump, jump, sizeof(jump));
   HIPCHK(hipHostMalloc((void **)&ctx->h_active, NRING * sizeof(int), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void **)&ctx->d_active, ctx->h_active, 0));
   for (int i = 0; i < NRING; i++) HIPCHK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
@@ -176,6 +190,9 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (ctx->pc_work) (void)hipFree(ctx->pc_work);
   if (ctx->fd_ws) (void)hipFree(ctx->fd_ws);
   if (ctx->blk_pack) (void)hipFree(ctx->blk_pack);
+  if (ctx->d_cparams) (void)hipFree(ctx->d_cparams);
+  for (auto &kv : ctx->rtc)
+    if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   for (int i = 0; i < NRING; i++)
     if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
   for (auto e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -219,6 +236,124 @@ extern "C" int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *t) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
   }
+  return 0;
+}
+
+// ------------------------------------------------------------------ user-defined targets (hipRTC)
+// The kernels that evaluate the target are templates / inline functions of engine.cuh, nuts_resident.cuh and
+// hmc_fused.cuh; for a user-defined coordinate-wise target they are compiled at run time against the user's
+// aehmc_custom_elem (engine.cuh: target_elem's AEHMC_T_CUSTOM case).  One hipRTC program per kernel family, compiled
+// on first use: `which` = "base" (the lock-step engine's target-dependent kernels + new_state), "nuts" (one
+// k_nuts_resident instantiation), "hmc" (one k_hmc_fused instantiation).
+static const char *RTC_PROLOGUE =
+    "typedef signed int int32_t; typedef unsigned int uint32_t; typedef long long int64_t;\n"
+    "typedef unsigned long long uint64_t; typedef unsigned long long uintptr_t; typedef unsigned long size_t;\n"
+    "#define INFINITY __builtin_huge_val()\n"
+    "#define AEHMC_CUSTOM_TARGET 1\n";
+static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vector<std::string> &names,
+                        const std::string &want, hipFunction_t *out) {
+  const std::string key = which + "|" + (which == "base" ? std::string() : want);
+  auto it = ctx->rtc.find(key);
+  if (it == ctx->rtc.end()) {
+    if (ctx->custom_src.empty()) FAIL("internal: no user-defined target source");
+    std::string src = RTC_PROLOGUE;
+    src += "#line 1 \"custom_target\"\n" + ctx->custom_src + "\n";
+    src += "#include \"engine.cuh\"\n";
+    if (which == "nuts") src += "#include \"nuts_resident.cuh\"\n";
+    if (which == "hmc") src += "#include \"hmc_fused.cuh\"\n";
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "aehmc_custom.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+      FAIL("hiprtcCreateProgram failed");
+    for (const auto &n : names) hiprtcAddNameExpression(prog, n.c_str());
+    hiprtcAddNameExpression(prog, "&aehmc::c_pcg_jump");
+    const std::string inc = "-I" + ctx->custom_inc;
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str(),
+                          "-mllvm", "-disable-machine-licm"};  // (the flags of csrc/Makefile)
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 7, opts);
+    if (rc != HIPRTC_SUCCESS) {
+      size_t n = 0;
+      hiprtcGetProgramLogSize(prog, &n);
+      std::string log(n, '\0');
+      if (n) hiprtcGetProgramLog(prog, &log[0]);
+      hiprtcDestroyProgram(&prog);
+      ctx->err = std::string("user-defined target: compilation failed (") + hiprtcGetErrorString(rc) + ")\n" + log;
+      return -3;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    hiprtcGetCode(prog, code.data());
+    aehmc_ctx::RtcProgram rp;
+    if (hipModuleLoadData(&rp.mod, code.data()) != hipSuccess) {
+      hiprtcDestroyProgram(&prog);
+      FAIL("user-defined target: hipModuleLoadData failed");
+    }
+    for (const auto &n : names) {
+      const char *low = nullptr;
+      hipFunction_t f = nullptr;
+      if (hiprtcGetLoweredName(prog, n.c_str(), &low) != HIPRTC_SUCCESS ||
+          hipModuleGetFunction(&f, rp.mod, low) != hipSuccess) {
+        hiprtcDestroyProgram(&prog);
+        FAIL("user-defined target: kernel " + n + " not found in the compiled code object");
+      }
+      rp.fn[n] = f;
+    }
+    const char *jlow = nullptr;  // this code object's copy of the jump-ahead table
+    hipDeviceptr_t jptr = nullptr;
+    size_t jbytes = 0;
+    if (hiprtcGetLoweredName(prog, "&aehmc::c_pcg_jump", &jlow) == HIPRTC_SUCCESS &&
+        hipModuleGetGlobal(&jptr, &jbytes, rp.mod, jlow) == hipSuccess && jbytes == sizeof(ctx->pcg_jump))
+      HIPCHK(hipMemcpy(jptr, ctx->pcg_jump, sizeof(ctx->pcg_jump), hipMemcpyHostToDevice));
+    hiprtcDestroyProgram(&prog);
+    it = ctx->rtc.emplace(key, rp).first;
+  }
+  auto f = it->second.fn.find(want);
+  if (f == it->second.fn.end()) FAIL("internal: kernel " + want + " was not compiled");
+  *out = f->second;
+  return 0;
+}
+// the lock-step engine's target-dependent kernels (+ new_state), compiled together
+static const std::vector<std::string> RTC_BASE = {
+    "aehmc::k_new_state_elem", "aehmc::k_step<true, true, true, false, true>", "aehmc::k_step<true, true, true, false, false>",
+    "aehmc::k_step<false, true, true, true, false>", "aehmc::k_step_linear<12, false>", "aehmc::k_step_linear<15, true>"};
+template <class... Args>
+static int rtc_launch(aehmc_ctx *ctx, const std::string &which, const std::vector<std::string> &names,
+                      const std::string &want, dim3 grid, dim3 block, size_t dyn, hipStream_t st, Args... args) {
+  hipFunction_t f = nullptr;
+  if (int rc = rtc_function(ctx, which, names, want, &f)) return rc;
+  void *params[] = {(void *)&args...};
+  HIPCHK(hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)dyn, st, params, nullptr));
+  return 0;
+}
+
+extern "C" int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
+                                       int32_t n_params, const char *include_dir) {
+  if (!ctx || !source || !include_dir) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (D <= 0) FAIL("target: D must be positive");
+  if (n_params < 0 || (n_params > 0 && !params)) FAIL("custom target: bad parameter list");
+  if (ctx->custom_src != source || ctx->custom_inc != include_dir) {  // another function: its own code objects
+    for (auto &kv : ctx->rtc)
+      if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+    ctx->rtc.clear();
+    ctx->custom_src = source;
+    ctx->custom_inc = include_dir;
+  }
+  if (ctx->d_cparams) {
+    HIPCHK(hipFree(ctx->d_cparams));
+    ctx->d_cparams = nullptr;
+  }
+  ctx->n_cparams = n_params;
+  HIPCHK(hipMalloc((void **)&ctx->d_cparams, (size_t)(n_params > 0 ? n_params : 1) * sizeof(double *)));
+  if (n_params > 0)
+    HIPCHK(hipMemcpy(ctx->d_cparams, params, (size_t)n_params * sizeof(double *), hipMemcpyHostToDevice));
+  hipFunction_t f = nullptr;  // compile now: errors in the user's source surface here, not in the first step
+  if (int rc = rtc_function(ctx, "base", RTC_BASE, RTC_BASE[0], &f)) return rc;
+  aehmc_target t{};
+  t.kind = AEHMC_T_CUSTOM;
+  t.D = D;
+  ctx->tgt = t;
+  ctx->has_tgt = true;
   return 0;
 }
 
@@ -587,6 +722,7 @@ static int fill_args(aehmc_ctx *ctx, int64_t C, int64_t E, EngineArgs &a, bool u
   a.sigma = ctx->tgt.sigma;
   a.log_sigma = ctx->log_sigma;
   a.X = ctx->tgt.X; a.y = ctx->tgt.y; a.N = ctx->tgt.N;
+  a.cparams = ctx->d_cparams;
   a.linear = (a.met_ndim == 2 && ctx->opt_dense_linear) ? 1 : 0;
   return 0;
 }
@@ -721,6 +857,17 @@ extern "C" int aehmc_gemm_nt(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, co
     HIPCHK(hipGetLastError());                                                        \
   } while (0)
 
+// kernels that evaluate a coordinate-wise target: the library's own instantiation, or -- user-defined target -- the
+// run-time compiled one of the same name
+#define LAUNCH_T(name, kern, C, st, a)                                                                  \
+  do {                                                                                                  \
+    if (ctx->tgt.kind == AEHMC_T_CUSTOM) {                                                              \
+      if (int rc_ = rtc_launch(ctx, "base", RTC_BASE, name, chain_grid(C), dim3(256), 0, st, a)) return rc_; \
+    } else {                                                                                            \
+      LAUNCH(kern, C, st, a);                                                                           \
+    }                                                                                                   \
+  } while (0)
+
 // one lock-step leapfrog of every live chain (integrators.py:54-73); `book` appends the
 // NUTS bookkeeping; `need_v` says whether v' = imm p' must be formed (dense metric);
 // `ri`/`nr`: compacted live-chain list for the GEMMs (may be null)
@@ -737,8 +884,8 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
   };
   const bool text = tdense || tlin;
   if (!md && !text) {
-    if (book) LAUNCH((k_step<true, true, true, false, true>), C, st, a);
-    else LAUNCH((k_step<true, true, true, false, false>), C, st, a);
+    if (book) LAUNCH_T("aehmc::k_step<true, true, true, false, true>", (k_step<true, true, true, false, true>), C, st, a);
+    else LAUNCH_T("aehmc::k_step<true, true, true, false, false>", (k_step<true, true, true, false, false>), C, st, a);
     return 0;
   }
   if (!md && text) {
@@ -751,12 +898,12 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
   if (a.linear) {  // dense metric, v carried by linearity: one metric GEMM (w' = imm g')
     // (NUTS lock-step loop: the first stages of every leapfrog but the first ride in the previous
     //  step's bookkeeping launch -- k_step_linear<15, true>)
-    if (!(book && ctx->pre_done)) LAUNCH((k_step_linear<12, false>), C, st, a);
+    if (!(book && ctx->pre_done)) LAUNCH_T("aehmc::k_step_linear<12, false>", (k_step_linear<12, false>), C, st, a);
     if (text)
       if (target_ext()) return -1;
     if (metric_mul(ctx, C, a.cur_g, ctx->met.imm, a.cur_w, st, ri, nr)) return -1;
     if (book && ctx->fuse_pre) {
-      LAUNCH((k_step_linear<15, true>), C, st, a);
+      LAUNCH_T("aehmc::k_step_linear<15, true>", (k_step_linear<15, true>), C, st, a);
       ctx->pre_done = true;
     } else if (book) LAUNCH((k_step_linear<3, true>), C, st, a);
     else LAUNCH((k_step_linear<3, false>), C, st, a);
@@ -766,7 +913,7 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
   LAUNCH((k_step<true, false, false, true, false>), C, st, a);
   if (metric_mul(ctx, C, a.cur_p, ctx->met.imm, a.vhalf, st, ri, nr)) return -1;
   if (!text) {
-    LAUNCH((k_step<false, true, true, true, false>), C, st, a);
+    LAUNCH_T("aehmc::k_step<false, true, true, true, false>", (k_step<false, true, true, true, false>), C, st, a);
   } else {
     LAUNCH((k_step<false, true, false, true, false>), C, st, a);
     if (target_ext()) return -1;
@@ -804,13 +951,13 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   EngineArgs a;
-  if (ctx->has_tgt && target_is_elem_host(ctx->tgt.kind)) {
-    if (!ctx->has_tgt) FAIL("set_target must be called first");
+  if (ctx->has_tgt && (target_is_elem_host(ctx->tgt.kind) || ctx->tgt.kind == AEHMC_T_CUSTOM)) {
     memset(&a, 0, sizeof(a));
     a.C = C; a.D = ctx->tgt.D; a.tkind = ctx->tgt.kind;
     a.mu = ctx->tgt.mu; a.sigma = ctx->tgt.sigma; a.log_sigma = ctx->log_sigma;
+    a.cparams = ctx->d_cparams;
     a.q = const_cast<double *>(q); a.U = U; a.g = g;
-    LAUNCH(k_new_state_elem, C, st, a);
+    LAUNCH_T("aehmc::k_new_state_elem", k_new_state_elem, C, st, a);
     return 0;
   }
   if (int rc = fill_args(ctx, C, 1, a, false)) return rc;
@@ -864,6 +1011,7 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   const bool want_resident = ctx->opt_resident_nuts != 0;
   (void)C;
   if (want_resident && nuts_resident_supported(tkind, nd, D)) return NUTS_PATH_TEAMS;  // D <= 512
+  if (want_resident && tkind == AEHMC_T_CUSTOM && nd < 2 && D <= 512) return NUTS_PATH_TEAMS;  // (run-time compiled)
   if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
@@ -923,7 +1071,14 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
         m = *multi;
         *multi_done = true;
       }
-      HIPCHK(launch_nuts_resident(a, m, st, ctx->opt_resident_min_team));
+      if (a.tkind == AEHMC_T_CUSTOM) {  // the same instantiation, compiled against the user's function
+        const ResidentPlan pl = plan_nuts_resident(a, m, ctx->opt_resident_min_team);
+        const std::string name = "aehmc::k_nuts_resident<" + std::to_string(pl.T) + ", " + std::to_string(pl.R) + ", " +
+                                 (pl.multi ? "true" : "false") + ", 0, " + (pl.ckl ? "true" : "false") + ">";
+        if (int rc = rtc_launch(ctx, "nuts", {name}, name, dim3(pl.grid), dim3(256), pl.dyn, st, a, m)) return rc;
+      } else {
+        HIPCHK(launch_nuts_resident(a, m, st, ctx->opt_resident_min_team));
+      }
     }
     return prof_end(ctx, st, p);
   }
@@ -1157,6 +1312,27 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
     HIPCHK(launch_hmc_fused(f, st));
+    return prof_end(ctx, st, p);
+  }
+  // user-defined coordinate-wise target: the same fused kernel, compiled against the user's function at run time
+  if (ctx->opt_fused_hmc && ctx->tgt.kind == AEHMC_T_CUSTOM && ctx->met.ndim < 2 && D <= 1024) {
+    if (int rc = check_per_chain(ctx, C)) return rc;
+    HmcFusedArgs f{};
+    f.C = C; f.D = D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
+    f.met_ndim = ctx->met.ndim; f.imm = ctx->met.imm; f.sqrt_mass = ctx->met.sqrt_mass;
+    f.imm_cs = ctx->met.per_chain ? (ctx->met.ndim == 0 ? 1 : D) : 0;
+    f.eps_c = ctx->eps_c;
+    f.tkind = AEHMC_T_CUSTOM; f.cparams = ctx->d_cparams;
+    f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
+    f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;
+    f.fc = ctx->opt_fp_contract;
+    const int R = hmc_fused_r(D);
+    const std::string name = "aehmc::k_hmc_fused<" + std::to_string(R) + ", 5, " + (f.fc ? "true" : "false") + ">";
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (int rc = rtc_launch(ctx, "hmc", {name}, name, dim3((unsigned)((C + 3) / 4)), dim3(256),
+                            (size_t)4 * R * 64 * sizeof(double), st, f))
+      return rc;
     return prof_end(ctx, st, p);
   }
   // regression target: the whole call in one launch, four chains per workgroup (hmc_linreg.cuh)

@@ -40,6 +40,7 @@ struct HmcFusedArgs {
   double *acc_hist;  // [T,C] or null
   int32_t *div_hist; // [T,C] or null
   int fc;            // "fp_contract" option: fast arithmetic in the leapfrog bodies (1e-6 instead of bit parity)
+  const double *const *cparams;  // user-defined target (AEHMC_T_CUSTOM, run-time compiled instantiations only)
 };
 
 inline bool target_is_elem_host(int k) {
@@ -56,6 +57,13 @@ inline bool hmc_fused_supported(int tkind, int met_ndim, long long D) {
 // of 8 + two divisions).  Mathematically the integrator of integrators.py:54-73; results within the north star's
 // 1e-6 (relative) of the default mode, which stays bit-identical to the oracle.  Everything outside the
 // trajectory loop (momentum draw, energies, accept) is the default mode's code.
+// TK == AEHMC_T_CUSTOM exists only in the run-time compiled copy (aehmc_set_custom_target): potential and gradient
+// of a coordinate come from the user's aehmc_custom_elem
+#ifdef AEHMC_CUSTOM_TARGET
+#define AEHMC_CUSTOM_ELEM(q, i, u, g) aehmc_custom_elem((q), (i), a.cparams, (u), (g))
+#else
+#define AEHMC_CUSTOM_ELEM(q, i, u, g) do { (u) = 0.0; (g) = 0.0; } while (0)
+#endif
 template <int R, int TK, bool FC = false>
 __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double zlds[];  // [4 waves][R*64]
@@ -89,6 +97,7 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
   double pa = 0.0;
   int is_div = 0, acc = 0;
   double aim[FC ? R : 1], iv[(FC && TK == AEHMC_T_DIAG_GAUSSIAN) ? R : 1];
+  (void)iv;
   if (FC) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -115,7 +124,8 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
     const double H0 = U + 0.5 * kd;  // hmc.py:187
 
     if (FC) {
-      constexpr bool DGT = TK == AEHMC_T_DIAG_GAUSSIAN;  // otherwise dU/dq == q
+      constexpr bool DGT = TK == AEHMC_T_DIAG_GAUSSIAN || TK == AEHMC_T_CUSTOM;  // otherwise dU/dq == q
+      constexpr bool CUS = TK == AEHMC_T_CUSTOM;
       if (a.L > 0) {
         // half kick | (drift, full kick) x (L - 1) | drift, half kick: no per-iteration select, four leapfrogs per
         // trip of the loop (the body is four instructions per element: loop overhead would otherwise match it)
@@ -127,20 +137,37 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
 #pragma unroll
           for (int r = 0; r < R; r++) {
             q[r] = __builtin_fma(aim[FC ? r : 0], p[r], q[r]);
-            if (DGT) g[r] = (q[r] - mu[r]) * iv[(FC && DGT) ? r : 0];
+            if (CUS) {
+              double u_;
+              AEHMC_CUSTOM_ELEM(q[r], (long long)(lane + 64 * r < a.D ? lane + 64 * r : 0), u_, g[r]);
+            } else if (DGT) g[r] = (q[r] - mu[r]) * iv[(FC && TK == AEHMC_T_DIAG_GAUSSIAN) ? r : 0];
             p[r] = __builtin_fma(neg_eps, DGT ? g[r] : q[r], p[r]);
           }
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
           q[r] = __builtin_fma(aim[FC ? r : 0], p[r], q[r]);
-          if (DGT) g[r] = (q[r] - mu[r]) * iv[(FC && DGT) ? r : 0];
+          if (CUS) {
+            double u_;
+            AEHMC_CUSTOM_ELEM(q[r], (long long)(lane + 64 * r < a.D ? lane + 64 * r : 0), u_, g[r]);
+          } else if (DGT) g[r] = (q[r] - mu[r]) * iv[(FC && TK == AEHMC_T_DIAG_GAUSSIAN) ? r : 0];
           p[r] = __builtin_fma(-b, DGT ? g[r] : q[r], p[r]);
         }
       }
       if (!DGT) {
 #pragma unroll
         for (int r = 0; r < R; r++) g[r] = q[r];
+      }
+    } else if (TK == AEHMC_T_CUSTOM) {
+      for (long long l = 0; l < a.L; l++) {  // leap_stages<1,1,1> with the user's gradient
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          p[r] = p[r] - b * g[r];
+          q[r] = q[r] + aa * (im[r] * p[r]);
+          double u_;
+          AEHMC_CUSTOM_ELEM(q[r], (long long)(lane + 64 * r < a.D ? lane + 64 * r : 0), u_, g[r]);
+          p[r] = p[r] - b * g[r];
+        }
       }
     } else if (TK == AEHMC_T_DIAG_GAUSSIAN) {
       for (long long l = 0; l < a.L; l++) {  // trajectory.py:86-95, integrators.py:54-73
@@ -179,7 +206,11 @@ __global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
         const long long i = lane + 64 * r;
         if (TK == AEHMC_T_STD_NORMAL) usum += 0.5 * (q[r] * q[r]) + AEHMC_LOG_SQRT_2PI;
         else if (TK == AEHMC_T_ISO_GAUSSIAN) usum += q[r] * q[r];
-        else {
+        else if (TK == AEHMC_T_CUSTOM) {
+          double u_, g_;
+          AEHMC_CUSTOM_ELEM(q[r], i, u_, g_);
+          usum += u_;
+        } else {
           double z = (q[r] - mu[r]) / sg[r];
           usum += 0.5 * (z * z) + a.log_sigma[i] + AEHMC_LOG_SQRT_2PI;
         }
@@ -490,6 +521,7 @@ inline bool hmc_resident_supported(int tkind, int met_ndim, long long D) {
   //  decision: 16 D bytes next to the reduction scratch in the CU's 160 KB)
   return target_is_elem_host(tkind) && met_ndim < 2 && D > 1024 && D <= (tkind == AEHMC_T_DIAG_GAUSSIAN ? 10176 : 10240);
 }
+#ifndef __HIPCC_RTC__
 template <int T, int R>
 inline hipError_t launch_hmc_wide_r(const HmcFusedArgs &a, const double *zbuf, int nt, hipStream_t st) {
   const bool dg = a.tkind == AEHMC_T_DIAG_GAUSSIAN;
@@ -556,6 +588,12 @@ inline hipError_t launch_hmc_fused_fc(const HmcFusedArgs &a, hipStream_t st) {
 }
 inline hipError_t launch_hmc_fused(const HmcFusedArgs &a, hipStream_t st) {
   return a.fc ? launch_hmc_fused_fc<true>(a, st) : launch_hmc_fused_fc<false>(a, st);
+}
+#endif  // __HIPCC_RTC__
+// elements per lane of the k_hmc_fused instantiation that holds a D-dimensional chain
+inline int hmc_fused_r(long long D) {
+  const long long r = (D + 63) / 64;
+  return r <= 1 ? 1 : r <= 2 ? 2 : r <= 4 ? 4 : r <= 8 ? 8 : 16;
 }
 
 }  // namespace aehmc

@@ -3,7 +3,9 @@
 // r = y - x w_k, over all N data rows for the FOUR chains k it owns; every thread accumulates its
 // share of the rows, the callers finish with wave sums and a fixed-order pass over the waves.
 #pragma once
+#ifndef __HIPCC_RTC__  /* (hipRTC supplies the runtime, the math functions and the fixed-width integers itself) */
 #include <hip/hip_runtime.h>
+#endif
 
 namespace aehmc {
 

@@ -658,6 +658,7 @@ inline bool nuts_resident_dense_supported(int tkind, int met_ndim, long long D) 
   const bool elem = tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN;
   return D <= FUSED_DENSE_MAX_D && (met_ndim == 2 || tkind == AEHMC_T_DENSE_MVN) && (elem || tkind == AEHMC_T_DENSE_MVN);
 }
+#ifndef __HIPCC_RTC__
 template <int DENSE>
 inline hipError_t launch_nuts_resident_dense_v(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
   constexpr int nmat = ((DENSE & RES_DENSE_METRIC) && !(DENSE & RES_DENSE_PER_CHAIN) ? 2 : 0) +
@@ -690,52 +691,72 @@ inline hipError_t launch_nuts_resident_dense(const EngineArgs &a, const NutsSamp
   if (td) return launch_nuts_resident_dense_v<2>(a, m, st);
   return hipErrorInvalidValue;
 }
+#endif  // __HIPCC_RTC__
 
-template <int T, int R>
-inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
-  const unsigned grid = Team<T>::SUB ? (unsigned)((a.C * T + 255) / 256) : (unsigned)((a.C + 3) / 4);
-  const bool multi = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total || m.adapt;
-  if constexpr (T == 64 && R == 1) {
-    // a few chains (at most two wavefronts per SIMD): checkpoints in LDS, 4 waves x max_exp levels x 1 KB <= 64 KB
-    if (a.C <= 2048 && a.max_exp <= 16) {
-      const size_t dyn = (size_t)4 * a.max_exp * 2 * 64 * sizeof(double);
-      if (multi) hipLaunchKernelGGL((k_nuts_resident<T, R, true, 0, true>), dim3(grid), dim3(Team<T>::BLOCK), dyn, st, a, m);
-      else hipLaunchKernelGGL((k_nuts_resident<T, R, false, 0, true>), dim3(grid), dim3(Team<T>::BLOCK), dyn, st, a, m);
-      return hipGetLastError();
-    }
-  }
-  if (multi) hipLaunchKernelGGL((k_nuts_resident<T, R, true>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a, m);
-  else hipLaunchKernelGGL((k_nuts_resident<T, R, false>), dim3(grid), dim3(Team<T>::BLOCK), 0, st, a, m);
-  return hipGetLastError();
-}
-// Team size: the smallest team that holds the chain (<= 4 elements per lane below a wave,
-// <= 8-10 above), widened -- fewer chains per wavefront -- while that still leaves about
-// 4096 wavefronts in flight, because a wider team wastes lanes but keeps the per-chain RNG /
-// control state wave-uniform (SGPRs, scalar branches).
-inline hipError_t launch_nuts_resident(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st,
-                                       int force_min_team = 0) {
+// Which instantiation a call takes.  Team size: the smallest team that holds the chain (<= 4 elements per lane below a
+// wave, <= 8-10 above), widened -- fewer chains per wavefront -- while that still leaves about 4096 wavefronts in
+// flight, because a wider team wastes lanes but keeps the per-chain RNG / control state wave-uniform (SGPRs, scalar
+// branches).  CKL: a few chains (at most two wavefronts per SIMD) keep their checkpoints in LDS, 4 waves x max_exp
+// levels x 1 KB <= 64 KB.
+struct ResidentPlan {
+  int T, R;
+  bool multi, ckl;
+  unsigned grid;
+  size_t dyn;
+};
+inline ResidentPlan plan_nuts_resident(const EngineArgs &a, const NutsSampleArgs &m, int force_min_team = 0) {
   const long long D = a.D, C = a.C;
-  if (D > 512) return hipErrorInvalidValue;  // one workgroup per chain: nuts_wide.cuh
   const int tmin = D <= 4 ? 1 : D <= 8 ? 2 : D <= 16 ? 4 : D <= 32 ? 8 : D <= 64 ? 16 : D <= 128 ? 32 : 64;
   int twant = 64;
   while (twant > 1 && C * (twant / 2) >= 64LL * 4096) twant /= 2;
-  const int T = force_min_team ? tmin : (tmin > twant ? tmin : twant);
-  switch (T) {
+  ResidentPlan p{};
+  p.T = force_min_team ? tmin : (tmin > twant ? tmin : twant);
+  if (p.T == 1) p.R = D <= 1 ? 1 : D <= 2 ? 2 : 4;
+  else if (p.T < 64) p.R = 4;
+  else p.R = D <= 64 ? 1 : D <= 128 ? 2 : D <= 256 ? 4 : 8;
+  p.multi = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total || m.adapt;
+  p.ckl = p.T == 64 && p.R == 1 && a.C <= 2048 && a.max_exp <= 16;
+  p.grid = p.T < 64 ? (unsigned)((a.C * p.T + 255) / 256) : (unsigned)((a.C + 3) / 4);
+  p.dyn = p.ckl ? (size_t)4 * a.max_exp * 2 * 64 * sizeof(double) : 0;
+  return p;
+}
+
+#ifndef __HIPCC_RTC__
+template <int T, int R>
+inline hipError_t launch_nuts_resident_tr(const EngineArgs &a, const NutsSampleArgs &m, const ResidentPlan &p,
+                                          hipStream_t st) {
+  if constexpr (T == 64 && R == 1) {
+    if (p.ckl) {
+      if (p.multi) hipLaunchKernelGGL((k_nuts_resident<T, R, true, 0, true>), dim3(p.grid), dim3(Team<T>::BLOCK), p.dyn, st, a, m);
+      else hipLaunchKernelGGL((k_nuts_resident<T, R, false, 0, true>), dim3(p.grid), dim3(Team<T>::BLOCK), p.dyn, st, a, m);
+      return hipGetLastError();
+    }
+  }
+  if (p.multi) hipLaunchKernelGGL((k_nuts_resident<T, R, true>), dim3(p.grid), dim3(Team<T>::BLOCK), 0, st, a, m);
+  else hipLaunchKernelGGL((k_nuts_resident<T, R, false>), dim3(p.grid), dim3(Team<T>::BLOCK), 0, st, a, m);
+  return hipGetLastError();
+}
+inline hipError_t launch_nuts_resident(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st,
+                                       int force_min_team = 0) {
+  if (a.D > 512) return hipErrorInvalidValue;  // one workgroup per chain: nuts_wide.cuh
+  const ResidentPlan p = plan_nuts_resident(a, m, force_min_team);
+  switch (p.T) {
     case 1:
-      if (D <= 1) return launch_nuts_resident_tr<1, 1>(a, m, st);
-      if (D <= 2) return launch_nuts_resident_tr<1, 2>(a, m, st);
-      return launch_nuts_resident_tr<1, 4>(a, m, st);
-    case 2: return launch_nuts_resident_tr<2, 4>(a, m, st);
-    case 4: return launch_nuts_resident_tr<4, 4>(a, m, st);
-    case 8: return launch_nuts_resident_tr<8, 4>(a, m, st);
-    case 16: return launch_nuts_resident_tr<16, 4>(a, m, st);
-    case 32: return launch_nuts_resident_tr<32, 4>(a, m, st);
+      if (p.R == 1) return launch_nuts_resident_tr<1, 1>(a, m, p, st);
+      if (p.R == 2) return launch_nuts_resident_tr<1, 2>(a, m, p, st);
+      return launch_nuts_resident_tr<1, 4>(a, m, p, st);
+    case 2: return launch_nuts_resident_tr<2, 4>(a, m, p, st);
+    case 4: return launch_nuts_resident_tr<4, 4>(a, m, p, st);
+    case 8: return launch_nuts_resident_tr<8, 4>(a, m, p, st);
+    case 16: return launch_nuts_resident_tr<16, 4>(a, m, p, st);
+    case 32: return launch_nuts_resident_tr<32, 4>(a, m, p, st);
     default:
-      if (D <= 64) return launch_nuts_resident_tr<64, 1>(a, m, st);
-      if (D <= 128) return launch_nuts_resident_tr<64, 2>(a, m, st);
-      if (D <= 256) return launch_nuts_resident_tr<64, 4>(a, m, st);
-      return launch_nuts_resident_tr<64, 8>(a, m, st);
+      if (p.R == 1) return launch_nuts_resident_tr<64, 1>(a, m, p, st);
+      if (p.R == 2) return launch_nuts_resident_tr<64, 2>(a, m, p, st);
+      if (p.R == 4) return launch_nuts_resident_tr<64, 4>(a, m, p, st);
+      return launch_nuts_resident_tr<64, 8>(a, m, p, st);
   }
 }
+#endif  // __HIPCC_RTC__
 
 }  // namespace aehmc

@@ -8,8 +8,10 @@
 // All functions here are wave-uniform unless they say "per lane": every lane of the
 // 64-wide wavefront that owns a chain carries the same generator state in registers.
 #pragma once
+#ifndef __HIPCC_RTC__  /* (hipRTC supplies the runtime, the math functions and the fixed-width integers itself) */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "../../include/aehmc_ziggurat_tables.h"
 

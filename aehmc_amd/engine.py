@@ -147,6 +147,20 @@ class Engine:
         p = {k: _dev_f64(v, self.device) for k, v in params.items()}
         if target.dim is not None and target.dim != D:
             raise ValueError(f"target has dimension {target.dim}, position has {D}")
+        if getattr(target, "source", None) is not None:  # user-defined coordinate-wise target: compiled with hipRTC
+            import os
+            key = key + (target.source,)
+            if self._target_key == key and not force:
+                return
+            arrs = [p[f"p{k}"] for k in range(len(p))]
+            ptrs = (ct.c_void_p * max(len(arrs), 1))(*[a.data_ptr() for a in arrs])
+            inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+            self._keep["target"] = (target, p)
+            self._check(self.lib.aehmc_set_custom_target(self.ctx, target.source.encode(), D, ptrs, len(arrs),
+                                                         inc.encode()), "aehmc_set_custom_target")
+            self._target_key, self.D = key, D
+            self._ws = None
+            return
         c = _lib.CTarget(kind=target.kind, D=D, N=0)
         for name in ("mu", "sigma", "prec", "X", "y"):
             if name in p:

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 # must match enum aehmc_target_kind in include/aehmc_hip.h
-T_STD_NORMAL, T_ISO_GAUSSIAN, T_DIAG_GAUSSIAN, T_DENSE_MVN, T_LINREG = range(5)
+T_STD_NORMAL, T_ISO_GAUSSIAN, T_DIAG_GAUSSIAN, T_DENSE_MVN, T_LINREG, T_CUSTOM = range(6)
 
 
 class Target:
@@ -73,3 +73,30 @@ class LinearRegression(Target):
 
     def params(self):
         return {"X": self.X, "y": self.y}
+
+
+class Custom(Target):
+    """A user-defined coordinate-wise ``logprob_fn`` (reference: aehmc/hmc.py:16-40 takes any callable and
+    differentiates it, integrators.py:61-65).  ``source`` is HIP source defining
+
+        __device__ void aehmc_custom_elem(double q, long long i, const double *const *prm, double &u, double &g)
+
+    -- ``u`` = coordinate i's contribution to the potential energy U = -logprob(q) = sum_i u_i, ``g`` = du_i/dq_i --
+    with ``prm[k]`` the k-th array of ``params`` (device float64 arrays, e.g. one value per coordinate).  The engine
+    compiles its kernel templates against it with hipRTC on first use (a few seconds; cached per source): the lock-step
+    engine for any metric and dimension, the register-resident NUTS kernel (D <= 512) and the fused HMC kernel
+    (D <= 1024) for diagonal / scalar metrics.  Example (independent Student-t coordinates, nu_i = prm[0][i]):
+
+        Custom('''__device__ void aehmc_custom_elem(double q, long long i, const double *const *prm, double &u, double &g) {
+                     const double nu = prm[0][i];
+                     u = 0.5 * (nu + 1.0) * log1p(q * q / nu);
+                     g = (nu + 1.0) * q / (nu + q * q);
+                   }''', params=[nu])"""
+
+    kind = T_CUSTOM
+
+    def __init__(self, source: str, params=(), dim=None):
+        self.source, self.param_list, self.dim = str(source), list(params), dim
+
+    def params(self):
+        return {f"p{k}": v for k, v in enumerate(self.param_list)}

@@ -30,8 +30,10 @@
 #ifndef AEHMC_HIP_H
 #define AEHMC_HIP_H
 
+#ifndef __HIPCC_RTC__  /* (hipRTC supplies the runtime, the math functions and the fixed-width integers itself) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -45,7 +47,8 @@ enum aehmc_target_kind {
   AEHMC_T_ISO_GAUSSIAN = 1, /* U = 0.5 |q|^2 (tests/test_trajectory.py:150-151) */
   AEHMC_T_DIAG_GAUSSIAN = 2,/* N(mu, diag sigma^2) */
   AEHMC_T_DENSE_MVN = 3,    /* U = 0.5 (q-mu)^T P (q-mu), P dense symmetric [D,D] */
-  AEHMC_T_LINREG = 4        /* examples/LinearRegression.ipynb:126-166, q = [w, log n] */
+  AEHMC_T_LINREG = 4,       /* examples/LinearRegression.ipynb:126-166, q = [w, log n] */
+  AEHMC_T_CUSTOM = 5        /* user-defined coordinate-wise target, compiled at run time: aehmc_set_custom_target */
 };
 
 typedef struct {
@@ -111,6 +114,20 @@ const char *aehmc_last_error(const aehmc_ctx *ctx);
 
 /* bind logprob_fn / inverse_mass_matrix (device buffers must outlive their use) */
 int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *target);
+
+/* A USER-DEFINED coordinate-wise logprob_fn (hmc.py:16-40 takes any callable; its gradient comes from autodiff,
+ * integrators.py:61-65): `source` is HIP source that defines the device function `aehmc_custom_elem`,
+ *     __device__ void aehmc_custom_elem
+ *         (double q, long long i, const double *const *prm, double &u, double &g)
+ * -- the contribution u of coordinate i to the potential energy U = -logprob(q) = sum_i u_i and du_i/dq_i = g --
+ * with prm[k] the k-th of `n_params` device arrays (`params`: HOST array of device pointers; [D] each, or whatever the
+ * function indexes).  The library compiles its kernel templates against it with hipRTC (libhiprtc, gfx950;
+ * `include_dir` = the directory that holds the library's csrc/ headers) on first use and caches the code objects by
+ * source: the lock-step engine (any metric, any D), the register-resident NUTS kernel (D <= 512, diagonal / scalar
+ * metric) and the fused HMC kernel (D <= 1024, diagonal / scalar metric).  Compilation errors come back through
+ * aehmc_last_error with the compiler's log. */
+int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
+                            int32_t n_params, const char *include_dir);
 int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
 
 /* engine options (name, default):

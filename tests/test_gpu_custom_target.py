@@ -1,0 +1,219 @@
+"""User-defined coordinate-wise targets (``targets.Custom``): the reference takes ANY logprob callable and
+differentiates it (/root/reference/aehmc/hmc.py:16-40, integrators.py:61-65); here the user supplies the potential's
+coordinate term and its derivative as HIP source and the engine compiles its kernel templates against it with hipRTC.
+Parity: the same expression as a numpy callable through the numpy restatement (oracle/np_oracle.py), chain by chain on
+identical seeds, 1e-9 with every discrete output identical; statistics as /root/reference/tests/test_hmc.py:267-346."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import np_oracle as no  # noqa: E402
+
+RTOL = 1e-9
+
+STUDENT_T = """
+__device__ void aehmc_custom_elem(double q, long long i, const double *const *prm, double &u, double &g) {
+  const double nu = prm[0][i], s = prm[1][i];   // Student-t, nu_i degrees of freedom, scale s_i
+  const double z = q / s;
+  u = 0.5 * (nu + 1.0) * log1p(z * z / nu);
+  g = (nu + 1.0) * z / (nu + z * z) / s;
+}
+"""
+
+
+class StudentT:
+    """the numpy side of STUDENT_T: U = sum 0.5 (nu + 1) log1p(z^2 / nu), z = q / s"""
+
+    def __init__(self, nu, s):
+        self.nu, self.s = np.asarray(nu, dtype=np.float64), np.asarray(s, dtype=np.float64)
+
+    def __call__(self, q):
+        q = np.asarray(q, dtype=np.float64)
+        z = q / self.s
+        u = 0.0
+        for t in 0.5 * (self.nu + 1.0) * np.log1p(z * z / self.nu):  # sequential sum, as the restatement's targets
+            u += t
+        return float(u), (self.nu + 1.0) * z / (self.nu + z * z) / self.s
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), device="cuda", dtype=torch.float64)
+
+
+@pytest.fixture()
+def eng():
+    from aehmc_amd.engine import get_engine
+    e = get_engine()
+    try:
+        yield e
+    finally:
+        for name, val in (("resident_nuts", 2), ("fused_hmc", 1), ("fp_contract", 0)):
+            e.set_option(name, val)
+
+
+def oracle_nuts(tgt, seeds, q0, eps, imm, max_exp, n):
+    out = []
+    for c, seed in enumerate(seeds):
+        kern = no.nuts_kernel(no.RandomStream(seed), tgt, max_num_expansions=max_exp)
+        state, infos = no.new_state(q0[c].copy(), tgt), []
+        for _ in range(n):
+            info = kern(state, eps, imm)
+            infos.append(info)
+            state = info.state._replace(momentum=None)
+        out.append(infos)
+    return out
+
+
+@pytest.mark.parametrize("D,metric,resident", [(10, "diag", 2), (10, "diag", 0), (70, "diag", 2), (300, "diag", 2),
+                                               (40, "dense", 2), (90, "dense", 2), (600, "diag", 2)])
+def test_custom_target_nuts_matches_numpy(eng, D, metric, resident):
+    """register-resident kernel (D <= 512, diagonal / scalar metric), lock-step engine (resident_nuts = 0, dense metrics
+    in both dense modes' default, D > 512): all compiled at run time against the user's function"""
+    from aehmc_amd import RandomStream, nuts, targets
+    eng.set_option("resident_nuts", resident)
+    r = np.random.default_rng(D + len(metric))
+    nu, s = 3.0 + 5 * r.random(D), 0.5 + r.random(D)
+    C, n, max_exp, eps = 4, 3, 5, 0.35
+    q0 = r.normal(size=(C, D))
+    if metric == "scalar":
+        imm = np.float64(0.8)
+    elif metric == "diag":
+        imm = 0.5 + r.random(D)
+    else:
+        A = r.normal(size=(D, D))
+        imm = A @ A.T / D + np.eye(D)
+        imm = 0.5 * (imm + imm.T)
+    seeds = [40 + c for c in range(C)]
+    tgt = targets.Custom(STUDENT_T, params=[nu, s])
+    kern = nuts.new_kernel(RandomStream(seeds=seeds), tgt, max_num_expansions=max_exp)
+    state = nuts.new_state(dev(q0), tgt)
+    ref = oracle_nuts(StudentT(nu, s), seeds, q0, eps, imm, max_exp, n)
+    np.testing.assert_allclose(state.potential_energy.cpu().numpy(), [StudentT(nu, s)(q0[c])[0] for c in range(C)], rtol=1e-12)
+    for t in range(n):
+        info, _ = kern(state, eps, dev(imm) if metric == "dense" else imm)
+        state = info.state._replace(momentum=None)
+        for c in range(C):
+            o = ref[c][t]
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL)
+            np.testing.assert_allclose(info.state.potential_energy_grad[c].cpu().numpy(), o.state.potential_energy_grad,
+                                       rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(info.acceptance_probability[c].item(), o.acceptance_probability, rtol=1e-8)
+            assert info.n_leapfrog[c].item() == o.n_leapfrog and info.num_doublings[c].item() == o.num_doublings
+            assert bool(info.is_turning[c]) == bool(o.is_turning) and bool(info.is_diverging[c]) == bool(o.is_diverging)
+
+
+@pytest.mark.parametrize("D,fused", [(10, 1), (10, 0), (200, 1), (1500, 1)])
+def test_custom_target_hmc_matches_numpy(eng, D, fused):
+    """fused register-resident HMC (D <= 1024) and the lock-step engine"""
+    from aehmc_amd import RandomStream, hmc, targets
+    eng.set_option("fused_hmc", fused)
+    r = np.random.default_rng(D)
+    nu, s = 3.0 + 5 * r.random(D), 0.5 + r.random(D)
+    C, n, L, eps = 3, 3, 7, 0.2
+    q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
+    seeds = [90 + c for c in range(C)]
+    tgt, otgt = targets.Custom(STUDENT_T, params=[nu, s]), StudentT(nu, s)
+    kern = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
+    state = hmc.new_state(dev(q0), tgt)
+    okern = [no.hmc_kernel(no.RandomStream(sd), otgt) for sd in seeds]
+    ostate = [no.new_state(q0[c].copy(), otgt) for c in range(C)]
+    for _ in range(n):
+        info, _ = kern(state, eps, imm, L)
+        state = info.state._replace(momentum=None)
+        for c in range(C):
+            o = okern[c](ostate[c], eps, imm, L)
+            ostate[c] = o.state._replace(momentum=None)
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL)
+            np.testing.assert_allclose(info.acceptance_probability[c].item(), o.acceptance_probability, rtol=1e-8)
+            assert bool(info.is_diverging[c]) == bool(o.is_diverging)
+
+
+def test_custom_target_fused_paths_equal_lockstep_bitwise(eng):
+    """sample(T) on the run-time compiled fused kernels == the lock-step engine with the same user function, bit for bit
+    (D = 100: one wavefront per chain in both)."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    r = np.random.default_rng(2)
+    D, C = 100, 6
+    nu, s = 4.0 + r.random(D), 0.7 + r.random(D)
+    q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
+    tgt = targets.Custom(STUDENT_T, params=[dev(nu), dev(s)])
+
+    def run(mod, fast, *extra):
+        eng.set_option("resident_nuts", 2 if fast else 0)
+        eng.set_option("fused_hmc", 1 if fast else 0)
+        eng.set_option("resident_min_team", 0)
+        kern = mod.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        out = kern.sample(mod.new_state(dev(q0), tgt), 0.3, imm, *extra, 4)
+        return out[0], out[2]
+
+    for mod, extra in ((hmc, (9,)), (nuts, ())):
+        s1, a1 = run(mod, True, *extra)
+        s0, a0 = run(mod, False, *extra)
+        if mod is hmc:
+            assert torch.equal(s1, s0) and torch.equal(a1, a0)
+        else:  # C = 6 chains of D = 100: a 64-lane team per chain, the lock-step path's summation order
+            assert torch.equal(s1, s0) and torch.equal(a1, a0)
+
+
+def test_custom_target_statistics_and_warmup(eng):
+    """window adaptation + sampling of a user-defined target (the loop of tests/test_hmc.py:190-346): Student-t(5)
+    coordinates with scales 1 and 3 -- mean 0, variance s^2 nu / (nu - 2).  HMC's moments are held to Monte-Carlo
+    error; NUTS reproduces the reference's upward variance bias (its 2**j + 1 leapfrogs per sub-trajectory:
+    tests/test_nuts_quirks.py), so its variance is only bracketed."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets, window_adaptation
+    C, D = 2048, 2
+    nu, s = np.array([5.0, 5.0]), np.array([1.0, 3.0])
+    var_true = s ** 2 * nu / (nu - 2)
+    tgt = targets.Custom(STUDENT_T, params=[nu, s])
+    q0 = dev(np.random.default_rng(0).normal(size=(C, D)))
+    for mod in (hmc, nuts):
+        kern = mod.new_kernel(RandomStream(seeds=list(range(7000, 7000 + C))), tgt)
+        state = mod.new_state(q0, tgt)
+        extra = dict(num_integration_steps=7) if mod is hmc else {}
+        state, (eps, imm), _ = window_adaptation.run(kern, state, 300, **extra)
+        out = kern.sample(state, eps, imm, *((7,) if mod is hmc else ()), 400)
+        x, acc = out[0].cpu().numpy(), out[2]  # [400, C, 2]
+        mean, var = x.mean(axis=(0, 1)), x.var(axis=(0, 1))
+        # chains are independent: Monte-Carlo error from the spread of the per-chain statistics
+        se_mean = x.mean(axis=0).std(axis=0) / np.sqrt(C)
+        se_var = x.var(axis=0).std(axis=0) / np.sqrt(C)
+        assert np.all(np.abs(mean) < 5 * se_mean + 1e-3), (mod.__name__, mean, se_mean)
+        if mod is hmc:
+            assert np.all(np.abs(var - var_true) < 5 * se_var + 0.02 * var_true), (var, var_true, se_var)
+        else:
+            assert np.all(var > 0.98 * var_true) and np.all(var < 1.2 * var_true), (var, var_true)
+        assert 0.6 < float(acc.mean()) < 0.97
+
+
+def test_custom_target_compile_error_is_reported(eng):
+    from aehmc_amd import nuts, targets
+    from aehmc_amd.engine import EngineError
+    bad = targets.Custom("__device__ void aehmc_custom_elem(double q, long long i, const double *const *prm, double &u, "
+                         "double &g) { u = undefined_symbol(q); g = q; }")
+    with pytest.raises(EngineError, match="compilation failed"):
+        nuts.new_state(dev(np.zeros((2, 3))), bad)
+    # the engine is usable afterwards
+    ok = targets.Custom(STUDENT_T, params=[np.full(3, 4.0), np.ones(3)])
+    st = nuts.new_state(dev(np.ones((2, 3))), ok)
+    np.testing.assert_allclose(st.potential_energy.cpu().numpy(), [StudentT(np.full(3, 4.0), np.ones(3))(np.ones(3))[0]] * 2, rtol=1e-12)
+
+
+def test_custom_target_fp_contract_hmc(eng):
+    """the fast-arithmetic mode of the fused HMC kernel with a user-defined target: within 1e-6 of the default mode"""
+    from aehmc_amd import RandomStream, hmc, targets
+    r = np.random.default_rng(3)
+    D, C = 64, 5
+    nu, s = 4.0 + r.random(D), 0.7 + r.random(D)
+    q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
+    tgt = targets.Custom(STUDENT_T, params=[nu, s])
+    outs = []
+    for fc in (0, 1):
+        eng.set_option("fp_contract", fc)
+        kern = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        outs.append(kern.sample(hmc.new_state(dev(q0), tgt), 0.1, imm, 20, 3)[0])
+    assert not torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[1].cpu().numpy(), outs[0].cpu().numpy(), rtol=1e-6, atol=1e-9)
