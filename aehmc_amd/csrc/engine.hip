@@ -88,6 +88,11 @@ struct aehmc_ctx {
   std::string custom_src, custom_inc;
   const double **d_cparams = nullptr;
   int n_cparams = 0;
+  // user-defined row-reduction target: data matrix X [N,D], its transpose (owned), responses, [C,N] / [C] work arrays (owned)
+  const double *glm_X = nullptr, *glm_y = nullptr;
+  double *glm_XT = nullptr, *glm_z = nullptr, *glm_lsum = nullptr;
+  int64_t glm_N = 0;
+  size_t glm_z_bytes = 0, glm_lsum_bytes = 0;
   uint64_t pcg_jump[64][4] = {};  // the LCG jump-ahead table (every code object has its own __constant__ copy)
   struct RtcProgram {
     hipModule_t mod = nullptr;
@@ -191,6 +196,9 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (ctx->fd_ws) (void)hipFree(ctx->fd_ws);
   if (ctx->blk_pack) (void)hipFree(ctx->blk_pack);
   if (ctx->d_cparams) (void)hipFree(ctx->d_cparams);
+  if (ctx->glm_XT) (void)hipFree(ctx->glm_XT);
+  if (ctx->glm_z) (void)hipFree(ctx->glm_z);
+  if (ctx->glm_lsum) (void)hipFree(ctx->glm_lsum);
   for (auto &kv : ctx->rtc)
     if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
   for (int i = 0; i < NRING; i++)
@@ -248,19 +256,20 @@ extern "C" int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *t) {
 static const char *RTC_PROLOGUE =
     "typedef signed int int32_t; typedef unsigned int uint32_t; typedef long long int64_t;\n"
     "typedef unsigned long long uint64_t; typedef unsigned long long uintptr_t; typedef unsigned long size_t;\n"
-    "#define INFINITY __builtin_huge_val()\n"
-    "#define AEHMC_CUSTOM_TARGET 1\n";
+    "#define INFINITY __builtin_huge_val()\n";
 static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vector<std::string> &names,
                         const std::string &want, hipFunction_t *out) {
-  const std::string key = which + "|" + (which == "base" ? std::string() : want);
+  const std::string key = which + "|" + ((which == "base" || which == "glm") ? std::string() : want);
   auto it = ctx->rtc.find(key);
   if (it == ctx->rtc.end()) {
     if (ctx->custom_src.empty()) FAIL("internal: no user-defined target source");
     std::string src = RTC_PROLOGUE;
+    if (which != "glm") src += "#define AEHMC_CUSTOM_TARGET 1\n";  // (engine.cuh: target_elem calls aehmc_custom_elem)
     src += "#line 1 \"custom_target\"\n" + ctx->custom_src + "\n";
     src += "#include \"engine.cuh\"\n";
     if (which == "nuts") src += "#include \"nuts_resident.cuh\"\n";
     if (which == "hmc") src += "#include \"hmc_fused.cuh\"\n";
+    if (which == "glm") src += "#include \"glm_rows.cuh\"\n";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "aehmc_custom.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
       FAIL("hiprtcCreateProgram failed");
@@ -326,19 +335,13 @@ static int rtc_launch(aehmc_ctx *ctx, const std::string &which, const std::vecto
   return 0;
 }
 
-extern "C" int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
-                                       int32_t n_params, const char *include_dir) {
-  if (!ctx || !source || !include_dir) return -2;
-  HIPCHK(hipSetDevice(ctx->device));
-  if (D <= 0) FAIL("target: D must be positive");
+static const std::vector<std::string> RTC_GLM = {"aehmc::k_glm_rows", "aehmc::k_glm_finish"};
+__global__ void k_transpose_rect(const double *src, double *dst, long long rows, long long cols) {  // dst [cols, rows]
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < rows * cols) dst[(e % cols) * rows + e / cols] = src[e];
+}
+static int set_custom_params(aehmc_ctx *ctx, const double *const *params, int32_t n_params) {
   if (n_params < 0 || (n_params > 0 && !params)) FAIL("custom target: bad parameter list");
-  if (ctx->custom_src != source || ctx->custom_inc != include_dir) {  // another function: its own code objects
-    for (auto &kv : ctx->rtc)
-      if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
-    ctx->rtc.clear();
-    ctx->custom_src = source;
-    ctx->custom_inc = include_dir;
-  }
   if (ctx->d_cparams) {
     HIPCHK(hipFree(ctx->d_cparams));
     ctx->d_cparams = nullptr;
@@ -347,6 +350,51 @@ extern "C" int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64
   HIPCHK(hipMalloc((void **)&ctx->d_cparams, (size_t)(n_params > 0 ? n_params : 1) * sizeof(double *)));
   if (n_params > 0)
     HIPCHK(hipMemcpy(ctx->d_cparams, params, (size_t)n_params * sizeof(double *), hipMemcpyHostToDevice));
+  return 0;
+}
+static int set_custom_source(aehmc_ctx *ctx, const char *source, const char *include_dir) {
+  if (ctx->custom_src != source || ctx->custom_inc != include_dir) {  // another function: its own code objects
+    for (auto &kv : ctx->rtc)
+      if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+    ctx->rtc.clear();
+    ctx->custom_src = source;
+    ctx->custom_inc = include_dir;
+  }
+  return 0;
+}
+extern "C" int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, int64_t N, const double *X,
+                                           const double *y, const double *const *params, int32_t n_params,
+                                           const char *include_dir) {
+  if (!ctx || !source || !include_dir) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (D <= 0 || N <= 0 || !X || !y) FAIL("GLM target needs D, N, X [N,D] and y [N]");
+  if (int rc = set_custom_source(ctx, source, include_dir)) return rc;
+  if (int rc = set_custom_params(ctx, params, n_params)) return rc;
+  hipFunction_t f = nullptr;  // compile now: errors in the user's source surface here
+  if (int rc = rtc_function(ctx, "glm", RTC_GLM, RTC_GLM[0], &f)) return rc;
+  if (ctx->glm_XT) HIPCHK(hipFree(ctx->glm_XT));
+  ctx->glm_XT = nullptr;
+  HIPCHK(hipMalloc((void **)&ctx->glm_XT, (size_t)N * D * sizeof(double)));
+  hipLaunchKernelGGL(k_transpose_rect, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, 0, X, ctx->glm_XT,
+                     (long long)N, (long long)D);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  ctx->glm_X = X; ctx->glm_y = y; ctx->glm_N = N;
+  aehmc_target t{};
+  t.kind = AEHMC_T_GLM;
+  t.D = D;
+  ctx->tgt = t;
+  ctx->has_tgt = true;
+  return 0;
+}
+
+extern "C" int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
+                                       int32_t n_params, const char *include_dir) {
+  if (!ctx || !source || !include_dir) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (D <= 0) FAIL("target: D must be positive");
+  if (int rc = set_custom_source(ctx, source, include_dir)) return rc;
+  if (int rc = set_custom_params(ctx, params, n_params)) return rc;
   hipFunction_t f = nullptr;  // compile now: errors in the user's source surface here, not in the first step
   if (int rc = rtc_function(ctx, "base", RTC_BASE, RTC_BASE[0], &f)) return rc;
   aehmc_target t{};
@@ -850,6 +898,35 @@ extern "C" int aehmc_gemm_nt(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, co
   return gemm(ctx, M, N, K, A, lda, B, ldb, Cm, ldc, (hipStream_t)stream);
 }
 
+// user-defined row-reduction target at the positions q [C,D]: Z = Q X^T (GEMM) -> dloss/dz in place + the loss sums
+// (run-time compiled) -> G = dLoss X (GEMM) -> + the prior's terms, U (run-time compiled)
+static int launch_glm(aehmc_ctx *ctx, const EngineArgs &a, const double *q, double *g, double *U, int to_ctl,
+                      hipStream_t st, const int *ri, const int *nr) {
+  const int64_t C = a.C, D = a.D, N = ctx->glm_N;
+  const size_t zb = (size_t)C * N * sizeof(double), lb = (size_t)C * sizeof(double);
+  if (ctx->glm_z_bytes < zb) {
+    if (ctx->glm_z) HIPCHK(hipFree(ctx->glm_z));
+    ctx->glm_z = nullptr;
+    ctx->glm_z_bytes = 0;
+    HIPCHK(hipMalloc((void **)&ctx->glm_z, zb));
+    ctx->glm_z_bytes = zb;
+  }
+  if (ctx->glm_lsum_bytes < lb) {
+    if (ctx->glm_lsum) HIPCHK(hipFree(ctx->glm_lsum));
+    ctx->glm_lsum = nullptr;
+    ctx->glm_lsum_bytes = 0;
+    HIPCHK(hipMalloc((void **)&ctx->glm_lsum, lb));
+    ctx->glm_lsum_bytes = lb;
+  }
+  if (int rc = gemm(ctx, C, N, D, q, D, ctx->glm_X, D, ctx->glm_z, N, st, ri, nr)) return rc;
+  if (int rc = rtc_launch(ctx, "glm", RTC_GLM, "aehmc::k_glm_rows", chain_grid(C), dim3(256), 0, st, (long long)C,
+                          (long long)N, ctx->glm_y, (const double *const *)ctx->d_cparams, ctx->glm_z, ctx->glm_lsum, ri, nr))
+    return rc;
+  if (int rc = gemm(ctx, C, D, N, ctx->glm_z, N, ctx->glm_XT, N, g, D, st, ri, nr)) return rc;
+  return rtc_launch(ctx, "glm", RTC_GLM, "aehmc::k_glm_finish", chain_grid(C), dim3(256), 0, st, a, q, g, U,
+                    (const double *)ctx->glm_lsum, to_ctl);
+}
+
 // ------------------------------------------------------------------ leapfrog driver
 #define LAUNCH(kern, C, st, ...)                                                      \
   do {                                                                                \
@@ -876,13 +953,14 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
   const bool md = a.met_ndim == 2;
   const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
   const int64_t C = a.C, D = a.D;
-  const bool tlin = a.tkind == AEHMC_T_LINREG;
-  // targets evaluated between the stages: dense MVN (GEMM) or linear regression (row sums)
+  const bool tlin = a.tkind == AEHMC_T_LINREG, tglm = a.tkind == AEHMC_T_GLM;
+  // targets evaluated between the stages: dense MVN (GEMM), linear regression (row sums), user-defined row reduction
   auto target_ext = [&]() -> int {
     if (tdense) return gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr);
+    if (tglm) return launch_glm(ctx, a, a.cur_q, a.cur_g, nullptr, 1, st, ri, nr);
     return launch_linreg(ctx, a, a.cur_q, a.cur_g, nullptr, 1, st);
   };
-  const bool text = tdense || tlin;
+  const bool text = tdense || tlin || tglm;
   if (!md && !text) {
     if (book) LAUNCH_T("aehmc::k_step<true, true, true, false, true>", (k_step<true, true, true, false, true>), C, st, a);
     else LAUNCH_T("aehmc::k_step<true, true, true, false, false>", (k_step<true, true, true, false, false>), C, st, a);
@@ -970,6 +1048,7 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
   if (a.tkind == AEHMC_T_LINREG) {
     return launch_linreg(ctx, a, q, g, U, 0, st);
   }
+  if (a.tkind == AEHMC_T_GLM) return launch_glm(ctx, a, q, g, U, 0, st, nullptr, nullptr);
   FAIL("new_state: target kind not implemented");
 }
 
@@ -1127,7 +1206,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   if (int rc = launch_begin(ctx, a, true, st)) return rc;
   long long maxsteps = 0;
   for (int j = 0; j < max_num_expansions; j++) maxsteps += (1LL << j) + 1;  // 2**j + 1 per expansion
-  const bool compact = ctx->opt_compact && (a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN);
+  const bool compact = ctx->opt_compact && (a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN || a.tkind == AEHMC_T_GLM);
   const int *ri = compact ? a.row_idx : nullptr, *nr = compact ? a.n_rows : nullptr;
   if (compact) {
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, (const ChainCtl *)a.ctl, (long long)C,

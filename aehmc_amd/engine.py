@@ -152,12 +152,21 @@ class Engine:
             key = key + (target.source,)
             if self._target_key == key and not force:
                 return
-            arrs = [p[f"p{k}"] for k in range(len(p))]
+            arrs = [p[f"p{k}"] for k in range(len(target.param_list))]
             ptrs = (ct.c_void_p * max(len(arrs), 1))(*[a.data_ptr() for a in arrs])
             inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
             self._keep["target"] = (target, p)
-            self._check(self.lib.aehmc_set_custom_target(self.ctx, target.source.encode(), D, ptrs, len(arrs),
-                                                         inc.encode()), "aehmc_set_custom_target")
+            if "X" in p:  # row-reduction target over a data matrix
+                X, y = p["X"].contiguous(), p["y"].reshape(-1).contiguous()
+                if X.ndim != 2 or X.shape[1] != D or y.numel() != X.shape[0]:
+                    raise ValueError(f"GLM target: X must be [N, {D}] and y [N], got {tuple(X.shape)} and {tuple(y.shape)}")
+                self._keep["target"] = (target, p, X, y)
+                self._check(self.lib.aehmc_set_custom_glm_target(self.ctx, target.source.encode(), D, X.shape[0],
+                                                                 X.data_ptr(), y.data_ptr(), ptrs, len(arrs), inc.encode()),
+                            "aehmc_set_custom_glm_target")
+            else:
+                self._check(self.lib.aehmc_set_custom_target(self.ctx, target.source.encode(), D, ptrs, len(arrs),
+                                                             inc.encode()), "aehmc_set_custom_target")
             self._target_key, self.D = key, D
             self._ws = None
             return

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 # must match enum aehmc_target_kind in include/aehmc_hip.h
-T_STD_NORMAL, T_ISO_GAUSSIAN, T_DIAG_GAUSSIAN, T_DENSE_MVN, T_LINREG, T_CUSTOM = range(6)
+T_STD_NORMAL, T_ISO_GAUSSIAN, T_DIAG_GAUSSIAN, T_DENSE_MVN, T_LINREG, T_CUSTOM, T_GLM = range(7)
 
 
 class Target:
@@ -100,3 +100,36 @@ class Custom(Target):
 
     def params(self):
         return {f"p{k}": v for k, v in enumerate(self.param_list)}
+
+
+class CustomGLM(Target):
+    """A user-defined row-reduction ("GLM-type") ``logprob_fn`` over a data matrix ``X`` [N, D] and responses ``y`` [N]:
+    U(q) = sum_n loss(x_n . q, y_n) + sum_i prior(q_i).  ``source`` is HIP source defining
+
+        __device__ void aehmc_glm_row(double z, double y, long long n, const double *const *prm, double &loss, double &dloss_dz)
+        __device__ void aehmc_glm_prior(double q, long long i, const double *const *prm, double &u, double &g)
+
+    The two products with X per leapfrog run as chain-batched fp64 MFMA GEMMs, the user's functions in kernels compiled
+    with hipRTC on first use (lock-step engine, any metric).  Logistic regression with a N(0, tau^2) prior:
+
+        CustomGLM('''
+          __device__ void aehmc_glm_row(double z, double y, long long n, const double *const *prm, double &l, double &d) {
+            l = (z > 0 ? z + log1p(exp(-z)) : log1p(exp(z))) - y * z;
+            d = 1.0 / (1.0 + exp(-z)) - y;
+          }
+          __device__ void aehmc_glm_prior(double q, long long i, const double *const *prm, double &u, double &g) {
+            const double tau = prm[0][0];
+            u = 0.5 * q * q / (tau * tau);
+            g = q / (tau * tau);
+          }''', X, y, params=[[2.0]])"""
+
+    kind = T_GLM
+
+    def __init__(self, source: str, X, y, params=()):
+        self.source, self.X, self.y, self.param_list = str(source), X, y, list(params)
+        self.dim = int(X.shape[1])
+
+    def params(self):
+        d = {f"p{k}": v for k, v in enumerate(self.param_list)}
+        d.update(X=self.X, y=self.y)
+        return d

@@ -48,7 +48,8 @@ enum aehmc_target_kind {
   AEHMC_T_DIAG_GAUSSIAN = 2,/* N(mu, diag sigma^2) */
   AEHMC_T_DENSE_MVN = 3,    /* U = 0.5 (q-mu)^T P (q-mu), P dense symmetric [D,D] */
   AEHMC_T_LINREG = 4,       /* examples/LinearRegression.ipynb:126-166, q = [w, log n] */
-  AEHMC_T_CUSTOM = 5        /* user-defined coordinate-wise target, compiled at run time: aehmc_set_custom_target */
+  AEHMC_T_CUSTOM = 5,       /* user-defined coordinate-wise target, compiled at run time: aehmc_set_custom_target */
+  AEHMC_T_GLM = 6           /* user-defined row-reduction target over a data matrix: aehmc_set_custom_glm_target */
 };
 
 typedef struct {
@@ -128,6 +129,21 @@ int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *target);
  * aehmc_last_error with the compiler's log. */
 int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
                             int32_t n_params, const char *include_dir);
+
+/* A user-defined ROW-REDUCTION ("GLM-type") logprob_fn over a data matrix X [N,D] (row-major, device) and responses
+ * y [N] (device):  U(q) = sum_n loss(x_n . q, y_n) + sum_i prior(q_i),  dU/dq = X^T dloss/dz + prior'(q).  `source`
+ * defines the device functions `aehmc_glm_row` and `aehmc_glm_prior`,
+ *     __device__ void aehmc_glm_row
+ *         (double z, double y, long long n, const double *const *prm, double &loss, double &dloss_dz)
+ *     __device__ void aehmc_glm_prior
+ *         (double q, long long i, const double *const *prm, double &u, double &g)
+ * (logistic regression: loss = log1p(exp(z)) - y z, dloss = 1 / (1 + exp(-z)) - y).  Per leapfrog the two products
+ * with X run as chain-batched fp64 MFMA GEMMs (Z = Q X^T, then G = dLoss X), the user's functions in run-time
+ * compiled kernels between and behind them; lock-step engine (any metric).  The library keeps a transposed copy of X
+ * and a [C, N] work array. */
+int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, int64_t N, const double *X,
+                                const double *y, const double *const *params, int32_t n_params,
+                                const char *include_dir);
 int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
 
 /* engine options (name, default):

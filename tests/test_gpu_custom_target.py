@@ -217,3 +217,109 @@ def test_custom_target_fp_contract_hmc(eng):
         outs.append(kern.sample(hmc.new_state(dev(q0), tgt), 0.1, imm, 20, 3)[0])
     assert not torch.equal(outs[0], outs[1])
     np.testing.assert_allclose(outs[1].cpu().numpy(), outs[0].cpu().numpy(), rtol=1e-6, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# row-reduction ("GLM-type") user-defined targets: logistic regression
+LOGISTIC = """
+__device__ void aehmc_glm_row(double z, double y, long long n, const double *const *prm, double &l, double &d) {
+  l = (z > 0 ? z + log1p(exp(-z)) : log1p(exp(z))) - y * z;   // log(1 + e^z) - y z
+  d = 1.0 / (1.0 + exp(-z)) - y;
+}
+__device__ void aehmc_glm_prior(double q, long long i, const double *const *prm, double &u, double &g) {
+  const double tau = prm[0][0];                                  // N(0, tau^2) prior on every weight
+  u = 0.5 * q * q / (tau * tau);
+  g = q / (tau * tau);
+}
+"""
+
+
+class Logistic:
+    """the numpy side of LOGISTIC"""
+
+    def __init__(self, X, y, tau):
+        self.X, self.y, self.tau = np.asarray(X, dtype=np.float64), np.asarray(y, dtype=np.float64), float(tau)
+
+    def __call__(self, q):
+        q = np.asarray(q, dtype=np.float64)
+        z = self.X @ q
+        loss = np.where(z > 0, z + np.log1p(np.exp(-np.abs(z))), np.log1p(np.exp(-np.abs(z)))) - self.y * z
+        d = 1.0 / (1.0 + np.exp(-z)) - self.y
+        U = float(loss.sum() + (0.5 * q * q / self.tau ** 2).sum())
+        return U, self.X.T @ d + q / self.tau ** 2
+
+
+def logistic_data(N, D, seed):
+    r = np.random.default_rng(seed)
+    X = r.normal(size=(N, D))
+    w = r.normal(size=D)
+    y = (r.random(N) < 1.0 / (1.0 + np.exp(-X @ w))).astype(np.float64)
+    return X, y, w
+
+
+@pytest.mark.parametrize("N,D,metric", [(300, 6, "diag"), (1000, 3, "scalar1"), (257, 20, "dense"), (64, 70, "dense")])
+def test_custom_glm_target_matches_numpy(eng, N, D, metric):
+    """logistic regression through NUTS and HMC on the lock-step engine (the two products with X on the fp64 MFMA GEMM,
+    the user's loss / prior in run-time compiled kernels) against the numpy restatement, chain by chain"""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    X, y, _ = logistic_data(N, D, N + D)
+    r = np.random.default_rng(D)
+    tau, C = 2.0, 4
+    q0 = 0.3 * r.normal(size=(C, D))
+    if metric == "dense":
+        A = r.normal(size=(D, D))
+        imm = 0.05 * (A @ A.T / D + np.eye(D))
+        imm = 0.5 * (imm + imm.T)
+    elif metric == "diag":
+        imm = 0.02 + 0.05 * r.random(D)
+    else:
+        imm = np.full(D, 0.01)
+    immg = dev(imm) if metric == "dense" else imm
+    tgt, otgt = targets.CustomGLM(LOGISTIC, X, y, params=[[tau]]), Logistic(X, y, tau)
+    seeds = [11 + c for c in range(C)]
+    state = nuts.new_state(dev(q0), tgt)
+    for c in range(C):
+        U, g = otgt(q0[c])
+        np.testing.assert_allclose(state.potential_energy[c].item(), U, rtol=1e-12)
+        np.testing.assert_allclose(state.potential_energy_grad[c].cpu().numpy(), g, rtol=1e-10, atol=1e-11)
+    kern = nuts.new_kernel(RandomStream(seeds=seeds), tgt, max_num_expansions=5)
+    ref = oracle_nuts(otgt, seeds, q0, 0.5, imm, 5, 2)
+    for t in range(2):
+        info, _ = kern(state, 0.5, immg)
+        state = info.state._replace(momentum=None)
+        for c in range(C):
+            o = ref[c][t]
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-11)
+            np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL)
+            assert info.n_leapfrog[c].item() == o.n_leapfrog and info.num_doublings[c].item() == o.num_doublings
+            assert bool(info.is_turning[c]) == bool(o.is_turning) and bool(info.is_diverging[c]) == bool(o.is_diverging)
+    hk = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
+    hstate = hmc.new_state(dev(q0), tgt)
+    info, _ = hk(hstate, 0.3, immg, 6)
+    for c in range(C):
+        o = no.hmc_kernel(no.RandomStream(seeds[c]), otgt)(no.new_state(q0[c].copy(), otgt), 0.3, imm, 6)
+        np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-11)
+        np.testing.assert_allclose(info.acceptance_probability[c].item(), o.acceptance_probability, rtol=1e-8)
+
+
+def test_custom_glm_posterior(eng):
+    """Bayesian logistic regression sampled with NUTS after window adaptation (the use the reference's README and
+    notebook show for its own models): the posterior mean recovers the generating weights within its own spread, and
+    HMC with the adapted parameters gives the same posterior means within Monte-Carlo error."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets, window_adaptation
+    N, D, C = 2000, 5, 512
+    X, y, w = logistic_data(N, D, 5)
+    tgt = targets.CustomGLM(LOGISTIC, dev(X), dev(y), params=[[3.0]])
+    kern = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=6)
+    state = nuts.new_state(dev(np.zeros((C, D))), tgt)
+    state, (eps, imm), _ = window_adaptation.run(kern, state, 200)
+    samples, info, acc, div = kern.sample(state, eps, imm, 150)
+    x = samples.cpu().numpy()
+    mean, sd = x.mean(axis=(0, 1)), x.std(axis=(0, 1))
+    assert np.all(np.abs(mean - w) < 4 * sd), (mean, w, sd)   # N = 2000 rows: sd ~ 0.06
+    assert np.all(sd < 0.2) and not bool(div.any()) and 0.6 < float(acc.mean()) < 0.97
+    hk = hmc.new_kernel(RandomStream(seeds=list(range(C, 2 * C))), tgt)
+    hs, _, hacc, _ = hk.sample(state, eps, imm, 8, 150)
+    hmean = hs.cpu().numpy().mean(axis=(0, 1))
+    se = x.mean(axis=0).std(axis=0) / np.sqrt(C)
+    assert np.all(np.abs(hmean - mean) < 6 * se + 2e-3), (hmean, mean, se)
