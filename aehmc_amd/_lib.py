@@ -46,6 +46,7 @@ SYMBOLS = {
     "aehmc_set_custom_glm_target": (_I, [_P, ct.c_char_p, _I64, _I64, _P, _P, ct.POINTER(_P), ct.c_int32, ct.c_char_p]),
     "aehmc_set_metric": (_I, [_P, ct.POINTER(CMetric)]),
     "aehmc_set_step_sizes": (_I, [_P, _P, _I64]),
+    "aehmc_metric_sqrt": (_I, [_P, ct.c_int32, _I64, _P, _P, _P]),
     "aehmc_metric_sqrt_per_chain": (_I, [_P, _I64, _I64, _P, _P, _P]),
     "aehmc_adapt_init": (_I, [_P, _I64, _I64, _D, ct.POINTER(CAdaptState), _P]),
     "aehmc_adapt_update": (_I, [_P, _I64, _I64, ct.c_int32, ct.c_int32, ct.c_int32, _D, _P, _P,

@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long 
 // metric products are per-chain mat-vecs instead of one GEMM over all chains.  Up to
 // AEHMC_PC_LDS_MAX_D the factorisation of a chain's matrix runs in LDS, above it in global memory.
 constexpr int AEHMC_PC_LDS_MAX_D = 64;
-constexpr int AEHMC_PC_DENSE_MAX_D = 512;  // (tested and timed up to here: tests/test_gpu_adaptation.py)
+constexpr int AEHMC_PC_DENSE_MAX_D = 2048;  // (one wavefront factors a chain's matrix; tested up to D = 1024: tests/test_gpu_adaptation.py)
 // out[c, i] = sum_j mats[c, i, j] x[c, j]  (j ascending); one wavefront per (live) chain
 __global__ __launch_bounds__(256) void k_matvec_pc(const double *mats, const double *x, double *out, long long C,
                                                    long long D, const int *row_idx, const int *n_rows) {

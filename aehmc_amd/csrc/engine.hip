@@ -511,6 +511,24 @@ extern "C" int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *m) {
   return 0;
 }
 
+extern "C" int aehmc_metric_sqrt(aehmc_ctx *ctx, int32_t ndim, int64_t D, const double *imm, double *sqrt_mass,
+                                 void *stream) {
+  if (!ctx) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ndim < 0 || ndim > 2)
+    FAIL("Expected a mass matrix of dimension 1 (diagonal) or 2, got " + std::to_string(ndim));
+  if (!imm || !sqrt_mass || D <= 0) FAIL("metric_sqrt: bad arguments");
+  (void)stream;  // (the factorisation runs on the default stream and is complete on return, as in aehmc_set_metric)
+  if (ndim < 2) {
+    const int64_t n = ndim == 0 ? 1 : D;
+    hipLaunchKernelGGL(k_sqrt_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, imm, sqrt_mass, (long long)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+  }
+  return dense_sqrt_mass(ctx, imm, D, sqrt_mass);
+}
+
 extern "C" int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D, const double *imm,
                                            double *sqrt_mass, void *stream) {
   if (!ctx) return -2;
@@ -1451,7 +1469,11 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     const size_t vec = (size_t)((char *)a.cur_p - (char *)a.cur_q);
     const size_t cap_bytes = (size_t)((char *)a.zbuf - (char *)a.cur_q) + vec;
     const int64_t cap = (int64_t)(cap_bytes / ((size_t)C * D * sizeof(double)));
-    if (cap < 1) FAIL("internal: workspace holds no momentum row");
+    // the chunk's normals overlay cur_q .. zbuf: that span must be what ws_layout makes it -- contiguous vectors of
+    // one size, inside the caller's workspace, none of them touched by k_draw_momentum / k_hmc_wide themselves
+    if (cap < 1 || (char *)a.cur_g - (char *)a.cur_p != (ptrdiff_t)vec || a.zbuf < a.cur_q ||
+        (char *)a.zbuf + vec > (char *)ctx->ws + ctx->ws_bytes || (char *)a.cur_q < (char *)ctx->ws)
+      FAIL("internal: the workspace span for the momentum rows is not the layout hmc_run expects");
     double *zall = a.cur_q;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;

@@ -2,6 +2,7 @@
 buffers handed to it.  PyTorch is used for device memory and streams only."""
 from __future__ import annotations
 
+import collections
 import ctypes as ct
 import hashlib
 
@@ -111,6 +112,11 @@ class Engine:
             raise EngineError(f"aehmc_create failed: {self._err()}")
         self._target_key = None
         self._metric_key = None
+        # metric handles: (device imm, device sqrt-mass) per metric content, so that kernels which alternate between
+        # metrics on one device (each kernel its own dense mass matrix) factor every matrix ONCE
+        self._metric_cache = collections.OrderedDict()
+        self.metric_cache_bytes = 4 << 30
+        self.n_metric_factorizations = 0
         self._keep = {}
         self._ws = None
         self.D = None
@@ -197,23 +203,38 @@ class Engine:
             key = (arr.shape, _content_key(arr), D)
         if self._metric_key == key and not force:
             return
-        t = _dev_f64(imm, self.device)
-        if ndim == 2:
-            if t.shape != (D, D):
-                raise ValueError(f"dense inverse mass matrix must be [{D},{D}], got {tuple(t.shape)}")
-            # the reference factors one triangle (metrics.py:56) and multiplies by the full matrix
-            # (metrics.py:71); the two agree for a symmetric matrix.  Estimates such as A @ A.T or
-            # a Welford covariance are symmetric only up to rounding: tolerate that much.
-            if _asymmetry(t) > 1e-10 * float(t.diagonal().abs().max()):
-                raise ValueError("dense inverse mass matrix must be symmetric")
+        handle = None if force else self._metric_cache.get(key)
+        if handle is None:
+            t = _dev_f64(imm, self.device)
+            if ndim == 2:
+                if t.shape != (D, D):
+                    raise ValueError(f"dense inverse mass matrix must be [{D},{D}], got {tuple(t.shape)}")
+                # the reference factors one triangle (metrics.py:56) and multiplies by the full matrix
+                # (metrics.py:71); the two agree for a symmetric matrix.  Estimates such as A @ A.T or
+                # a Welford covariance are symmetric only up to rounding: tolerate that much.
+                if _asymmetry(t) > 1e-10 * float(t.diagonal().abs().max()):
+                    raise ValueError("dense inverse mass matrix must be symmetric")
+            else:
+                t = t.reshape(-1)
+                if ndim == 1 and t.numel() != D:
+                    raise ValueError(f"diagonal inverse mass matrix must have {D} entries")
+            # sqrt(1 / imm) / L^-T (metrics.py:45,49,56-58), once per metric content
+            sm = torch.empty_like(t)
+            self._check(self.lib.aehmc_metric_sqrt(self.ctx, ndim, D, t.data_ptr(), sm.data_ptr(), self.stream),
+                        "aehmc_metric_sqrt")
+            self.n_metric_factorizations += 1
+            handle = (imm, t, sm)  # (the caller's object too: a torch tensor's id() must stay taken while cached)
+            self._metric_cache[key] = handle
+            held = 0
+            for k in reversed(list(self._metric_cache)):  # keep the most recent handles within the byte budget
+                held += 2 * self._metric_cache[k][1].numel() * 8
+                if held > self.metric_cache_bytes and k != key:
+                    del self._metric_cache[k]
         else:
-            t = t.reshape(-1)
-            if ndim == 1 and t.numel() != D:
-                raise ValueError(f"diagonal inverse mass matrix must have {D} entries")
-        # sqrt_mass = NULL: the library forms sqrt(1/imm) / L^-T itself (metrics.py:45,49,56-58)
-        c = _lib.CMetric(ndim=ndim, D=D, imm=t.data_ptr(), sqrt_mass=None)
-        sqrt_mass = None
-        self._keep["metric"] = (imm, t, sqrt_mass)
+            self._metric_cache.move_to_end(key)
+        _, t, sm = handle
+        c = _lib.CMetric(ndim=ndim, D=D, imm=t.data_ptr(), sqrt_mass=sm.data_ptr())
+        self._keep["metric"] = handle
         self._check(self.lib.aehmc_set_metric(self.ctx, ct.byref(c)), "aehmc_set_metric")
         if self.metric_ndim != ndim:
             self._ws = None

@@ -35,16 +35,29 @@ class RandomStream:
         self._resume = None  # generator states handed to the next kernel instead of fresh spawns
 
     @classmethod
-    def from_state(cls, states, seed=None, seeds=None, batched=None):
+    def from_state(cls, states, seed=None, seeds=None, batched=None, n_spawned=0):
         """Stream whose next ``sites(n)`` returns the saved states ``[C, n, 4]`` (uint64 / int64 bit
-        patterns; a device tensor, numpy array or nested list) instead of spawning.  With the original
-        ``seed`` / ``seeds`` the spawn counter moves on as well, so kernels built AFTER the resumed one
-        get the same call sites as in an unbroken session; without them a further kernel raises."""
+        patterns; a device tensor, numpy array or nested list of Python ints) instead of spawning.  With the
+        original ``seed`` / ``seeds`` the spawn counter moves on as well, so kernels built AFTER the resumed one
+        get the same call sites as in an unbroken session -- when the resumed kernel was not the first one built
+        from the stream, pass ``n_spawned`` = the number of call sites handed out BEFORE it (``stream.n_spawned``
+        of the original session at that point: 4 per NUTS kernel, 2 per HMC kernel); without the seeds a further
+        kernel raises."""
         if hasattr(states, "detach"):
             states = states.detach().cpu().numpy()
-        arr = np.ascontiguousarray(np.asarray(states))
+        arr = states if isinstance(states, np.ndarray) else np.array(states, dtype=object)  # (lists: exact Python ints)
+        if arr.dtype == object:  # nested lists mixing negative values and values >= 2**63: no silent truncation
+            if not all(isinstance(v, (int, np.integer)) for v in arr.reshape(-1)):
+                raise ValueError("generator states must be integers (64-bit patterns)")
+            flat = [int(v) for v in arr.reshape(-1)]
+            if any(v < -(1 << 63) or v > _M64 for v in flat):
+                raise ValueError("generator states must be 64-bit patterns (int64 or uint64)")
+            arr = np.array([v & _M64 for v in flat], dtype=np.uint64).reshape(arr.shape)
+        if arr.dtype.kind not in "iu" or arr.dtype.itemsize != 8:
+            raise ValueError(f"generator states must be int64 or uint64 bit patterns, got dtype {arr.dtype}")
+        arr = np.ascontiguousarray(arr)
         if arr.dtype != np.uint64:
-            arr = arr.astype(np.int64).view(np.uint64)
+            arr = arr.view(np.uint64)
         if arr.ndim != 3 or arr.shape[2] != 4:
             raise ValueError(f"generator states must be [C, n_sites, 4], got {arr.shape}")
         C = arr.shape[0]
@@ -58,8 +71,17 @@ class RandomStream:
                 raise ValueError(f"{self.num_chains} seeds for {C} saved chains")
             if batched is not None:
                 self.batched = bool(batched)
+            if n_spawned:  # the call sites the original session had handed out before the resumed kernel
+                for ss in self._seed_seqs:
+                    ss.spawn(int(n_spawned))
+                self._n_spawned = int(n_spawned)
         self._resume = arr.copy()
         return self
+
+    @property
+    def n_spawned(self) -> int:
+        """Call sites handed out so far (save it with the states when the kernel is not the stream's first)."""
+        return self._n_spawned
 
     @property
     def num_chains(self) -> int:

@@ -67,9 +67,9 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     C, D = layout.C, layout.D
     scalar_position = (len(layout.user_shape) - (1 if batched else 0)) == 0
     full = bool(is_mass_matrix_full) and not scalar_position  # mass_matrix.py:54-57: a scalar stays a scalar
-    if full and D > 512:  # one wavefront factors each chain's matrix: tested and timed up to here
+    if full and D > 2048:  # one wavefront factors each chain's matrix (tests: up to D = 1024)
         raise ValueError("is_mass_matrix_full keeps one dense D x D matrix per chain (as the reference does) and "
-                         "is supported up to D = 512")
+                         "is supported up to D = 2048")
     st, cst = eng.adapt_alloc(C, D, full)
     eng.adapt_init(C, D, float(initial_step_size), cst)
     schedule = build_schedule(int(num_steps))
@@ -81,8 +81,9 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
     if fused and nk is not None and len(schedule) > 0:
         from ._common import diagnostics, state_rows
         from .engine import rng_to_device
-        if "rng" not in nk["holder"]:
-            nk["holder"]["rng"] = rng_to_device(nk["rng_host"], eng.device)
+        if "rng" not in nk["holder"] or nk["holder"]["rng"].device != eng.device:  # (uploaded at construction, maybe elsewhere)
+            nk["holder"]["rng"] = (nk["holder"]["rng"].to(eng.device) if "rng" in nk["holder"]
+                                   else rng_to_device(nk["rng_host"], eng.device))
         q, U, g = state_rows(initial_state, layout, eng.device)
         eng.set_target(nk["logprob_fn"], D)
         out = eng.nuts_warmup(nk["holder"]["rng"], schedule, float(target_acceptance_rate),
@@ -94,8 +95,9 @@ def run(kernel, initial_state: IntegratorState, num_steps=1000, *, is_mass_matri
         from ._common import diagnostics, state_rows
         from .engine import rng_to_device
         hk = kernel._hmc
-        if "rng" not in hk["holder"]:
-            hk["holder"]["rng"] = rng_to_device(hk["rng_host"], eng.device)
+        if "rng" not in hk["holder"] or hk["holder"]["rng"].device != eng.device:
+            hk["holder"]["rng"] = (hk["holder"]["rng"].to(eng.device) if "rng" in hk["holder"]
+                                   else rng_to_device(hk["rng_host"], eng.device))
         q, U, g = state_rows(initial_state, layout, eng.device)
         eng.set_target(hk["logprob_fn"], D)
         out = eng.hmc_warmup(hk["holder"]["rng"], schedule, float(target_acceptance_rate), extra[0],

@@ -70,7 +70,7 @@ typedef struct {
 typedef struct {
   int32_t ndim;
   int32_t per_chain;       /* 1: imm / sqrt_mass are [C,1] (ndim 0), [C,D] (ndim 1) or [C,D,D]
-                              (ndim 2, D <= 512), one per chain -- what per-chain window
+                              (ndim 2, D <= 2048), one per chain -- what per-chain window
                               adaptation produces; sqrt_mass must be given
                               (aehmc_metric_sqrt_per_chain computes the dense one); 0: shared */
   int64_t D;
@@ -93,7 +93,7 @@ typedef struct {
   double *step_size;                     /* [C] */
   double *imm, *sqrt_mass;               /* [C,D] */
   int32_t full;                          /* 1: is_mass_matrix_full -- wc_m2, imm and sqrt_mass are
-                                            [C,D,D] (full covariance per chain, D <= 512) */
+                                            [C,D,D] (full covariance per chain, D <= 2048) */
   int32_t reserved;
   double *work;                          /* full && D > 64: [C,D,D] scratch of the window-end
                                             factorisation (smaller D: LDS; may be NULL) */
@@ -299,7 +299,13 @@ int aehmc_nuts_sample(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size
                       double *acceptance_history, int32_t *divergence_history,
                       int64_t *n_leapfrog_total, void *stream);
 
-/* sqrt_mass[c] = chol(imm[c])^-T (metrics.py:56-58) for C dense D x D matrices, D <= 512 (one
+/* sqrt_mass = sqrt(1 / imm) (ndim 0 / 1) or chol(imm)^-T (ndim 2; metrics.py:45,49,56-58: blocked Cholesky +
+ * triangular inverse on the fp64 MFMA GEMM) of ONE shared metric into a caller-owned array ([1] | [D] | [D,D]) --
+ * what aehmc_set_metric computes into ctx memory when aehmc_metric.sqrt_mass is NULL.  A caller that alternates
+ * between several metrics factors each once, keeps the results and passes them in aehmc_metric.sqrt_mass. */
+int aehmc_metric_sqrt(aehmc_ctx *ctx, int32_t ndim, int64_t D, const double *imm, double *sqrt_mass, void *stream);
+
+/* sqrt_mass[c] = chol(imm[c])^-T (metrics.py:56-58) for C dense D x D matrices, D <= 2048 (one
  * wavefront per matrix: in LDS up to D = 64, in a temporary device buffer above) */
 int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D, const double *imm, double *sqrt_mass,
                                 void *stream);

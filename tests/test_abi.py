@@ -168,3 +168,25 @@ def test_large_host_arrays_are_keyed_by_full_content():
             assert engine._param_key(a) == s0  # the opt-in's documented blind spot
         finally:
             engine.SAMPLED_HASH_ABOVE = None
+
+
+def test_random_stream_from_state_for_a_later_kernel_and_dtype_checks():
+    """Resuming a kernel that was NOT the first one built from its stream: `n_spawned` puts the spawn sequence where the
+    unbroken session had it, so kernels built after the resumed one get the call sites they would have got; states of
+    another dtype (floats, 32-bit ints, out-of-range Python ints) are refused instead of truncated."""
+    import numpy as np
+    from aehmc_amd import RandomStream
+    s = RandomStream(seed=3)
+    first, second, third = s.sites(4), s.sites(2), s.sites(4)
+    assert s.n_spawned == 10
+    r = RandomStream.from_state(second, seed=3, n_spawned=4)  # resume the SECOND kernel
+    assert np.array_equal(r.sites(2), second) and np.array_equal(r.sites(4), third) and r.n_spawned == 10
+    wrong = RandomStream.from_state(second, seed=3)  # without n_spawned the next kernel would get the first one's sites
+    wrong.sites(2)
+    assert not np.array_equal(wrong.sites(4), third)
+    mixed = [[[-1, 2 ** 63 + 5, 7, 9], [1, 2, 3, 4]]]  # negative (int64 view) and >= 2**63 (uint64) in one nested list
+    got = RandomStream.from_state(mixed).sites(2)
+    assert got.dtype == np.uint64 and int(got[0, 0, 0]) == 2 ** 64 - 1 and int(got[0, 0, 1]) == 2 ** 63 + 5
+    for bad in (np.zeros((1, 2, 4)), np.zeros((1, 2, 4), dtype=np.int32), [[[2 ** 64, 0, 0, 0], [0, 0, 0, 0]]]):
+        with pytest.raises(ValueError):
+            RandomStream.from_state(bad)

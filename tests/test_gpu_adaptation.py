@@ -152,7 +152,7 @@ def test_metric_sqrt_per_chain_matches_numpy():
     from aehmc_amd.engine import EngineError, get_engine
     eng = get_engine()
     r = np.random.default_rng(3)
-    for D in (1, 2, 5, 17, 64, 65, 130, 300, 512):  # LDS up to 64, global memory above; 512 = the documented maximum
+    for D in (1, 2, 5, 17, 64, 65, 130, 300, 512, 700):  # LDS up to 64, global memory above (documented maximum: 2048)
         C = 7
         A = r.normal(size=(C, D, D))
         imm = A @ A.transpose(0, 2, 1) / D + 0.5 * np.eye(D)
@@ -164,10 +164,10 @@ def test_metric_sqrt_per_chain_matches_numpy():
     bad = np.stack([np.eye(3), np.diag([1.0, -1.0, 1.0])])
     with pytest.raises(EngineError, match="positive definite"):
         eng.set_metric(PerChain(torch.as_tensor(bad, device="cuda")), 3)
-    with pytest.raises(EngineError, match="up to D = 512"):
+    with pytest.raises(EngineError, match="up to D = 2048"):
         eng.lib.aehmc_metric_sqrt_per_chain.restype  # (the limit is checked before any allocation)
         z = torch.zeros(1, dtype=torch.float64, device="cuda")
-        eng._check(eng.lib.aehmc_metric_sqrt_per_chain(eng.ctx, 1, 513, z.data_ptr(), z.data_ptr(), eng.stream),
+        eng._check(eng.lib.aehmc_metric_sqrt_per_chain(eng.ctx, 1, 2049, z.data_ptr(), z.data_ptr(), eng.stream),
                    "aehmc_metric_sqrt_per_chain")
 
 
@@ -508,3 +508,29 @@ def test_scalar_position_warmup_in_one_launch(min_team):
     for k, (a, b) in enumerate(zip(*outs)):
         assert torch.equal(a, b), k
     assert outs[0][2].shape == (C,) and not torch.allclose(outs[0][2], torch.ones_like(outs[0][2]))
+
+
+@pytest.mark.timeout(600)
+def test_full_adaptation_at_d_1024():
+    """is_mass_matrix_full above D = 512 (the reference has no size limit, mass_matrix.py:12-120; one dense matrix per
+    chain, factored by one wavefront in global memory): a short warm-up with one window end at D = 1024 gives finite,
+    symmetric, positive-definite matrices whose L^-T is the factor the engine samples with afterwards."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    D, C, n = 1024, 2, 24
+    r = np.random.default_rng(4)
+    sigma = 0.5 + r.random(D)
+    tgt = targets.DiagGaussian(np.zeros(D), sigma)
+    kern = nuts.new_kernel(RandomStream(seeds=[1, 2]), tgt, max_num_expansions=4)
+    state = nuts.new_state(torch.as_tensor(r.normal(size=(C, D)), device="cuda"), tgt)
+    state, (eps, imm), _ = window_adaptation.run(kern, state, n, is_mass_matrix_full=True)
+    M = imm.value.cpu().numpy()
+    assert M.shape == (C, D, D) and np.isfinite(M).all()
+    for c in range(C):
+        np.testing.assert_allclose(M[c], M[c].T, rtol=1e-12, atol=1e-15)
+        np.linalg.cholesky(M[c])  # positive definite (raises otherwise)
+        S = imm.sqrt_mass[c].cpu().numpy()
+        # S = L^-T with imm = L L^T: S^T imm S = I (the estimate from 20 draws is ill-conditioned: check the identity)
+        np.testing.assert_allclose(S.T @ M[c] @ S, np.eye(D), rtol=0, atol=1e-7)
+        assert np.allclose(S, np.triu(S))  # upper triangular
+    info, _ = kern(state, eps, imm)
+    assert torch.isfinite(info.state.position).all()

@@ -215,3 +215,48 @@ def test_warmup_refuses_copies_of_the_adaptation_state():
     with pytest.raises(EngineError, match="adaptation state's own arrays"):
         eng._step_call(eng.lib.aehmc_nuts_warmup, "aehmc_nuts_warmup", eng.ctx, C, rng.data_ptr(), 3, stage, wend, 0.8,
                        10, 1000.0, q.data_ptr(), U.data_ptr(), g.data_ptr(), ct.byref(c), ct.byref(cst), eng.stream)
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), device="cuda", dtype=torch.float64)
+
+
+def test_alternating_dense_metrics_are_factored_once_each():
+    """Two kernels with different dense inverse mass matrices alternating on one device: each matrix is uploaded and
+    factored (Cholesky + triangular inverse, ~0.1 s at D = 1e4) ONCE -- the engine keeps a handle (device copy + L^-T)
+    per metric content -- and the results are those of a fresh engine state.  An in-place edit of a matrix is a new
+    content, hence a new factorisation."""
+    from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    r = np.random.default_rng(0)
+    D, C = 2000, 8
+
+    def spd():
+        A = r.normal(size=(D, D))
+        M = A @ A.T / D + np.eye(D)
+        return 0.5 * (M + M.T)
+
+    imms = [spd(), spd()]
+    tgt = targets.StdNormal()
+    q0 = r.normal(size=(C, D))
+    kerns = [nuts.new_kernel(RandomStream(seeds=list(range(10 * k, 10 * k + C))), tgt, max_num_expansions=3) for k in range(2)]
+    states = [nuts.new_state(dev(q0), tgt) for _ in range(2)]
+    n0 = eng.n_metric_factorizations
+    first = []
+    for rep in range(3):
+        for k in range(2):
+            info, _ = kerns[k](states[k], 0.05, imms[k])
+            states[k] = info.state._replace(momentum=None)
+            if rep == 0:
+                first.append(info.state.position.clone())
+    assert eng.n_metric_factorizations - n0 == 2
+    # same transitions from a cold cache (force): same bits
+    k2 = nuts.new_kernel(RandomStream(seeds=list(range(0, C))), tgt, max_num_expansions=3)
+    eng.set_metric(imms[0], D, force=True)
+    info, _ = k2(nuts.new_state(dev(q0), tgt), 0.05, imms[0])
+    assert torch.equal(info.state.position, first[0])
+    n1 = eng.n_metric_factorizations
+    imms[1][5, 5] += 0.5  # in-place edit: new content
+    kerns[1](states[1], 0.05, imms[1])
+    assert eng.n_metric_factorizations == n1 + 1
