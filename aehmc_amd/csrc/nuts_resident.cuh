@@ -85,9 +85,20 @@ __device__ __forceinline__ void team_sum2(double &x, double &y, bool single = fa
 // in LDS instead of global memory -- [wave][level][2][64] doubles, element i written and read by lane i only.  For a
 // few chains (one wavefront per SIMD or less: the README example's single chain) the checkpoint reads are dependent
 // L2 round trips on the serial path of every leapfrog; with many chains the 40 KB per workgroup would cost occupancy.
+// Wavefronts per SIMD the register allocator has to leave room for.  A MULTI launch of one wavefront per chain keeps
+// ~80 VGPRs of chain state live through the tree loop; left alone, the scheduler gives up on 128 registers once the
+// inlined log1p / exp bodies of the proposal weights push past them and settles at 150-170 (3 waves per SIMD: 4096 chains
+// then run as a full round plus a one-third-full one).  Held to 4 waves it fits 127-128 registers and what it spills
+// (10-54 dwords: row base addresses and adaptation scalars) is stored once per launch and reloaded once per TRANSITION,
+// outside the tree loop (profiles/r4/INDEX.md has the per-loop-depth count of scratch instructions).
+#ifndef AEHMC_RES_MIN_WAVES
+#define AEHMC_RES_MIN_WAVES 1
+#endif
+constexpr int res_min_waves(int T, int R, bool MULTI) { return (AEHMC_RES_MIN_WAVES && T == 64 && MULTI && R <= 4) ? 4 : 1; }
+
 template <int T, int R, bool MULTI, int DENSE = 0, bool CKL = false>
-__global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK) void k_nuts_resident(EngineArgs a,
-                                                                                            NutsSampleArgs m) {
+__global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK)
+    __attribute__((amdgpu_waves_per_eu(res_min_waves(T, R, MULTI)))) void k_nuts_resident(EngineArgs a, NutsSampleArgs m) {
   using TM = Team<T>;
   static_assert(DENSE == 0 || (T == 64 && R == 1), "dense products: one wavefront per chain, one element per lane");
   static_assert(!CKL || (DENSE == 0 && T == 64 && R == 1), "LDS checkpoints: one wavefront per chain, one element per lane");
