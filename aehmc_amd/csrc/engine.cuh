@@ -99,6 +99,9 @@ struct NutsSampleArgs {
   // small dense problems (k_nuts_resident's DENSE instantiations)
   const double *prec;  // the dense target's precision [D, D]
   double *imm_ws;      // per-chain dense metrics: [C, D, D] workspace for the transposed matrices
+  // block-resident kernels (nuts_block_reg.cuh): waiting chains of a workgroup begin their next transition once this
+  // many wait (0: the kernel's default; 16: all together, transition by transition)
+  int roll;
 };
 
 // two-entry arrays are picked with a select, never indexed dynamically (a dynamic index

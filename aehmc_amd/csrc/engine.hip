@@ -18,6 +18,7 @@
 #include "nuts_linreg.cuh"
 #include "nuts_block.cuh"
 #include "nuts_block_reg.cuh"
+#include "nuts_block_roll.cuh"
 #include "nuts_resident.cuh"
 #include "nuts_wide.cuh"
 
@@ -52,6 +53,7 @@ struct aehmc_ctx {
   bool opt_fused_nuts = false;   // whole NUTS transition in one launch (diag metric, coordinate-wise target)
   bool opt_dense_linear = true;  // one metric GEMM per leapfrog (v carried by linearity)
   bool opt_compact = true;       // finished chains drop out of the GEMMs
+  int opt_block_roll = 0;        // block-resident NUTS: waiting chains that trigger a begin round (0: kernel default)
   int opt_block_dense = 1;       // mid-size dense problems (64 < D <= 512): one workgroup per 16 chains, whole call in one launch
                                  // (1: chain state in registers up to D = 256, in L2-resident work rows above; 2: always work rows)
   bool opt_fp_contract = false;  // fast arithmetic in the leapfrog bodies of the register-resident kernels (1e-6, not bit parity)
@@ -699,6 +701,11 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
     ctx->opt_block_dense = (int)value;
     return 0;
   }
+  if (!strcmp(name, "block_roll")) {
+    if (value < 0 || value > 16) FAIL("block_roll: 0 (default) ... 16");
+    ctx->opt_block_roll = (int)value;
+    return 0;
+  }
   if (!strcmp(name, "fp_contract")) {
     ctx->opt_fp_contract = value != 0;
     return 0;
@@ -1204,11 +1211,13 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       *multi_done = true;
     }
     m.prec = ctx->tgt.prec;
+    m.roll = ctx->opt_block_roll;
     double *bp = nullptr;
     if (int rc = block_pack_workspace(ctx, a.D, &bp)) return rc;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(launch_nuts_block_reg(a, m, bp, st));
+    if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(launch_nuts_block_roll(a, m, bp, st));
+    else if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(launch_nuts_block_reg(a, m, bp, st));
     else HIPCHK(launch_nuts_block_dense(a, m, bp, st));
     return prof_end(ctx, st, p);
   }

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void k_blk_pack(const double *src, double *dst
 
 // One wavefront: out[m][n0 + n] = sum_k A[m][k] B[n0 + n][k] for the 16 chains m of the workgroup and 16 columns n
 // -- the A rows in LDS (abuf [16][S], zero beyond D), B packed row-major [Dp][Dp] in global memory (L2), the result
-// to out[m * ldo + n0 + n] for m < mvalid, n0 + n < N (global rows of the work arrays, or rows of an LDS buffer).
+// to out[m * ldo + n0 + n] for the rows m of `rowmask` (bit m), n0 + n < N (global rows of the work arrays, or rows of
+// an LDS buffer; rows are independent, so a masked-out row costs nothing but its share of the MFMA).
 // B is fetched in whole cache lines: lane (r = lane >> 2, kq = lane & 3) loads doubles 2 kq, 2 kq + 1 and 8 + 2 kq,
 // 9 + 2 kq of row n0 + r of the K-tile -- four consecutive lanes read 64 contiguous bytes (a first version had lane
 // (row = lane & 15, quarter = lane >> 4) load its fragment's 32 bytes directly: 64 separate 16-byte requests per
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void k_blk_pack(const double *src, double *dst
 // to 18 doubles per row (conflict-free reads, two-way conflicts on the writes) 98, swizzled 77; the global loads
 // and the wavefront fences add nothing.
 __device__ __forceinline__ void blk_wave_tile(const double *abuf, int S, const double *__restrict__ Bp, int Dp,
-                                              long long N, int n0, double *out, long long ldo, int mvalid,
+                                              long long N, int n0, double *out, long long ldo, unsigned rowmask,
                                               int lane, double *tb) {
   const int fr = lane & 15, fk = lane >> 4;
   const int r = lane >> 2, kq = lane & 3;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void blk_wave_tile(const double *abuf, int S, const d
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int mrow = fk + 4 * q;
-    if (mrow < mvalid && col < N) out[(long long)mrow * ldo + col] = acc[q];
+    if (((rowmask >> mrow) & 1u) && col < N) out[(long long)mrow * ldo + col] = acc[q];
   }
 }
 
@@ -169,7 +170,7 @@ __device__ __forceinline__ void blk_gemm(double *abuf, int S, const double *X, c
   const int mvalid = (int)(C - c0 < BLK_CHAINS ? C - c0 : BLK_CHAINS);
   double *const tb = abuf + BLK_CHAINS * S + wave * BLK_TB;  // this wavefront's staging tile
   for (int nt = wave; nt < NT; nt += BLK_CHAINS)
-    blk_wave_tile(abuf, S, B, NT * 16, D, nt * 16, out + c0 * D, D, mvalid, lane, tb);
+    blk_wave_tile(abuf, S, B, NT * 16, D, nt * 16, out + c0 * D, D, (1u << mvalid) - 1u, lane, tb);
   tm.tick(2);  // MFMA column blocks
   __syncthreads();
   tm.tick(3);  // barrier

@@ -24,7 +24,7 @@ namespace aehmc {
 
 constexpr int BLK_REG_MAX_D = 256;
 inline bool block_reg_supported(long long D) { return D >= BLK_MIN_D && D <= BLK_REG_MAX_D; }
-constexpr int BLK_PARK = 16;  // doubles per wavefront: the chain's four generators (see k_nuts_block_reg)
+constexpr int BLK_PARK = 20;  // doubles per wavefront: the chain's four generators (see k_nuts_block_reg) + the rolling kernel's between-transition scalars
 // two row buffers [16][S] (operand / result, swapping roles from product to product) + one staging tile per wavefront
 // + the target's mean [S] + the parking areas
 inline size_t blk_reg_lds_bytes(long long D) {
@@ -54,11 +54,11 @@ __device__ __forceinline__ int blk_bernoulli(double *d, int k, double p, int lan
   return r;
 }
 
-// dst[16][S] = src[16][S] * Bp^T, both in LDS; the caller places the barriers
+// dst[16][S] = src[16][S] * Bp^T, both in LDS, for the rows of `rowmask`; the caller places the barriers
 __device__ __forceinline__ void blk_gemm_lds(const double *src, double *dst, int S, const double *Bp, long long D,
-                                             int wave, int lane, double *tb) {
+                                             int wave, int lane, double *tb, unsigned rowmask = 0xffffu) {
   const int NT = (int)((D + 15) / 16);
-  for (int nt = wave; nt < NT; nt += BLK_CHAINS) blk_wave_tile(src, S, Bp, NT * 16, D, nt * 16, dst, S, BLK_CHAINS, lane, tb);
+  for (int nt = wave; nt < NT; nt += BLK_CHAINS) blk_wave_tile(src, S, Bp, NT * 16, D, nt * 16, dst, S, rowmask, lane, tb);
 }
 
 template <int R, bool TDENSE>

@@ -1,0 +1,685 @@
+// Block-resident dense NUTS, several transitions per launch, chains ROLLING ON (gfx950): 64 < D <= 256.
+//
+// k_nuts_block_reg (nuts_block_reg.cuh) runs the transitions of a workgroup's 16 chains together: every transition lasts
+// as long as the deepest of 16 trees (28 rounds at D = 200 where the mean tree has 17.3 leapfrogs).  Here a chain whose
+// tree has ended records its transition, draws its next momentum and begins again while its neighbours are still in
+// their trees -- the products of a round serve whatever mixture of running and beginning chains there is (row masks);
+// a round in which chains begin carries one more product (p = L^-T z).  Same stage / bookkeeping arithmetic as
+// k_nuts_block_reg, chain by chain: the results do not depend on the schedule, bit for bit (tests/test_gpu_block_dense.py).
+// Measured (profiles/r4/INDEX.md): rounds per transition 27.2 -> 21.2, products -13 %; what of that is left after the
+// compiler's handling of the larger loop body is 3-4 % at D = 200 and a loss below D = 128, so the engine uses this
+// kernel for D > 128 and launches of more than one transition (option "block_roll").
+// Reference: nuts.py:56-153, trajectory.py:154-374,428-714, termination.py:85-235, proposals.py:19-174,
+// integrators.py:54-73, metrics.py:44-104.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "nuts_block_reg.cuh"
+
+namespace aehmc {
+
+// The D standard normals of a chain's next momentum (site #1: generator 0 of the chain, home in LDS at `park`) into its
+// operand row.  A real call, not inlined: the draw wants ~90 registers of its own, and inside the round loop of
+// k_nuts_block_reg they would come out of the chain state's 128 (spill code all over the hot path); as a callee it
+// saves what it needs around itself, once per transition.
+__device__ __attribute__((noinline)) void blk_draw_normals(double *park, double *xrow, long long D, int lane) {
+  Pcg64 g0 = blk_gen_load(park, 0);
+  wave_normals(g0, D, [=](long long i, double z) { xrow[i] = z; });
+  blk_gen_store(park, 0, g0, lane);
+  __threadfence_block();
+}
+
+// a value the optimizer has to take as it comes (see ATL in k_nuts_block_reg)
+__device__ __forceinline__ int blk_opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+template <int R, bool TDENSE>
+__global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, NutsSampleArgs m) {
+  extern __shared__ __attribute__((aligned(16))) double blk_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long c0 = (long long)blockIdx.x * BLK_CHAINS, c = c0 + wave;
+  const bool valid = c < a.C;
+  const long long D = a.D;
+  const int S = (int)blk_lds_stride(D);
+  double *const xbuf = blk_lds, *const ybuf = blk_lds + BLK_CHAINS * S;
+  double *const tb = blk_lds + 2 * BLK_CHAINS * S + wave * BLK_TB;
+  double *const mus = blk_lds + 2 * BLK_CHAINS * S + BLK_CHAINS * BLK_TB;  // the dense target's mean
+  // Register budget: 16 wavefronts per workgroup leave a lane 128 registers.  The chain's q, p, v and momentum sum
+  // (8 R registers), its tree state (wave-uniform, but the product of fp64 VALU arithmetic: ~26 VGPRs) and the
+  // product's ~45 fit; dU/dq and w do not have to be in registers (they stay in the LDS rows the products write), and
+  // the four generators (32 more: 64-bit integer VALU arithmetic) have their home in LDS, a draw holding one of them
+  // for its own duration.  A first version with q, p, g, v, w and the generators in registers spilled 270-450 bytes
+  // per lane: the spill code alone moved 2.9 TB/s through HBM and the kernel waited on it (profiles/r4/INDEX.md);
+  // now the per-leapfrog loop has no scratch access.
+  double *const park = mus + S + wave * BLK_PARK;
+  double *const xrow = xbuf + wave * S, *const yrow = ybuf + wave * S;
+  const size_t row = (size_t)(valid ? c : 0) * D;
+  const bool elem = target_is_elem(a.tkind);
+  for (int k = lane; k < S; k += 64) {  // pads (and the rows of chains past C) stay zero for the whole launch
+    xrow[k] = 0.0;
+    yrow[k] = 0.0;
+  }
+  if (TDENSE)
+    for (int k = threadIdx.x; k < S; k += BLK_THREADS) mus[k] = k < D ? a.mu[k] : 0.0;
+#define EI(r) (lane + 64 * (r))
+#define AT(ptr, r) ((ptr) + row)[EI(r)]
+// The chain's row of a [C, D] array from code that runs once per transition or expansion inside the round loop: the lane
+// index passes through blk_opaque first, so that the address is the array's row base (wave-uniform: scalar registers)
+// plus a lane offset formed on the spot.  Left visible, the loop-invariant per-lane addresses of all ~20 arrays are
+// hoisted out of the round loop as 64-bit VGPR pairs, spilled, and reloaded one by one behind an s_waitcnt that also
+// waits for the previous store's acknowledgement -- ~60 dependent L2 round trips per tree start (measured: the
+// beginning of a transition cost four rounds' worth of bookkeeping, and every round waited for it at the barrier).
+#define ATL(ptr, r) ((ptr) + row)[lc + 64 * (r)]
+  bool ok[R];
+  // q, p, v and the sub-trajectory momentum sum in registers; dU/dq and w = imm dU/dq stay where the products leave
+  // them, in the chain's rows of the two LDS buffers (dense target: P r lands in ybuf, imm g' in xbuf; coordinate-wise
+  // target: g' is written to xbuf as the operand, imm g' lands in ybuf) -- 16 registers less at R = 4
+  double q[R], p[R], v[R], pb[R];
+  double *const grow = TDENSE ? yrow : xrow, *const wrow = TDENSE ? xrow : yrow;
+  // The lock-step engine's work vectors (engine.hip ws_layout: one after the other, the same distance apart) are
+  // addressed from ONE base and stride: two scalar register pairs instead of twenty-five -- with every pointer of
+  // EngineArgs live in the round loop the scalar file overflowed into VGPR lanes, and the v_readlane traffic of getting
+  // them back (1215 sites against 293) made the per-leapfrog code 25 % slower (profiles/r4/INDEX.md).
+  // launch_nuts_block_reg checks the layout it relies on.  w = imm dU/dq of the two proposal slots (beside slot_q /
+  // slot_p / slot_g) lives in the moving-end rows cur_w / cur_v, which this kernel does not use otherwise.
+  // Pointers that only the once-per-transition code uses (the state and diagnostics arrays, the per-transition records)
+  // are read from a table in LDS where they are used -- as kernel arguments referenced inside the round loop each would
+  // hold a scalar register pair (or a VGPR lane and a v_readlane) for the whole loop.
+  __shared__ void *blk_cold[12];
+  if (threadIdx.x == 0) {
+    blk_cold[0] = a.q; blk_cold[1] = a.g; blk_cold[2] = a.U;
+    blk_cold[3] = a.out.momentum; blk_cold[4] = a.out.acceptance_probability; blk_cold[5] = a.out.num_doublings;
+    blk_cold[6] = a.out.is_turning; blk_cold[7] = a.out.is_diverging; blk_cold[8] = a.out.n_leapfrog;
+    blk_cold[9] = m.samples; blk_cold[10] = m.acc_hist; blk_cold[11] = m.div_hist;
+  }
+#define COLD(T, i) (static_cast<T *>(blk_cold[i]))
+  double *const wsb = a.cur_q;
+  const size_t wss = (size_t)(a.cur_p - a.cur_q);
+  const int wmd = 20 + 2 * a.max_exp;  // first vector of the dense-metric group
+#define WSV(k) (wsb + (size_t)(k) * wss)
+#define W_END_Q(e) WSV(3 + 3 * (e))
+#define W_END_P(e) WSV(4 + 3 * (e))
+#define W_END_G(e) WSV(5 + 3 * (e))
+#define W_SLOT_Q(s) WSV(9 + 3 * (s))
+#define W_SLOT_P(s) WSV(10 + 3 * (s))
+#define W_SLOT_G(s) WSV(11 + 3 * (s))
+#define W_PSUM WSV(15)
+#define W_END_V(e) WSV(wmd + 1 + (e))
+#define W_END_W(e) WSV(wmd + 4 + a.max_exp + (e))
+#define W_SLOT_W(s) WSV((s) ? wmd : wmd + 3 + a.max_exp)
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    ok[r] = valid && EI(r) < D;
+    q[r] = p[r] = v[r] = pb[r] = 0.0;
+  }
+  ChainCtl ct = {};
+  ct.done = 1;
+  double eps = 0.0;
+  // what a chain carries from one transition to the next -- its potential energy, its leapfrog total, the number of
+  // transitions it has completed -- is touched once per transition: parked in LDS beside the generators
+  double *const U_home = park + 16;
+  long long *const nleap_home = reinterpret_cast<long long *>(park + 17), *const t_home = reinterpret_cast<long long *>(park + 18);
+  if (valid) {
+    const ChainRng rng0 = rng_load(a, c);
+#pragma unroll
+    for (int k = 0; k < 4; k++) blk_gen_store(park, k, rng0.g[k], lane);
+    eps = a.eps_c ? a.eps_c[c] : a.eps;
+    if (lane == 0) {
+      *U_home = a.U[c];
+      *nleap_home = 0;
+      *t_home = 0;
+    }
+  }
+  BlkTimer tm;
+
+  // first stages of a leapfrog (leap_linear<12>): p_half, v_half, q', the target where it is coordinate-wise, and the
+  // operand row of the next product -- r = q' - mu (dense target) or dU/dq' itself -- into this chain's row of xbuf
+  auto stage12 = [&]() __attribute__((always_inline)) {
+    const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
+    const double b = 0.5 * step_size, aa = 1 * step_size;
+    double usum = 0.0;
+    const int ls = blk_opaque(lane) & 63;  // (the target's parameter addresses are formed here: see ATL)
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        const double pp = p[r] - b * grow[EI(r)];
+        const double vv = v[r] - b * wrow[EI(r)];
+        p[r] = pp;
+        v[r] = vv;
+        const double qq = q[r] + aa * vv;
+        q[r] = qq;
+        if (!TDENSE) {
+          double u, gnew;
+          target_elem(a, ls + 64 * r, qq, u, gnew);
+          usum += u;
+          xrow[EI(r)] = gnew;  // (= grow: the new gradient over the old one, and the next product's operand)
+        } else {
+          xrow[EI(r)] = qq - mus[EI(r)];
+        }
+      }
+    }
+    if (!TDENSE) ct.U_cur = target_finish(a, wave_sum(usum));
+  };
+  // sub-trajectory proposal <- moving end (copy_cur_to_slot)
+  auto take = [&](int slot) __attribute__((always_inline)) {
+    const int lc = blk_opaque(lane) & 63;  // (addresses formed here, not hoisted out of the round loop: see ATL)
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        ATL(W_SLOT_Q(slot), r) = q[r];
+        ATL(W_SLOT_P(slot), r) = p[r];
+        ATL(W_SLOT_G(slot), r) = grow[EI(r)];
+        ATL(W_SLOT_W(slot), r) = wrow[EI(r)];  // (w = imm dU/dq travels with the proposal: the next transition starts from it)
+      }
+    }
+    put2(ct.U_slot, slot, ct.U_cur);
+  };
+  // expand_once after integrate() returned (nuts_finalize_expansion<true> + nuts_write_outputs / nuts_begin_expansion)
+  auto finalize = [&](bool is_div, bool has_term) __attribute__((always_inline)) {
+    const int lc = blk_opaque(lane) & 63;  // (addresses formed here, not hoisted out of the round loop: see ATL)
+    const int dir = ct.dir, oth = 1 - dir;
+    double d_l = 0.0, d_r = 0.0;
+    double pov[R], vov[R], psv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      pov[r] = ok[r] ? ATL(W_END_P(oth), r) : 0.0;
+      vov[r] = ok[r] ? ATL(W_END_V(oth), r) : 0.0;
+      psv[r] = ok[r] ? ATL(W_PSUM, r) : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        const double pc = p[r], po = pov[r], vc = v[r], vo = vov[r];
+        const double s = psv[r] + pb[r];
+        ATL(W_PSUM, r) = s;
+        const double pl = dir ? po : pc, pr = dir ? pc : po;
+        const double vl = dir ? vo : vc, vr = dir ? vc : vo;
+        const double rho = s - (pr + pl) / 2;
+        d_l += vl * rho;
+        d_r += vr * rho;
+        ATL(W_END_Q(dir), r) = q[r];
+        ATL(W_END_P(dir), r) = pc;
+        ATL(W_END_G(dir), r) = grow[EI(r)];
+        ATL(W_END_V(dir), r) = vc;
+        ATL(W_END_W(dir), r) = wrow[EI(r)];
+      }
+    }
+    d_l = wave_sum(d_l);
+    d_r = wave_sum(d_r);
+    const bool turning = (d_l <= 0) | (d_r <= 0);
+    put2(ct.U_end, dir, ct.U_cur);
+    ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;  // trajectory.py:551-553
+    double pbias = exp(ct.sub_w - ct.prop_w);            // proposals.py:130 (always drawn)
+    if (pbias > 1.0) pbias = 1.0;
+    if (pbias < 0.0) pbias = 0.0;
+    const int acc_b = blk_bernoulli(park, 3, pbias, lane);
+    if (is_div || has_term) {
+      ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);  // trajectory.py:560-564
+    } else {
+      ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);           // proposals.py:141-144
+      ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
+      if (acc_b) {
+        ct.prop_slot ^= 1;
+        ct.prop_E = ct.sub_E;
+      }
+    }
+    ct.ndoubl = ct.j + 1;
+    ct.out_div = is_div;
+    ct.out_turn = turning;
+    const bool end_transition = is_div || turning || has_term || (ct.j + 1 == a.max_exp);
+    if (end_transition) {  // nuts_write_outputs
+      const int s = ct.prop_slot;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          ATL(COLD(double, 0), r) = ATL(W_SLOT_Q(s), r);
+          ATL(COLD(double, 1), r) = ATL(W_SLOT_G(s), r);
+          if (COLD(double, 3)) ATL(COLD(double, 3), r) = ATL(W_SLOT_P(s), r);
+        }
+      }
+      if (lane == 0) {
+        COLD(double, 2)[c] = pick2(ct.U_slot, s);
+        COLD(double, 4)[c] = ct.acc_prob;
+        if (COLD(int64_t, 5)) COLD(int64_t, 5)[c] = ct.ndoubl;
+        if (COLD(int32_t, 6)) COLD(int32_t, 6)[c] = ct.out_turn;
+        COLD(int32_t, 7)[c] = ct.out_div;
+        if (COLD(int64_t, 8)) COLD(int64_t, 8)[c] = ct.nleap;
+      }
+      ct.done = 1;  // (the caller keeps the chain alive while a phantom scan is pending)
+    } else {        // nuts_begin_expansion
+      ct.j += 1;
+      const int go_right = blk_bernoulli(park, 1, 0.5, lane);  // trajectory.py:516
+      ct.dir = go_right;
+      ct.step = 0;
+      if (dir != go_right) {  // cur <- the other end (trajectory.py:518)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          if (ok[r]) {
+            q[r] = ATL(W_END_Q(go_right), r);
+            p[r] = ATL(W_END_P(go_right), r);
+            grow[EI(r)] = ATL(W_END_G(go_right), r);
+            v[r] = ATL(W_END_V(go_right), r);
+            wrow[EI(r)] = ATL(W_END_W(go_right), r);
+          }
+        }
+        ct.U_cur = pick2(ct.U_end, go_right);
+      }
+    }
+  };
+  // last stage of the leapfrog + one iteration of dynamic_integration's scan (nuts_book<true, 1>)
+  auto book = [&]() __attribute__((always_inline)) {
+    const int step = ct.step;
+    if (!ct.phantom) ct.nleap += 1;
+    int tmin, tmax;
+    if (step == 0) {  // termination.py:109-113: indices inherited from the previous sub-trajectory
+      tmin = ct.tmin;
+      tmax = ct.tmax;
+    } else {          // termination.py:192-235 in closed form
+      const int n1 = __ffs(~step) - 1;
+      tmax = __popc(step >> 1);
+      tmin = tmax - n1 + 1;
+    }
+    const bool even = (step & 1) == 0;
+    const bool f_turn = step >= 1 && tmax >= tmin;
+    const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
+    const double b = 0.5 * step_size;
+    double *const ckp = a.ckp + ((size_t)tmax * a.C + c) * D;
+    double *const cks = a.cks + ((size_t)tmax * a.C + c) * D;
+    double *const ckv = a.ckv + ((size_t)tmax * a.C + c) * D;
+    double kpv[R], kvv[R], ksv[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {  // (loaded before this step's pair is stored over them)
+      kpv[r] = (f_turn && ok[r]) ? ckp[EI(r)] : 0.0;
+      kvv[r] = (f_turn && ok[r]) ? ckv[EI(r)] : 0.0;
+      ksv[r] = (f_turn && ok[r]) ? cks[EI(r)] : 0.0;
+    }
+    double usum = 0.0, kd = 0.0, f_dl = 0.0, f_dr = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (ok[r]) {
+        const double gr = grow[EI(r)], wr = wrow[EI(r)];
+        if (TDENSE) usum += (q[r] - mus[EI(r)]) * gr;  // leap_linear<3>
+        const double pn = p[r] - b * gr;
+        const double vn = v[r] - b * wr;
+        p[r] = pn;
+        v[r] = vn;
+        kd += vn * pn;                                            // bookkeeping
+        const double s = (step == 0) ? pn : pb[r] + pn;
+        pb[r] = s;
+        if (even) {
+          ckp[EI(r)] = pn;
+          cks[EI(r)] = s;
+          ckv[EI(r)] = vn;
+        }
+        if (f_turn) {                                             // first level of is_iterative_turning
+          const double pl = kpv[r], vl = kvv[r];
+          const double sub = s - ksv[r] + pl;
+          const double rho = sub - (pn + pl) / 2;
+          f_dl += vl * rho;
+          f_dr += vn * rho;
+        }
+      }
+    }
+    tm.tick(0);  // (timing build) vector pass incl. the first-level checkpoint loads
+    if (TDENSE) ct.U_cur = target_finish(a, wave_sum(usum));
+    kd = wave_sum(kd);
+    ct.tmin = tmin;
+    ct.tmax = tmax;
+    const double E = ct.U_cur + 0.5 * kd;  // proposals.py:19-62
+    double delta = ct.H0 - E;
+    if (isnan(delta)) delta = -INFINITY;
+    const bool div = fabs(delta) > a.thr;
+    const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
+    bool term = false, do_take = false;
+    if (step == 0) {
+      ct.sub_E = E;
+      ct.sub_w = np_w;
+      ct.sub_slpa = np_slpa;
+      ct.length = 1;
+      do_take = true;
+    } else {
+      const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
+      const int acc = blk_bernoulli(park, 2, sc.pa, lane);
+      ct.sub_w = sc.sub_w;
+      ct.sub_slpa = sc.sub_slpa;
+      if (acc) {
+        ct.sub_E = E;
+        do_take = !ct.phantom;
+      }
+      ct.length += 1;
+    }
+    if (do_take) take(ct.prop_slot ^ 1);  // sub-trajectory proposal <- moving end (one call site: the copy is inlined once)
+    tm.tick(1);  // (timing build) reductions, step scalars, accept draw, proposal copy
+    if (step >= 1) {
+      if (tmax >= tmin) {  // termination.py:133-187
+        int idx = tmax;
+        bool crit = false;
+        for (;;) {
+          double d_l = 0.0, d_r = 0.0;
+          if (idx == tmax) {
+            d_l = f_dl;
+            d_r = f_dr;
+          } else {
+            const double *kp = a.ckp + ((size_t)idx * a.C + c) * D;
+            const double *ks = a.cks + ((size_t)idx * a.C + c) * D;
+            const double *kv = a.ckv + ((size_t)idx * a.C + c) * D;
+            double lp[R], lv[R], ls[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              lp[r] = ok[r] ? kp[EI(r)] : 0.0;
+              lv[r] = ok[r] ? kv[EI(r)] : 0.0;
+              ls[r] = ok[r] ? ks[EI(r)] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+              if (ok[r]) {
+                const double pl = lp[r], pr = p[r], vl = lv[r], vr = v[r];
+                const double sub = pb[r] - ls[r] + pl;
+                const double rho = sub - (pr + pl) / 2;
+                d_l += vl * rho;
+                d_r += vr * rho;
+              }
+            }
+          }
+          d_l = wave_sum(d_l);
+          d_r = wave_sum(d_r);
+          crit = (d_l <= 0) | (d_r <= 0);
+          const bool reached = (idx - 1) < tmin;
+          idx -= 1;
+          if (crit || reached) break;
+        }
+        term = crit;
+      }
+    }
+    bool fin = false, fin_div = false, fin_term = false, to_phantom = false;
+    if (step == 0 && div && !ct.phantom) {
+      // trajectory.py:336: integrate() returns the first-step tuple, yet the scan still executes (and draws from
+      // site #3): finalize now, keep stepping as a phantom
+      fin = fin_div = to_phantom = true;
+    } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
+      if (ct.phantom) ct.done = 1;
+      else {
+        fin = true;
+        fin_div = div;
+        fin_term = term;
+      }
+    } else {
+      ct.step = step + 1;
+    }
+    if (fin) {  // (one call site: the expansion code is inlined once)
+      finalize(fin_div, fin_term);
+      if (to_phantom) {
+        ct.done = 0;
+        ct.phantom = 1;
+        ct.step = 1;
+      }
+    }
+  };
+
+  // ---- scheduling: chains roll on ----------------------------------------------------------------------------------
+  // A chain whose tree has ended does not wait for the deepest tree of its workgroup: it records the transition, in the
+  // next round -- while the running chains do their bookkeeping, so that nobody waits for it at the barrier -- draws
+  // the next momentum's normals into its operand row (protected from the products by their row masks) and WAITS; once
+  // `roll` chains wait (or nothing else runs) the round carries one more product -- p = L^-T z for the waiting rows --
+  // and the products of the round form v = imm p beside the running chains' rows; w = imm dU/dq of the accepted state
+  // is the one the leapfrog that produced it computed (kept with the proposal: slot_w), so the chain is back in the
+  // next round.  With the trees of a warmed-up sampler (12 or 21 leapfrogs at D = 200, rarely 27 / 35) a launch of T
+  // transitions costs ~T x (mean + a begin round) rounds instead of T x the deepest tree of 16 (profiles/r4/INDEX.md:
+  // the estimate from recorded tree lengths and the measurement).  Only the FIRST transition of a launch has to form w
+  // (one more product, all chains together).  Per-chain arithmetic is untouched: same bits whatever the schedule.
+  constexpr int PH_RUN = 0, PH_WAIT = 1, PH_DONE = 2, PH_DRAW = 3;
+  __shared__ int blk_status[BLK_CHAINS];
+  const int roll = m.roll > 0 ? m.roll : (TDENSE ? 3 : 4);
+  int phase = valid ? PH_WAIT : PH_DONE;
+  // the normals of the next momentum (site #1) into the chain's operand row
+  auto draw_z = [&]() __attribute__((always_inline)) { blk_draw_normals(park, xrow, D, lane); };
+  // nuts_init_chain<true>: q, p, v in registers, dU/dq and w in their rows
+  auto init_tree = [&]() __attribute__((always_inline)) {
+    const int lc = blk_opaque(lane) & 63;  // (addresses formed here, not hoisted out of the round loop: see ATL)
+    double kd = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      pb[r] = 0.0;
+      if (ok[r]) {
+        const double gr = grow[EI(r)], wr = wrow[EI(r)];
+        kd += v[r] * p[r];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          ATL(W_END_Q(e), r) = q[r];
+          ATL(W_END_P(e), r) = p[r];
+          ATL(W_END_G(e), r) = gr;
+          ATL(W_END_V(e), r) = v[r];
+          ATL(W_END_W(e), r) = wr;
+        }
+        ATL(W_SLOT_Q(0), r) = q[r];
+        ATL(W_SLOT_P(0), r) = p[r];
+        ATL(W_SLOT_G(0), r) = gr;
+        ATL(W_SLOT_W(0), r) = wr;
+        ATL(W_PSUM, r) = p[r];
+      }
+    }
+    kd = wave_sum(kd);
+    const double U = *U_home;
+    ct.H0 = U + 0.5 * kd;
+    ct.prop_E = ct.H0;
+    ct.prop_w = 0.0;
+    ct.prop_slpa = -INFINITY;
+    ct.sub_E = ct.sub_w = ct.sub_slpa = 0.0;
+    ct.U_cur = ct.U_end[0] = ct.U_end[1] = ct.U_slot[0] = ct.U_slot[1] = U;
+    ct.acc_prob = 0.0;
+    ct.nleap = 0;
+    ct.j = 0;
+    ct.length = 0;
+    ct.tmin = ct.tmax = 0;
+    ct.done = ct.phantom = 0;
+    ct.prop_slot = 0;
+    ct.ndoubl = ct.out_div = ct.out_turn = 0;
+    ct.dir = blk_bernoulli(park, 1, 0.5, lane);  // trajectory.py:516
+    ct.step = 0;
+  };
+  // per-transition records (the outputs themselves were written when the transition ended), then WAIT or DONE
+  auto end_transition = [&]() __attribute__((always_inline)) {
+    const int lc = blk_opaque(lane) & 63;  // (addresses formed here, not hoisted out of the round loop: see ATL)
+    const long long t_cur = *t_home;
+    if (lane == 0) {
+      *U_home = pick2(ct.U_slot, ct.prop_slot);
+      *nleap_home += ct.nleap;
+      *t_home = t_cur + 1;
+      if (COLD(double, 10)) COLD(double, 10)[(size_t)t_cur * a.C + c] = ct.acc_prob;
+      if (COLD(int, 11)) COLD(int, 11)[(size_t)t_cur * a.C + c] = ct.out_div;
+    }
+    if (COLD(double, 9)) {
+      double *dst = COLD(double, 9) + ((size_t)t_cur * a.C + c) * D;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (ok[r]) dst[lc + 64 * r] = ATL(COLD(double, 0), r);
+    }
+    phase = t_cur + 1 < m.T ? PH_DRAW : PH_DONE;
+  };
+
+  if (phase == PH_WAIT) draw_z();
+  tm.tick(7);
+  bool first = true;  // the launch's first round: every chain begins, and w = imm dU/dq has to be formed
+  // ---- one round: a leapfrog of every running chain (first stages | P r | imm g' | last stage + bookkeeping), the
+  //      beginning of the next transition of the waiting ones when enough of them wait ----
+  for (;;) {
+    if (phase == PH_RUN) stage12();
+    tm.tick(5);
+    if (lane == 0) blk_status[wave] = phase;
+    __syncthreads();
+    unsigned runmask = 0, waitmask = 0, drawmask = 0;
+#pragma unroll
+    for (int k = 0; k < BLK_CHAINS; k++) {
+      const int sk = blk_status[k];
+      runmask |= (sk == PH_RUN ? 1u : 0u) << k;
+      waitmask |= (sk == PH_WAIT ? 1u : 0u) << k;
+      drawmask |= (sk == PH_DRAW ? 1u : 0u) << k;
+    }
+    runmask = __builtin_amdgcn_readfirstlane(runmask);
+    waitmask = __builtin_amdgcn_readfirstlane(waitmask);
+    drawmask = __builtin_amdgcn_readfirstlane(drawmask);
+    tm.tick(6);  // vote (waits for the slowest chain's bookkeeping)
+    if (!(runmask | waitmask | drawmask)) break;
+    const int nrun = __popc(runmask), nwait = __popc(waitmask);
+    const int quarter = (nrun + nwait) / 4;  // (towards the end of the launch few chains are left to wait for)
+    const int need = roll >= BLK_CHAINS ? BLK_CHAINS + 1 : (roll < quarter ? roll : (quarter > 1 ? quarter : 1));
+    // rows that begin a transition in this round (nothing running: all that wait, once the last normals are drawn)
+    const unsigned bmask = (nwait >= need || (nrun == 0 && drawmask == 0)) ? waitmask : 0u;
+    const bool beginning = (bmask >> wave) & 1u;
+    if (!(runmask | bmask)) {
+      // (the workgroup's last trees have just ended: their chains draw below, the round has no products)
+      __syncthreads();  // (blk_status is rewritten at the head of the next round)
+    } else if (TDENSE) {
+      if (bmask) blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb, bmask);  // p = L^-T z (metrics.py:66-67)
+      if (runmask) blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb, runmask);   // dU/dq' = P r
+      tm.tick(2);
+      __syncthreads();
+      tm.tick(3);
+      if (__builtin_expect(beginning, 0)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) p[r] = ok[r] ? yrow[EI(r)] : 0.0;
+      }
+      blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb, runmask | bmask);          // w' = imm dU/dq' | v = imm p
+      tm.tick(2);
+      __syncthreads();
+      tm.tick(3);
+      if (__builtin_expect(beginning, 0)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = ok[r] ? xrow[EI(r)] : 0.0;
+      }
+    } else {
+      if (bmask) blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb, bmask);  // p = L^-T z
+      if (runmask) blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb, runmask);    // w' = imm dU/dq'
+      tm.tick(2);
+      __syncthreads();
+      tm.tick(3);
+      if (__builtin_expect(beginning, 0)) {  // p becomes the operand row of v = imm p
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          p[r] = ok[r] ? yrow[EI(r)] : 0.0;
+          if (ok[r]) xrow[EI(r)] = p[r];
+        }
+      }
+    }
+    if (phase == PH_RUN) {  // (one call site: the bookkeeping is inlined once)
+      book();
+      tm.tick(4);
+    }
+    if (!TDENSE && __builtin_expect(bmask != 0, 0)) {  // (the running chains' bookkeeping above filled the wait)
+      __syncthreads();
+      blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb, bmask);  // v = imm p
+      tm.tick(2);
+      __syncthreads();
+      tm.tick(3);
+      if (beginning) {
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = ok[r] ? yrow[EI(r)] : 0.0;
+      }
+    }
+    if (__builtin_expect(beginning, 0)) {  // the state the transition starts from: position, dU/dq -> its row, w -> its row
+      const int s_acc = ct.prop_slot;
+      const int lc = blk_opaque(lane) & 63;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        q[r] = ok[r] ? ATL(COLD(double, 0), r) : 0.0;
+        if (ok[r]) {
+          grow[EI(r)] = ATL(COLD(double, 1), r);
+          if (!first) wrow[EI(r)] = ATL(W_SLOT_W(s_acc), r);
+        }
+      }
+    }
+    if (__builtin_expect(first, 0)) {  // w = imm dU/dq (grow's buffer -> wrow's buffer)
+      __syncthreads();
+      if (TDENSE) blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb, bmask);
+      else blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb, bmask);
+      __syncthreads();
+      tm.tick(2);
+    }
+    if (__builtin_expect(phase == PH_DRAW, 0)) {
+      draw_z();
+      phase = PH_WAIT;
+      tm.tick(7);
+    } else if (__builtin_expect(phase == PH_RUN && ct.done, 0)) {
+      end_transition();
+      tm.tick(7);
+    } else if (__builtin_expect(beginning, 0)) {
+      init_tree();
+      phase = PH_RUN;
+      tm.tick(7);
+    }
+    first = false;
+  }
+  if (valid) {
+    ChainRng rng1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) rng1.g[k] = blk_gen_load(park, k);
+    rng_store(a, c, lane, rng1, 0, 3);
+    if (lane == 0 && m.nleap_total) m.nleap_total[c] = *nleap_home;
+#ifdef AEHMC_WIDE_TIMING
+    if (lane == 0)
+      for (int k = 0; k < 8; k++) a.linreg_part[c * 8 + k] = (double)tm.acc[k];
+#endif
+  }
+  (void)elem;
+#undef EI
+#undef AT
+#undef ATL
+#undef COLD
+#undef WSV
+#undef W_END_Q
+#undef W_END_P
+#undef W_END_G
+#undef W_SLOT_Q
+#undef W_SLOT_P
+#undef W_SLOT_G
+#undef W_PSUM
+#undef W_END_V
+#undef W_END_W
+#undef W_SLOT_W
+}
+
+// k_nuts_block_roll addresses the work vectors as cur_q + k * (cur_p - cur_q) (engine.hip ws_layout)
+inline bool blk_roll_layout_ok(const EngineArgs &a) {
+  const ptrdiff_t s = a.cur_p - a.cur_q;
+  const ptrdiff_t E = a.max_exp, md = 20 + 2 * E;
+  auto at = [&](const double *p, ptrdiff_t k) { return p == a.cur_q + k * s; };
+  bool ok = s > 0 && at(a.psum, 15) && at(a.ckp, 17) && at(a.cur_v, md) && at(a.ckv, md + 3) && at(a.cur_w, md + 3 + E);
+  for (int e = 0; e < 2; e++)
+    ok = ok && at(a.end_q[e], 3 + 3 * e) && at(a.end_p[e], 4 + 3 * e) && at(a.end_g[e], 5 + 3 * e) &&
+         at(a.slot_q[e], 9 + 3 * e) && at(a.slot_p[e], 10 + 3 * e) && at(a.slot_g[e], 11 + 3 * e) &&
+         at(a.end_v[e], md + 1 + e) && at(a.end_w[e], md + 4 + E + e);
+  return ok;
+}
+template <int R>
+inline hipError_t launch_nuts_block_roll_r(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
+  const size_t dyn = blk_reg_lds_bytes(a.D);
+  const dim3 grid((unsigned)((a.C + BLK_CHAINS - 1) / BLK_CHAINS)), block(BLK_THREADS);
+#define AEHMC_BLK(TDV)                                                                                       \
+  do {                                                                                                       \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_nuts_block_roll<R, TDV>),           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                \
+    if (e != hipSuccess) return e;                                                                           \
+    hipLaunchKernelGGL((k_nuts_block_roll<R, TDV>), grid, block, dyn, st, a, m);                             \
+  } while (0)
+  if (a.tkind == AEHMC_T_DENSE_MVN) AEHMC_BLK(true);
+  else AEHMC_BLK(false);
+#undef AEHMC_BLK
+  return hipGetLastError();
+}
+// does a call of m.T transitions at this D go to the rolling kernel?  roll: option "block_roll"
+inline bool block_roll_wanted(long long D, long long T, int roll) {
+  if (T <= 1 || roll >= BLK_CHAINS || !block_reg_supported(D)) return false;
+  return roll > 0 || D > 128;
+}
+inline hipError_t launch_nuts_block_roll(EngineArgs a, NutsSampleArgs m, double *bp, hipStream_t st) {
+  if (!blk_roll_layout_ok(a)) return hipErrorInvalidValue;
+  BlkMats mats;
+  if (hipError_t e = blk_pack_matrices(a, m.prec, bp, mats, st)) return e;
+  a.imm = mats.imm; a.sqrt_mass = mats.sqrt_mass; m.prec = mats.prec;
+  return a.D <= 128 ? launch_nuts_block_roll_r<2>(a, m, st) : launch_nuts_block_roll_r<4>(a, m, st);
+}
+
+}  // namespace aehmc

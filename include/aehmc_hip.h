@@ -185,6 +185,13 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   products on fp64 MFMA inside the workgroup, same k-order as the chain-batched GEMM (bitwise
  *                   the lock-step path's results).  1: the chains' moving state in registers up to D = 256, in
  *                   L2-resident work rows above; 2: work rows at every D; 0 = the lock-step path
+ *  "block_roll" 0   block-resident NUTS with the state in registers, launches of several transitions: a chain whose
+ *                   tree has ended begins its next transition as soon as this many chains of its workgroup wait
+ *                   (one more in-workgroup product in that round: csrc/nuts_block_roll.cuh) instead of waiting for
+ *                   the deepest of the 16 trees.  0 = rolling with the kernel's threshold (3 with a dense-precision
+ *                   target, 4 otherwise) for D > 128, all chains of a workgroup transition by transition below;
+ *                   1 ... 15 = rolling at every D with this threshold; 16 = never.  Results do not depend on it
+ *                   (bitwise)
  *  "fp_contract" 0  1: fast arithmetic in the leapfrog bodies of the register-resident HMC kernels
  *                   (diagonal / scalar metric, coordinate-wise target): every a*b+c one fused multiply-add,
  *                   eps*imm and 1/sigma^2 formed once, the half kicks between consecutive leapfrogs of a

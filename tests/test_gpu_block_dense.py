@@ -182,6 +182,52 @@ def test_block_dense_sample_equals_repeated_steps(eng, sampler, mode):
                        kern2._nuts["holder"]["rng"] if sampler == "nuts" else kern2._hmc["holder"]["rng"])
 
 
+@pytest.mark.parametrize("tkind,D,C,T", [("dense", 200, 37, 9), ("diag", 130, 16, 7), ("dense", 70, 5, 12), ("std", 256, 20, 6)])
+def test_block_dense_chains_roll_on_without_changing_a_bit(eng, tkind, D, C, T):
+    """sample(T) in the register kernel: a chain whose tree has ended begins its next transition while its neighbours
+    are still in theirs ("block_roll": how many waiting chains trigger a begin round; 16 = transition by transition).
+    Every schedule gives the bits of T separate calls on the lock-step path, RNG state included."""
+    from aehmc_amd import RandomStream, nuts
+    r = np.random.default_rng(D + C)
+    tgt, _, imm = make(tkind, D, r)
+    immd, q0 = dev(imm), r.normal(size=(C, D))
+    seeds = list(range(900, 900 + C))
+    eps = 0.5 * D ** -0.25
+
+    def sample(roll):
+        eng.set_option("block_dense", 1)
+        eng.set_option("block_roll", roll)
+        try:
+            srng = RandomStream(seeds=seeds)
+            kern = nuts.new_kernel(srng, tgt, max_num_expansions=6)
+            out = kern.sample(nuts.new_state(dev(q0), tgt), eps, immd, T)
+            return out, kern._nuts["holder"]["rng"].clone()
+        finally:
+            eng.set_option("block_roll", 0)
+
+    eng.set_option("block_dense", 0)
+    srng = RandomStream(seeds=seeds)
+    kern = nuts.new_kernel(srng, tgt, max_num_expansions=6)
+    state, ref, total = nuts.new_state(dev(q0), tgt), [], torch.zeros(C, dtype=torch.int64, device="cuda")
+    for _ in range(T):
+        info, upd = kern(state, eps, immd)
+        ref.append(info)
+        total += info.n_leapfrog
+        state = info.state._replace(momentum=None)
+    ref_rng = upd[srng].clone()
+    assert len(set(int(i.n_leapfrog[0]) for i in ref)) > 1 or T < 4  # trees of different lengths: chains do drift apart
+    for roll in (0, 1, 2, 16):
+        out, rng = sample(roll)
+        samples, info, acc, div = out[:4]
+        for t in range(T):
+            assert torch.equal(samples[t], ref[t].state.position), (roll, t)
+            assert torch.equal(acc[t], ref[t].acceptance_probability), (roll, t)
+            assert torch.equal(div[t].bool(), ref[t].is_diverging.bool()), (roll, t)
+        same_bits(info, ref[-1]._replace(n_leapfrog=info.n_leapfrog))
+        assert torch.equal(info.n_leapfrog, total)
+        assert torch.equal(rng, ref_rng), roll
+
+
 def test_block_dense_is_independent_of_the_workgroup_a_chain_lands_in(eng):
     """A chain's results do not depend on which chains share its workgroup (rows of the MFMA tile are independent):
     chains 5..12 run alone (one partly filled workgroup) equal the same chains inside a 40-chain call."""

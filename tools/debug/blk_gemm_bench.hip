@@ -29,7 +29,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_bench(const double *X, const do
       const int NT = (int)((D + 15) / 16);
       double *const tb = lds + BLK_CHAINS * S + wave * BLK_TB;
       for (int nt = wave; nt < NT; nt += BLK_CHAINS)
-        blk_wave_tile(lds, S, B, NT * 16, D, nt * 16, out + c0 * D, D, 16, lane, tb);
+        blk_wave_tile(lds, S, B, NT * 16, D, nt * 16, out + c0 * D, D, 0xffffu, lane, tb);
     }
   }
   const long long t1 = (long long)__builtin_amdgcn_s_memtime();

@@ -21,29 +21,38 @@ if os.environ.get("BLOCK_DENSE"):
 kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=E)
 state = nuts.new_state(q0, tgt)
 eps = 0.3 * D ** -0.25
-for _ in range(2):
-    info, _ = kernel(state, eps, imm)
-    state = info.state._replace(momentum=None)
-torch.cuda.synchronize()
+T = int(os.environ.get("T", 1))
+if os.environ.get("BLOCK_ROLL"):
+    eng.set_option("block_roll", int(os.environ["BLOCK_ROLL"]))
 import time
-t0 = time.perf_counter()
-info, _ = kernel(state, eps, imm)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
+if T > 1:
+    out = kernel.sample(state, eps, imm, 3)
+    state = out[1].state._replace(momentum=None)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = kernel.sample(state, eps, imm, T)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / T
+    info = out[1]
+    nl = info.n_leapfrog.cpu().numpy() / T
+else:
+    for _ in range(2):
+        info, _ = kernel(state, eps, imm)
+        state = info.state._replace(momentum=None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info, _ = kernel(state, eps, imm)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nl = info.n_leapfrog.cpu().numpy()
 ws = eng._ws
 vec = ((C * D * 8) + 255) & ~255
 off = (26 + 3 * E) * vec
 tim = ws[off: off + C * 8 * 8].view(torch.float64).reshape(C, 8).cpu().numpy()
-nl = info.n_leapfrog.cpu().numpy()
 blocks = nl[: C // 16 * 16].reshape(-1, 16).max(axis=1)
 names = ["rows->LDS", "barrier A", "MFMA", "barrier B", "book", "leap12", "vote", "begin"]
 if D <= 256 and os.environ.get("BLOCK_DENSE", "1") == "1":  # the register kernel's phases
-    names = ["book: pass", "book: scal", "MFMA", "barriers", "book: rest", "stage12", "vote", "begin"]
-if os.environ.get("BLOCK_DENSE"):
-    pass
+    names = ["book: pass", "book: scal", "MFMA", "barriers", "book: rest", "stage12", "vote", "begin/end/draw"]
 tot = tim.sum(axis=1)
-print(f"D={D} C={C}: one transition {dt*1e3:.3f} ms; leapfrogs/chain mean {nl.mean():.1f} max {nl.max()}; "
-      f"per workgroup max: mean {blocks.mean():.1f}; cycles per wave total {tot.mean():.0f}")
-steps = np.repeat(blocks, 16)[: len(tot)]
+print(f"D={D} C={C} T={T}: {dt*1e3:.3f} ms per transition; leapfrogs/chain/transition mean {nl.mean():.1f}; "
+      f"ticks per wave and transition {tot.mean() / T:.0f}")
 for k, n in enumerate(names):
-    print(f"  {n:10s} {np.mean(tim[:len(steps), k] / steps):9.0f} ticks / workgroup step  {100 * tim[:, k].sum() / tot.sum():5.1f} %")
+    print(f"  {n:16s} {tim[:, k].mean() / T:10.0f} ticks / transition  {100 * tim[:, k].sum() / tot.sum():5.1f} %")

@@ -284,6 +284,13 @@ int main(int argc, char **argv) {
   REGX(4, 8, 4, true, true, true, 256)
   REGX(4, 8, 4, true, true, false, 256)
   REGX(4, 8, 1, true, true, false, 256)
+  REGX(4, 8, 6, true, true, false, 256)
+  REGX(4, 8, 8, true, true, false, 256)
+  REGX(4, 8, 8, false, false, false, 256)
+  REGX(4, 8, 4, false, false, false, 256)
+  REGX(4, 12, 4, true, true, false, 256)
+  REGX(4, 16, 4, true, true, false, 256)
+  REGX(4, 16, 4, false, false, false, 256)
   REGX(4, 16, 2, true, true, false, 256)
   REGX(4, 4, 4, true, true, false, 256)
   REGX(8, 8, 2, true, true, false, 128)
