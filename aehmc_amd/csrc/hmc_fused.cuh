@@ -64,8 +64,14 @@ inline bool hmc_fused_supported(int tkind, int met_ndim, long long D) {
 #else
 #define AEHMC_CUSTOM_ELEM(q, i, u, g) do { (u) = 0.0; (g) = 0.0; } while (0)
 #endif
+// Wavefronts per SIMD the register allocator leaves room for: 4096 chains are 4 wavefronts per SIMD.  Left alone, the
+// contracted-arithmetic variants at R = 4 take 130 / 156 VGPRs (3 wavefronts) and R = 8 174 (2); held to 4 / 3 they fit
+// 111 / 127 / 168 with nothing spilled inside the leapfrog loop (the diagonal-Gaussian variant at R = 8 would spill there
+// and is left alone).
+constexpr int hmc_fused_min_waves(int R, int TK) { return R <= 4 ? 4 : (R == 8 && TK != AEHMC_T_DIAG_GAUSSIAN ? 3 : 1); }
+
 template <int R, int TK, bool FC = false>
-__global__ __launch_bounds__(256) void k_hmc_fused(HmcFusedArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(hmc_fused_min_waves(R, TK)))) void k_hmc_fused(HmcFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) double zlds[];  // [4 waves][R*64]
   __shared__ double ztab[ZIG_LDS_DOUBLES];
   const ZigTabLds tab = zig_tab_to_lds(ztab);
