@@ -228,6 +228,58 @@ def test_block_dense_chains_roll_on_without_changing_a_bit(eng, tkind, D, C, T):
         assert torch.equal(rng, ref_rng), roll
 
 
+@pytest.mark.parametrize("case", ["diverging", "depth1", "one_chain", "per_chain_eps"])
+def test_block_dense_rolling_edge_cases_match_lockstep_bitwise(eng, case):
+    """The rolling kernel where its scheduling is stressed: chains that diverge at their first step (the scan goes on as a
+    phantom while the transition's outputs are final), trees of a single expansion (a chain begins again every other
+    round), a workgroup with one chain, one step size per chain (very different tree lengths side by side)."""
+    from aehmc_amd import PerChain, RandomStream, nuts
+    D, C, T, max_exp, scale = 160, 27, 8, 6, 0.5
+    if case == "diverging":
+        scale = 40.0      # |dH| > 1000 at the first step of most transitions
+    elif case == "depth1":
+        max_exp = 1
+    elif case == "one_chain":
+        C = 1
+    r = np.random.default_rng(len(case))
+    tgt, _, imm = make("dense", D, r)
+    immd, q0 = dev(imm), r.normal(size=(C, D))
+    seeds = list(range(40, 40 + C))
+    eps = scale * D ** -0.25
+    if case == "per_chain_eps":
+        eps = PerChain(dev(D ** -0.25 * np.exp(r.uniform(np.log(0.05), np.log(1.5), size=C))))
+
+    def run(roll, single_calls):
+        eng.set_option("block_dense", 1 if roll else 0)
+        eng.set_option("block_roll", roll)
+        try:
+            srng = RandomStream(seeds=seeds)
+            kern = nuts.new_kernel(srng, tgt, max_num_expansions=max_exp)
+            state = nuts.new_state(dev(q0), tgt)
+            if not single_calls:
+                out = kern.sample(state, eps, immd, T)
+                return out[0], out[2], out[3], out[1], kern._nuts["holder"]["rng"].clone()
+            pos, acc, div = [], [], []
+            for _ in range(T):
+                info, upd = kern(state, eps, immd)
+                pos.append(info.state.position), acc.append(info.acceptance_probability), div.append(info.is_diverging)
+                state = info.state._replace(momentum=None)
+            return torch.stack(pos), torch.stack(acc), torch.stack(div), info, upd[srng].clone()
+        finally:
+            eng.set_option("block_roll", 0)
+            eng.set_option("block_dense", 1)
+
+    ref = run(0, True)   # lock-step path, one call per transition
+    if case == "diverging":
+        assert bool(ref[2].bool().any())
+    for roll in (1, 3):
+        got = run(roll, False)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2].bool(), ref[2].bool()), roll
+        assert torch.equal(got[3].state.potential_energy, ref[3].state.potential_energy)
+        assert torch.equal(got[3].state.potential_energy_grad, ref[3].state.potential_energy_grad)
+        assert torch.equal(got[4], ref[4]), roll
+
+
 def test_block_dense_is_independent_of_the_workgroup_a_chain_lands_in(eng):
     """A chain's results do not depend on which chains share its workgroup (rows of the MFMA tile are independent):
     chains 5..12 run alone (one partly filled workgroup) equal the same chains inside a 40-chain call."""
