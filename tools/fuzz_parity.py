@@ -34,7 +34,8 @@ def one(case):
         C = min(C, 5)
     opts = {"resident_nuts": int(r.choice([0, 1, 2])), "resident_min_team": int(r.integers(0, 2)),
             "fused_hmc": int(r.integers(0, 2)), "dense_linear": int(r.integers(0, 2)), "fused_nuts": int(r.integers(0, 2)),
-            "streamk": int(r.choice([0, 1, 2])), "compact": int(r.integers(0, 2))}
+            "streamk": int(r.choice([0, 1, 2])), "compact": int(r.integers(0, 2)),
+            "block_dense": int(r.choice([0, 1, 2], p=[0.2, 0.6, 0.2])), "block_roll": int(r.choice([0, 1, 2, 5, 16]))}
     mu, sigma = r.normal(size=D), 0.5 + r.random(D)
     if tk == "linreg":
         N = int(r.choice([37, 1000, 10176, 10177, 23001]))
@@ -62,7 +63,7 @@ def one(case):
             imm = np.float64(0.5 + r.random())
         eps = float(r.choice([0.25, 0.08, 1.5])) / D ** 0.25
     thr = float(r.choice([1000.0, 5.0]))
-    max_exp, L, T = int(r.choice([10, 6, 2])), int(r.choice([0, 1, 7, 20])), int(r.choice([1, 3]))
+    max_exp, L, T = int(r.choice([10, 6, 2])), int(r.choice([0, 1, 7, 20])), int(r.choice([1, 3, 6]))
     # per-chain step sizes / diagonal metrics (what window adaptation hands back), and sample() instead of calls
     per_chain = bool((mk == "diag" and r.random() < 0.3) or (mk == "dense" and D <= 130 and r.random() < 0.25))
     use_sample = bool(T > 1 and r.random() < 0.5)
@@ -141,7 +142,7 @@ def one(case):
         assert np.array_equal(got[:, :, :2], rng[:, :, :2]), "generator state"
     finally:
         for k, v in (("resident_nuts", 2), ("resident_min_team", 0), ("fused_hmc", 1), ("dense_linear", 1), ("fused_nuts", 0),
-                     ("streamk", 2), ("compact", 1)):
+                     ("streamk", 2), ("compact", 1), ("block_dense", 1), ("block_roll", 0)):
             eng.set_option(k, v)
     return desc
 
