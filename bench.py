@@ -205,6 +205,59 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
     return out
 
 
+def dense_mid_secondary(eng, device, C=4096, T=10):
+    """Mid-size dense problems (shared dense inverse mass matrix AND dense-precision target, D = 100 and 200: the
+    block-resident kernels of csrc/nuts_block_reg.cuh / nuts_block_roll.cuh, one launch per sample(T) call).  Per leapfrog
+    and chain two D x D products on fp64 MFMA inside the workgroup = 4 D^2 flop (algorithmic, metrics.py:71 and the
+    target's P r); `achieved` = that / the call's time, against the fp64 MFMA peak; the MFMA-busy counter of the same
+    workload (profiles/r4/dense/mid200_pmc_summary.json) is quoted when it was measured on the loaded library."""
+    from aehmc_amd import RandomStream, nuts, targets
+    out = []
+    for D in (100, 200):
+        try:
+            r = np.random.default_rng(0)
+
+            def spd():
+                A = r.normal(size=(D, D))
+                M = A @ A.T / D + np.eye(D)
+                return 0.5 * (M + M.T)
+            P, imm = spd(), torch.as_tensor(spd(), device=device)
+            tgt = targets.DenseMVN(torch.zeros(D, dtype=torch.float64, device=device), torch.as_tensor(P, device=device))
+            q0 = torch.as_tensor(r.standard_normal((C, D)), device=device)
+            kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+            eps = 0.3 * D ** -0.25
+            info = kernel.sample(nuts.new_state(q0, tgt), eps, imm, 3)[1]
+            best, nl = None, 0
+            for _ in range(3):  # (the first call at a new T also allocates its [T, C, D] sample buffer)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                info = kernel.sample(info.state._replace(momentum=None), eps, imm, T)[1]
+                torch.cuda.synchronize(device)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best:
+                    best, nl = dt, int(info.n_leapfrog.sum().item())
+            tflops = nl * 4.0 * D * D / best / 1e12
+            roof = {"bound": "mfma", "unit": "TFLOP/s", "achieved": tflops, "peak": PEAK_FP64_MFMA_TFLOPS,
+                    "frac": tflops / PEAK_FP64_MFMA_TFLOPS, "kernel": "k_nuts_block_reg" if D <= 128 else "k_nuts_block_roll",
+                    "launches": 1, "avg_launch_ms": best * 1e3, "traffic": None,
+                    "note": "4 D^2 flop per leapfrog and chain; every chain of a 16-chain workgroup steps through its own "
+                            "tree, so the products of a round also carry the rows of chains that have finished"}
+            if D == 200:
+                pmc, src = pmc_summary(os.path.join("dense", "mid200_pmc_summary.json"))
+                if pmc:
+                    roof["counters"] = {"mfma_busy_fraction": pmc["derived"]["mfma_busy_fraction"],
+                                        "wait_any_fraction_of_wave_cycles": pmc["derived"]["wait_any_frac"], "source": src}
+                roof["counters_dropped"] = PMC_STALE.get(os.path.join("dense", "mid200_pmc_summary.json"))
+            out.append({"config": f"dense-nuts-d{D}",
+                        "workload": f"{D}-dim correlated MVN (dense precision), dense inverse mass matrix, NUTS depth 10, {C} chains, "
+                                    f"sample({T}) in one launch",
+                        "value": nl / best, "unit": "leapfrog-steps/s", "ms_per_transition": best / T * 1e3,
+                        "leapfrogs_per_transition": nl / T, "roofline": roof})
+        except Exception as e:  # a failing side measurement must not cost the main line
+            out.append({"config": f"dense-nuts-d{D}", "error": repr(e)[:300]})
+    return out
+
+
 def launch_ranks(n, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one process per
     GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches
@@ -475,6 +528,7 @@ def main():
         del state, info, kernel, target, imm, gathered
         torch.cuda.empty_cache()
         secondary = bench_secondary(eng, device, max(args.steps, 3), 2)
+        secondary += dense_mid_secondary(eng, device)
         secondary += other_configs()
 
     print(json.dumps({

@@ -126,19 +126,23 @@ def test_bench_c4_and_c5_two_rank_dry_runs():
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac"] < 1
 
 
-def test_bench_default_line_has_five_good_secondary_entries():
-    """The default line (c3 at full size) carries the diagonal-mass NUTS / HMC numbers and c2, c5, c1 as
-    `secondary`: none of them may have degraded into an {"error": ...} entry."""
+def test_bench_default_line_has_its_good_secondary_entries():
+    """The default line (c3 at full size) carries the diagonal-mass NUTS / HMC numbers, the mid-size dense problems and
+    c2, c5, c1 as `secondary`: none of them may have degraded into an {"error": ...} entry."""
     d = _run("--steps", "2", "--no-cpu-baseline")
     assert all(k in d for k in REQUIRED) and d["roofline"]["bound"] == "mfma"
     assert d["config"]["dim"] == 10_000 and d["config"]["chains_total"] == 4096
     sec = d["secondary"]
-    assert [e["config"] for e in sec] == ["diag-nuts", "diag-hmc", "diag-hmc-fp_contract", "c2", "c2-fp_contract", "c5", "c1"]
+    assert [e["config"] for e in sec] == ["diag-nuts", "diag-hmc", "diag-hmc-fp_contract", "dense-nuts-d100", "dense-nuts-d200",
+                                          "c2", "c2-fp_contract", "c5", "c1"]
     for e in sec:
         assert "error" not in e and e["value"] > 0, e
     by = {e["config"]: e for e in sec}
     assert by["c5"]["roofline"]["bound"] == "valu" and by["c2"]["roofline"]["bound"] == "valu"
     assert by["c1"]["roofline"]["bound"] == "latency"
+    for k in ("dense-nuts-d100", "dense-nuts-d200"):  # block-resident kernels: one launch per sample() call
+        r = by[k]["roofline"]
+        assert r["bound"] == "mfma" and r["launches"] == 1 and 0 < r["frac"] < 1 and by[k]["ms_per_transition"] < 1.5
     # the fast-arithmetic mode is faster where the leapfrog loop dominates, and says that it is not the bit-exact mode
     assert by["diag-hmc-fp_contract"]["value"] > 1.15 * by["diag-hmc"]["value"]
     assert "fp_contract=1" in by["c2-fp_contract"]["workload"] and "fp_contract" not in by["c2"]["workload"]
