@@ -3,7 +3,7 @@
 # (no trace domains mixed in), the program directly after `--`.  Run through gpurun from the repo root with the FINAL
 # libaehmc_hip.so; profiles/summarize_r4.py folds the outputs into profiles/r4/*_pmc_summary.json, each stamped with the
 # sha256 of the library it measured (bench.py drops counter-derived figures whose stamp is not the loaded library's).
-# usage: run_r4.sh <tag> [<tag> ...]   tags: c1 c2 c2_fc c3 c5 diag_nuts diag_hmc diag_hmc_fc mid200
+# usage: run_r4.sh <tag> [<tag> ...]   tags: c1 c2 c2_fc c3 c5 diag_nuts diag_hmc diag_hmc_fc mid200 mid100
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS|SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES|SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64|GRBM_GUI_ACTIVE"
@@ -20,6 +20,7 @@ for tag in "$@"; do
     diag_hmc) CMD="python3 $R/tools/diag_run.py hmc 2" ;;
     diag_hmc_fc) CMD="python3 $R/tools/diag_run.py hmc 2 10000 4096 1" ;;
     mid200) CMD="python3 $R/tools/debug/mid_dense.py 200 4096 10"; groups="$groups|SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR|SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" ;;
+    mid100) CMD="python3 $R/tools/debug/mid_dense.py 100 4096 10"; groups="$groups|SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR|SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" ;;
     *) echo "unknown tag $tag"; continue ;;
   esac
   O=$R/gpurun_out/r4_$tag
