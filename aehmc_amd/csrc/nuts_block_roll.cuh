@@ -7,8 +7,9 @@
 // a round in which chains begin carries one more product (p = L^-T z).  Same stage / bookkeeping arithmetic as
 // k_nuts_block_reg, chain by chain: the results do not depend on the schedule, bit for bit (tests/test_gpu_block_dense.py).
 // Measured (profiles/r4/INDEX.md): rounds per transition 27.2 -> 21.2, products -13 %; what of that is left after the
-// compiler's handling of the larger loop body is 3-4 % at D = 200 and a loss below D = 128, so the engine uses this
-// kernel for D > 128 and launches of more than one transition (option "block_roll").
+// compiler's handling of the larger loop body is 3-5 % at D = 200 - 256 and a loss below D ~ 190 (short products: the extra
+// product of a begin round and the exposed first K-tile weigh more), so the engine uses this kernel for D >= 192 and
+// launches of more than one transition (option "block_roll").
 // Reference: nuts.py:56-153, trajectory.py:154-374,428-714, termination.py:85-235, proposals.py:19-174,
 // integrators.py:54-73, metrics.py:44-104.
 #pragma once
@@ -669,10 +670,13 @@ inline hipError_t launch_nuts_block_roll_r(const EngineArgs &a, const NutsSample
 #undef AEHMC_BLK
   return hipGetLastError();
 }
-// does a call of m.T transitions at this D go to the rolling kernel?  roll: option "block_roll"
+// does a call of m.T transitions at this D go to the rolling kernel?  roll: option "block_roll".  Measured, 4096 chains,
+// sample(10), rolling against transition by transition: D = 130 0.448 / 0.404 ms, 150 0.482 / 0.436, 180 0.589 / 0.572,
+// 200 0.692 / 0.726, 256 0.973 / 1.001
+constexpr long long BLK_ROLL_MIN_D = 192;
 inline bool block_roll_wanted(long long D, long long T, int roll) {
   if (T <= 1 || roll >= BLK_CHAINS || !block_reg_supported(D)) return false;
-  return roll > 0 || D > 128;
+  return roll > 0 || D >= BLK_ROLL_MIN_D;
 }
 inline hipError_t launch_nuts_block_roll(EngineArgs a, NutsSampleArgs m, double *bp, hipStream_t st) {
   if (!blk_roll_layout_ok(a)) return hipErrorInvalidValue;

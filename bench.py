@@ -238,7 +238,7 @@ def dense_mid_secondary(eng, device, C=4096, T=10):
                     best, nl = dt, int(info.n_leapfrog.sum().item())
             tflops = nl * 4.0 * D * D / best / 1e12
             roof = {"bound": "mfma", "unit": "TFLOP/s", "achieved": tflops, "peak": PEAK_FP64_MFMA_TFLOPS,
-                    "frac": tflops / PEAK_FP64_MFMA_TFLOPS, "kernel": "k_nuts_block_reg" if D <= 128 else "k_nuts_block_roll",
+                    "frac": tflops / PEAK_FP64_MFMA_TFLOPS, "kernel": "k_nuts_block_reg" if D < 192 else "k_nuts_block_roll",
                     "launches": 1, "avg_launch_ms": best * 1e3, "traffic": None,
                     "note": "4 D^2 flop per leapfrog and chain; every chain of a 16-chain workgroup steps through its own "
                             "tree, so the products of a round also carry the rows of chains that have finished"}

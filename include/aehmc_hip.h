@@ -189,7 +189,7 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   tree has ended begins its next transition as soon as this many chains of its workgroup wait
  *                   (one more in-workgroup product in that round: csrc/nuts_block_roll.cuh) instead of waiting for
  *                   the deepest of the 16 trees.  0 = rolling with the kernel's threshold (3 with a dense-precision
- *                   target, 4 otherwise) for D > 128, all chains of a workgroup transition by transition below;
+ *                   target, 4 otherwise) for D >= 192, all chains of a workgroup transition by transition below;
  *                   1 ... 15 = rolling at every D with this threshold; 16 = never.  Results do not depend on it
  *                   (bitwise)
  *  "fp_contract" 0  1: fast arithmetic in the leapfrog bodies of the register-resident HMC kernels
