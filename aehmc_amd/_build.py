@@ -54,13 +54,29 @@ def is_current() -> bool:
     return os.path.exists(LIB) and stamped_hash() == source_hash()
 
 
+def write_stamp() -> None:
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
+
+
 def build(force: bool = False, quiet: bool = True) -> bool:
-    """Compile the library unless the stamped source hash equals the tree's.  Returns True if it compiled."""
+    """Compile the library unless the stamped source hash equals the tree's.  Returns True if it compiled.
+    (`make` itself stamps the library -- csrc/Makefile runs `_build.py --stamp` after linking -- so a plain
+    `make -C aehmc_amd/csrc -j8` gives a loadable library too.)"""
     want = source_hash()
     if not force and os.path.exists(LIB) and stamped_hash() == want:
         return False
-    cmd = ["make", "-C", CSRC, "-B"] + (["-s"] if quiet else [])
+    jobs = str(min(8, os.cpu_count() or 1))
+    # -B: the decision to compile was taken on content; make's file times must not overrule it
+    cmd = ["make", "-C", CSRC, "-B", "-j", jobs] + (["-s"] if quiet else [])
     subprocess.check_call(cmd)
-    with open(STAMP, "w") as f:
-        f.write(want + "\n")
+    write_stamp()
     return True
+
+
+if __name__ == "__main__":
+    import sys
+    if "--stamp" in sys.argv:
+        write_stamp()
+    else:
+        print("compiled" if build(force="--force" in sys.argv, quiet=False) else "up to date")

@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void k_nuts_init(EngineArgs a) {
   rng_store(a, c, lane, rng, 1, 1);
   if (lane == 0) a.ctl[c] = ct;
 }
-__global__ __launch_bounds__(256) void k_nuts_begin_diag(EngineArgs a) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_nuts_begin_diag(EngineArgs a) {
   AEHMC_CHAIN_OF_WAVE();
   ChainRng rng = rng_load(a, c);
   ChainCtl ct;
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void k_nuts_begin_diag(EngineArgs a) {
 // target): the wave that owns the chain loops leapfrog + bookkeeping until its tree is
 // done; chains of different depth simply retire at different times.  Same device
 // functions, hence same bits, as the lock-step path.
-__global__ __launch_bounds__(256) void k_nuts_fused(EngineArgs a) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_nuts_fused(EngineArgs a) {
   AEHMC_CHAIN_OF_WAVE();
   ChainRng rng = rng_load(a, c);
   ChainCtl ct;
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256) void k_step_linear(EngineArgs a) {
 // ascending list of live chains + count (one 1024-thread block; deterministic order).  Runs after every lock-step
 // of a dense problem: thread t owns a contiguous run of chains, reads their flags ONCE (loads in flight together,
 // kept as a bit mask), ranks itself with a shuffle scan inside its wavefront and the 16 wavefront totals.
-__global__ __launch_bounds__(1024) void k_compact(const ChainCtl *ctl, long long C, int *row_idx,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(1024) void k_compact(const ChainCtl *ctl, long long C, int *row_idx,
                                                   int *n_rows, int *host_slot) {
   __shared__ int wsum[16];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(1024) void k_compact(const ChainCtl *ctl, long long
   }
 }
 
-__global__ void k_count_active(const ChainCtl *ctl, long long C, int *out) {
+AEHMC_TU_LOCAL __global__ void k_count_active(const ChainCtl *ctl, long long C, int *out) {
   __shared__ int s;
   if (threadIdx.x == 0) s = 0;
   __syncthreads();
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_hmc_init(EngineArgs a) {
   AEHMC_CHAIN_OF_WAVE();
   hmc_init_chain<MET_DENSE>(a, c, lane);
 }
-__global__ __launch_bounds__(256) void k_hmc_begin_diag(EngineArgs a) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_hmc_begin_diag(EngineArgs a) {
   AEHMC_CHAIN_OF_WAVE();
   ChainRng rng = rng_load(a, c);
   draw_momentum<false>(a, c, lane, rng.g[0]);
@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArg
 }
 
 // ---- new_state / stand-alone building blocks --------------------------------------
-__global__ __launch_bounds__(256) void k_new_state_elem(EngineArgs a) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_new_state_elem(EngineArgs a) {
   AEHMC_CHAIN_OF_WAVE();
   const size_t row = (size_t)c * a.D;
   double usum = 0.0;
@@ -1190,12 +1190,12 @@ __global__ __launch_bounds__(256) void k_new_state_elem(EngineArgs a) {
   usum = wave_sum(usum);
   if (lane == 0) a.U[c] = target_finish(a, usum);
 }
-__global__ __launch_bounds__(256) void k_residual(EngineArgs a, const double *q, double *r) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_residual(EngineArgs a, const double *q, double *r) {
   AEHMC_CHAIN_OF_WAVE();
   const size_t row = (size_t)c * a.D;
   for (long long i = lane; i < a.D; i += 64) r[row + i] = q[row + i] - a.mu[i];
 }
-__global__ __launch_bounds__(256) void k_half_dot(EngineArgs a, const double *x, const double *y,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_half_dot(EngineArgs a, const double *x, const double *y,
                                                   double *out) {
   AEHMC_CHAIN_OF_WAVE();
   const size_t row = (size_t)c * a.D;
@@ -1204,12 +1204,12 @@ __global__ __launch_bounds__(256) void k_half_dot(EngineArgs a, const double *x,
   s = wave_sum(s);
   if (lane == 0) out[c] = 0.5 * s;
 }
-__global__ __launch_bounds__(256) void k_vel_diag(EngineArgs a, const double *p, double *v) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_vel_diag(EngineArgs a, const double *p, double *v) {
   AEHMC_CHAIN_OF_WAVE();
   const size_t row = (size_t)c * a.D;
   for (long long i = lane; i < a.D; i += 64) v[row + i] = vel_diag(a, c, i, p[row + i]);
 }
-__global__ __launch_bounds__(256) void k_is_turning(EngineArgs a, const double *pl, const double *pr,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_is_turning(EngineArgs a, const double *pl, const double *pr,
                                                     const double *ps, const double *vl,
                                                     const double *vr, int32_t *out) {
   AEHMC_CHAIN_OF_WAVE();
@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_is_turning(EngineArgs a, const double *
 // (deterministic).  to_ctl: write U into ctl[c].U_cur (leapfrog) or into U[c] (new_state).
 constexpr int LINREG_CPB = 8;
 // stage 1: workgroup (g, s) sums row slice s for the 8 chains of group g -> part[g][s][16]
-__global__ __launch_bounds__(256) void k_target_linreg(EngineArgs a, const double *q, double *part,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_target_linreg(EngineArgs a, const double *q, double *part,
                                                        int S, int to_ctl) {
   __shared__ double red[4][2 * LINREG_CPB];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(256) void k_target_linreg(EngineArgs a, const doubl
 }
 // stage 2: one thread per chain adds the S slice sums in order and forms U and dU/dq
 // (examples/LinearRegression.ipynb:126-166, q = [w, log n]).  to_ctl: U -> ctl[c].U_cur.
-__global__ __launch_bounds__(256) void k_linreg_finish(EngineArgs a, const double *q, double *g, double *U,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_linreg_finish(EngineArgs a, const double *q, double *g, double *U,
                                                        const double *part, int S, int to_ctl) {
   const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= a.C || (to_ctl && a.ctl[c].done)) return;
@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(256) void k_linreg_finish(EngineArgs a, const doubl
 }
 
 // leapfrog-only driver state: ctl.dir = 1, U in ctl
-__global__ __launch_bounds__(256) void k_ctl_set(EngineArgs a, const double *U) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_ctl_set(EngineArgs a, const double *U) {
   AEHMC_CHAIN_OF_WAVE();
   if (lane == 0) {
     ChainCtl ct = {};
@@ -1318,11 +1318,11 @@ __global__ __launch_bounds__(256) void k_ctl_set(EngineArgs a, const double *U) 
     a.ctl[c] = ct;
   }
 }
-__global__ __launch_bounds__(256) void k_ctl_get_U(EngineArgs a, double *U) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_ctl_get_U(EngineArgs a, double *U) {
   AEHMC_CHAIN_OF_WAVE();
   if (lane == 0) U[c] = a.ctl[c].U_cur;
 }
-__global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C, long long n,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C, long long n,
                                                      double *out) {
   __shared__ double ztab[ZIG_LDS_DOUBLES];
   const ZigTabLds tab = zig_tab_to_lds(ztab);
@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(256) void k_rng_normals(uint64_t *rng, long long C,
 // while the other waves of the workgroup wait.
 // Rows of zbuf are `ld` >= D apart; [D, ld) is filled with zeros.  nt > 1: the momenta of nt consecutive
 // transitions (the stream of site #1 serves nothing else), transition tt in zbuf[tt][C][ld].
-__global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites, long long C, long long D,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites, long long C, long long D,
                                                        const double *sqrt_mass, long long sm_cs, int met_ndim,
                                                        double *zbuf, long long ld, int nt) {
   __shared__ double ztab[ZIG_LDS_DOUBLES];
@@ -1357,7 +1357,7 @@ __global__ __launch_bounds__(256) void k_draw_momentum(uint64_t *rng, int nsites
   }
   if ((threadIdx.x & 63) == 0) pcg_store(gs, g);
 }
-__global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long C, long long n,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long C, long long n,
                                                        const double *p, int32_t *out) {
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(256) void k_rng_bernoulli(uint64_t *rng, long long 
 constexpr int AEHMC_PC_LDS_MAX_D = 64;
 constexpr int AEHMC_PC_DENSE_MAX_D = 2048;  // (one wavefront factors a chain's matrix; tested up to D = 1024: tests/test_gpu_adaptation.py)
 // out[c, i] = sum_j mats[c, i, j] x[c, j]  (j ascending); one wavefront per (live) chain
-__global__ __launch_bounds__(256) void k_matvec_pc(const double *mats, const double *x, double *out, long long C,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_matvec_pc(const double *mats, const double *x, double *out, long long C,
                                                    long long D, const int *row_idx, const int *n_rows) {
   const int lane = threadIdx.x & 63;
   const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_matvec_pc(const double *mats, const dou
 // The same product for D > 64: workgroup (x, w) forms 64 rows of chain w's product, one row per
 // wave at a time with the 64 lanes striding over the columns (coalesced reads of the matrix row)
 // and a wave sum per row.
-__global__ __launch_bounds__(256) void k_matvec_pc_rows(const double *mats, const double *x, double *out,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_matvec_pc_rows(const double *mats, const double *x, double *out,
                                                         long long C, long long D, const int *row_idx,
                                                         const int *n_rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1447,7 +1447,7 @@ __device__ inline bool wave_chol_inv_t(double *A, double *S, int D, int lane) {
   return ok;
 }
 // sqrt_mass[c] = chol(imm[c])^-T for every chain; *err = 1 if a matrix is not positive definite
-__global__ __launch_bounds__(64) void k_chol_inv_pc(const double *imm, double *sqrt_mass, long long C, int D,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(64) void k_chol_inv_pc(const double *imm, double *sqrt_mass, long long C, int D,
                                                      int *err, double *work) {
   extern __shared__ __attribute__((aligned(16))) double pc_lds[];  // D <= 64: A [D*D], S [D*D]
   const int lane = threadIdx.x;
@@ -1517,7 +1517,7 @@ __device__ __forceinline__ void adapt_window_end_elem(long long n, double &mean,
   m2 = 0.0;
 }
 
-__global__ __launch_bounds__(256) void k_adapt_init(AdaptArgs a, double initial_step_size) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_adapt_init(AdaptArgs a, double initial_step_size) {
   const int lane = threadIdx.x & 63;
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= a.C) return;
@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(256) void k_adapt_init(AdaptArgs a, double initial_
     a.s.step_size[c] = exp(0.0);
   }
 }
-__global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
   const int lane = threadIdx.x & 63;
   const long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= a.C) return;
@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(256) void k_adapt_update(AdaptArgs a) {
 
 // step_size.dual_averaging_adaptation's update alone (step_size.py:97-98, algorithms.py:104-115), one
 // thread per chain: the arithmetic of adapt_da_update, hence the bits of the warm-up kernels
-__global__ __launch_bounds__(256) void k_dual_averaging(long long C, double target, double gamma, double t0,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_dual_averaging(long long C, double target, double gamma, double t0,
                                                          double kappa, const double *p_accept, long long *step,
                                                          double *x, double *x_avg, double *g_avg, const double *mu,
                                                          double *step_size_out) {
@@ -1661,7 +1661,7 @@ __global__ __launch_bounds__(256) void k_dual_averaging(long long C, double targ
 // algorithms.welford_covariance's update for C independent estimators, one wavefront each: the arithmetic of
 // adapt_welford_elem / k_adapt_update's full branch, hence the bits of the warm-up kernels.  full: m2 is [C,D,D] and
 // grows by outer(updated_delta, delta) (LDS: delta [D], updated delta [D]).
-__global__ __launch_bounds__(64) void k_welford_update(long long C, long long D, int full, const double *value,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(64) void k_welford_update(long long C, long long D, int full, const double *value,
                                                         double *mean, double *m2, long long *n_arr) {
   extern __shared__ __attribute__((aligned(16))) double wf_lds[];
   const int lane = threadIdx.x;
@@ -1697,7 +1697,7 @@ __global__ __launch_bounds__(64) void k_welford_update(long long C, long long D,
 // welford_covariance's final (algorithms.py:199-202: m2 / (n - 1)) and, with `shrink`, covariance_adaptation's final
 // (mass_matrix.py:83-118: Stan's shrinkage towards 1e-3 -- on every element of a diagonal estimate, on the diagonal
 // of a full one), one thread per element; the expressions of adapt_window_end_elem
-__global__ __launch_bounds__(256) void k_covariance_final(long long C, long long per, long long D, int full, int shrink,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_covariance_final(long long C, long long per, long long D, int full, int shrink,
                                                            const double *m2, const long long *n_arr, double *out) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= C * per) return;
@@ -1713,16 +1713,16 @@ __global__ __launch_bounds__(256) void k_covariance_final(long long C, long long
   out[e] = r;
 }
 
-__global__ __launch_bounds__(256) void k_fill_i64(long long *x, long long n, long long v) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_fill_i64(long long *x, long long n, long long v) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i < n; i += (long long)gridDim.x * blockDim.x) x[i] = v;
 }
-__global__ __launch_bounds__(256) void k_add_i64(long long *acc, const long long *x, long long n) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_add_i64(long long *acc, const long long *x, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (; i < n; i += (long long)gridDim.x * blockDim.x) acc[i] += x[i];
 }
 // ---- gaussian_metric set-up (metrics.py:44-59): sqrt(1/imm), or L^-T with imm = L L^T ----
-__global__ void k_sqrt_recip(const double *x, double *y, long long n) {
+AEHMC_TU_LOCAL __global__ void k_sqrt_recip(const double *x, double *y, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = sqrt(1.0 / x[i]);
 }
@@ -1730,7 +1730,7 @@ constexpr int FACT_NB = 64;
 // One workgroup: (optionally) Cholesky-factor the n x n (n <= 64) diagonal block in place
 // (lower), then invert the lower-triangular factor; writes inv and inv^T, zero padded to
 // [64][64].  info: first non-positive pivot (1-based, global index) if any.
-__global__ __launch_bounds__(256) void k_potrf_trtri(double *A, long long ld, int n, int do_factor,
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_potrf_trtri(double *A, long long ld, int n, int do_factor,
                                                      double *inv, double *invT, int *info, int pivot_base) {
   __shared__ double L[FACT_NB][FACT_NB + 1], X[FACT_NB][FACT_NB + 1];
   const int tid = threadIdx.x;
@@ -1777,13 +1777,13 @@ __global__ __launch_bounds__(256) void k_potrf_trtri(double *A, long long ld, in
     invT[e] = X[j][i];
   }
 }
-__global__ void k_copy_block(const double *src, long long lds_, double *dst, long long ldd, int rows, int cols) {
+AEHMC_TU_LOCAL __global__ void k_copy_block(const double *src, long long lds_, double *dst, long long ldd, int rows, int cols) {
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows * cols; e += gridDim.x * blockDim.x) {
     const int i = e / cols, j = e % cols;
     dst[(long long)i * ldd + j] = src[(long long)i * lds_ + j];
   }
 }
-__global__ void k_transpose(const double *src, double *dst, long long n) {  // dst = src^T, n x n
+AEHMC_TU_LOCAL __global__ void k_transpose(const double *src, double *dst, long long n) {  // dst = src^T, n x n
   __shared__ double tile[32][33];
   const long long bx = (long long)blockIdx.x * 32, by = (long long)blockIdx.y * 32;
   for (int r = threadIdx.y; r < 32; r += blockDim.y) {
@@ -1796,7 +1796,7 @@ __global__ void k_transpose(const double *src, double *dst, long long n) {  // d
     if (i < n && j < n) dst[i * n + j] = tile[threadIdx.x][r];
   }
 }
-__global__ void k_log(const double *x, double *y, long long n) {
+AEHMC_TU_LOCAL __global__ void k_log(const double *x, double *y, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = log(x[i]);
 }

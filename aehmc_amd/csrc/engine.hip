@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/aehmc_hip.h"
+#include "tu.h"
 #include "engine.cuh"
 #include "gemm_f64.cuh"
 #include "hmc_fused.cuh"
@@ -23,6 +24,10 @@
 #include "nuts_wide.cuh"
 
 using namespace aehmc;
+
+#ifndef AEHMC_GPU_ARCH
+#define AEHMC_GPU_ARCH "gfx950"  /* csrc/Makefile passes its ARCH */
+#endif
 
 namespace {
 constexpr int NRING = 4;       // pinned "chains still active" slots
@@ -95,7 +100,6 @@ struct aehmc_ctx {
   double *glm_XT = nullptr, *glm_z = nullptr, *glm_lsum = nullptr;
   int64_t glm_N = 0;
   size_t glm_z_bytes = 0, glm_lsum_bytes = 0;
-  uint64_t pcg_jump[64][4] = {};  // the LCG jump-ahead table (every code object has its own __constant__ copy)
   struct RtcProgram {
     hipModule_t mod = nullptr;
     std::map<std::string, hipFunction_t> fn;
@@ -143,21 +147,6 @@ extern "C" int aehmc_create(aehmc_ctx **out, int device) {
   ctx->device = device;
   *out = ctx;
   HIPCHK(hipSetDevice(device));
-  // LCG jump-ahead table: state_{t+n} = A^n state_t + G_n inc  (rng.cuh)
-  uint64_t jump[64][4];
-  typedef unsigned __int128 host_u128;
-  const host_u128 mult = (((host_u128)AEHMC_PCG_MULT_HI) << 64) | (host_u128)AEHMC_PCG_MULT_LO;
-  host_u128 A = 1, G = 0;
-  for (int k = 0; k < 64; k++) {
-    G = G * mult + 1;  // G_{k+1} = A * G_k + 1
-    A = A * mult;
-    jump[k][0] = (uint64_t)(A >> 64);
-    jump[k][1] = (uint64_t)A;
-    jump[k][2] = (uint64_t)(G >> 64);
-    jump[k][3] = (uint64_t)G;
-  }
-  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_pcg_jump), jump, sizeof(jump)));
-  memcpy(ctx->pcg_jump, jump, sizeof(jump));
   HIPCHK(hipHostMalloc((void **)&ctx->h_active, NRING * sizeof(int), hipHostMallocMapped));
   HIPCHK(hipHostGetDevicePointer((void **)&ctx->d_active, ctx->h_active, 0));
   for (int i = 0; i < NRING; i++) HIPCHK(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
@@ -165,7 +154,7 @@ extern "C" int aehmc_create(aehmc_ctx **out, int device) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     int per_cu = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (gemm_nt_f64_streamk_kernel<true, 4>), 256, 0));
+    HIPCHK(tu::gemm_streamk_occupancy(&per_cu));
     if (per_cu > 2) per_cu = 2;
     ctx->sk_grid = (prop.multiProcessorCount * per_cu / 8) * 8;  // all workgroups co-resident
     ctx->sk_grid_wide = (prop.multiProcessorCount / 8) * 8;       // 128 x 256 tiles: one workgroup per CU
@@ -276,9 +265,8 @@ static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vec
     if (hiprtcCreateProgram(&prog, src.c_str(), "aehmc_custom.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
       FAIL("hiprtcCreateProgram failed");
     for (const auto &n : names) hiprtcAddNameExpression(prog, n.c_str());
-    hiprtcAddNameExpression(prog, "&aehmc::c_pcg_jump");
     const std::string inc = "-I" + ctx->custom_inc;
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str(),
+    const char *opts[] = {"--offload-arch=" AEHMC_GPU_ARCH, "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str(),
                           "-mllvm", "-disable-machine-licm"};  // (the flags of csrc/Makefile)
     const hiprtcResult rc = hiprtcCompileProgram(prog, 7, opts);
     if (rc != HIPRTC_SUCCESS) {
@@ -309,12 +297,6 @@ static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vec
       }
       rp.fn[n] = f;
     }
-    const char *jlow = nullptr;  // this code object's copy of the jump-ahead table
-    hipDeviceptr_t jptr = nullptr;
-    size_t jbytes = 0;
-    if (hiprtcGetLoweredName(prog, "&aehmc::c_pcg_jump", &jlow) == HIPRTC_SUCCESS &&
-        hipModuleGetGlobal(&jptr, &jbytes, rp.mod, jlow) == hipSuccess && jbytes == sizeof(ctx->pcg_jump))
-      HIPCHK(hipMemcpy(jptr, ctx->pcg_jump, sizeof(ctx->pcg_jump), hipMemcpyHostToDevice));
     hiprtcDestroyProgram(&prog);
     it = ctx->rtc.emplace(key, rp).first;
   }
@@ -342,26 +324,57 @@ __global__ void k_transpose_rect(const double *src, double *dst, long long rows,
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < rows * cols) dst[(e % cols) * rows + e / cols] = src[e];
 }
-static int set_custom_params(aehmc_ctx *ctx, const double *const *params, int32_t n_params) {
-  if (n_params < 0 || (n_params > 0 && !params)) FAIL("custom target: bad parameter list");
-  if (ctx->d_cparams) {
-    HIPCHK(hipFree(ctx->d_cparams));
-    ctx->d_cparams = nullptr;
-  }
-  ctx->n_cparams = n_params;
-  HIPCHK(hipMalloc((void **)&ctx->d_cparams, (size_t)(n_params > 0 ? n_params : 1) * sizeof(double *)));
-  if (n_params > 0)
-    HIPCHK(hipMemcpy(ctx->d_cparams, params, (size_t)n_params * sizeof(double *), hipMemcpyHostToDevice));
-  return 0;
+// Binding a user-defined target is a transaction: the new source is compiled and the new parameter table uploaded
+// BESIDE what is bound, and only when every step has succeeded do they replace it (round 5; until then a failed compile
+// left the new source and parameter table in place under the old target: the next step of the old target then
+// recompiled the bad source, or read freed parameter arrays).
+struct CustomBinding {
+  std::string src, inc;
+  std::map<std::string, aehmc_ctx::RtcProgram> rtc;
+  const double **d_cparams = nullptr;
+  int n_cparams = 0;
+};
+static void custom_swap(aehmc_ctx *ctx, CustomBinding &b) {
+  std::swap(ctx->custom_src, b.src);
+  std::swap(ctx->custom_inc, b.inc);
+  std::swap(ctx->rtc, b.rtc);
+  std::swap(ctx->d_cparams, b.d_cparams);
+  std::swap(ctx->n_cparams, b.n_cparams);
 }
-static int set_custom_source(aehmc_ctx *ctx, const char *source, const char *include_dir) {
-  if (ctx->custom_src != source || ctx->custom_inc != include_dir) {  // another function: its own code objects
-    for (auto &kv : ctx->rtc)
-      if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
-    ctx->rtc.clear();
-    ctx->custom_src = source;
-    ctx->custom_inc = include_dir;
+static void custom_release(CustomBinding &b) {
+  for (auto &kv : b.rtc)
+    if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+  b.rtc.clear();
+  if (b.d_cparams) (void)hipFree(b.d_cparams);
+  b.d_cparams = nullptr;
+}
+// installs (source, params) in the ctx and compiles program `which`; on failure the previous binding is back in place
+static int custom_bind(aehmc_ctx *ctx, const char *source, const char *include_dir, const double *const *params,
+                       int32_t n_params, const std::string &which, const std::vector<std::string> &names) {
+  if (n_params < 0 || (n_params > 0 && !params)) FAIL("custom target: bad parameter list");
+  CustomBinding nb;
+  nb.src = source;
+  nb.inc = include_dir;
+  nb.n_cparams = n_params;
+  HIPCHK(hipMalloc((void **)&nb.d_cparams, (size_t)(n_params > 0 ? n_params : 1) * sizeof(double *)));
+  if (n_params > 0 &&
+      hipMemcpy(nb.d_cparams, params, (size_t)n_params * sizeof(double *), hipMemcpyHostToDevice) != hipSuccess) {
+    custom_release(nb);
+    FAIL("custom target: parameter table upload failed");
   }
+  const bool same_source = ctx->custom_src == nb.src && ctx->custom_inc == nb.inc;
+  if (same_source) std::swap(nb.rtc, ctx->rtc);  // the same function: its code objects stay
+  custom_swap(ctx, nb);                            // ctx: new binding; nb: the previous one
+  hipFunction_t f = nullptr;  // compile now: errors in the user's source surface here, not in the first step
+  if (int rc = rtc_function(ctx, which, names, names[0], &f)) {
+    const std::string err = ctx->err;
+    custom_swap(ctx, nb);  // ctx: the previous binding again; nb: the failed one
+    if (same_source) std::swap(nb.rtc, ctx->rtc);
+    custom_release(nb);
+    ctx->err = err;
+    return rc;
+  }
+  custom_release(nb);
   return 0;
 }
 extern "C" int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, int64_t N, const double *X,
@@ -370,13 +383,14 @@ extern "C" int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, i
   if (!ctx || !source || !include_dir) return -2;
   HIPCHK(hipSetDevice(ctx->device));
   if (D <= 0 || N <= 0 || !X || !y) FAIL("GLM target needs D, N, X [N,D] and y [N]");
-  if (int rc = set_custom_source(ctx, source, include_dir)) return rc;
-  if (int rc = set_custom_params(ctx, params, n_params)) return rc;
-  hipFunction_t f = nullptr;  // compile now: errors in the user's source surface here
-  if (int rc = rtc_function(ctx, "glm", RTC_GLM, RTC_GLM[0], &f)) return rc;
-  if (ctx->glm_XT) HIPCHK(hipFree(ctx->glm_XT));
-  ctx->glm_XT = nullptr;
-  HIPCHK(hipMalloc((void **)&ctx->glm_XT, (size_t)N * D * sizeof(double)));
+  double *XT = nullptr;  // (allocated before anything is replaced)
+  HIPCHK(hipMalloc((void **)&XT, (size_t)N * D * sizeof(double)));
+  if (int rc = custom_bind(ctx, source, include_dir, params, n_params, "glm", RTC_GLM)) {
+    (void)hipFree(XT);
+    return rc;
+  }
+  if (ctx->glm_XT) (void)hipFree(ctx->glm_XT);
+  ctx->glm_XT = XT;
   hipLaunchKernelGGL(k_transpose_rect, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, 0, X, ctx->glm_XT,
                      (long long)N, (long long)D);
   HIPCHK(hipGetLastError());
@@ -395,10 +409,7 @@ extern "C" int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64
   if (!ctx || !source || !include_dir) return -2;
   HIPCHK(hipSetDevice(ctx->device));
   if (D <= 0) FAIL("target: D must be positive");
-  if (int rc = set_custom_source(ctx, source, include_dir)) return rc;
-  if (int rc = set_custom_params(ctx, params, n_params)) return rc;
-  hipFunction_t f = nullptr;  // compile now: errors in the user's source surface here, not in the first step
-  if (int rc = rtc_function(ctx, "base", RTC_BASE, RTC_BASE[0], &f)) return rc;
+  if (int rc = custom_bind(ctx, source, include_dir, params, n_params, "base", RTC_BASE)) return rc;
   aehmc_target t{};
   t.kind = AEHMC_T_CUSTOM;
   t.D = D;
@@ -414,7 +425,7 @@ static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A
 // metrics.py:56-58: L = cholesky(imm); mass_matrix_sqrt = solve_triangular(L, I, lower, trans)
 // = L^-T.  Blocked (64-wide) right-looking Cholesky and blocked triangular inverse; the
 // O(D^3) work is in the fp64 MFMA GEMM.  `out` [D,D] receives L^-T.
-static int dense_sqrt_mass(aehmc_ctx *ctx, const double *imm, int64_t D, double *out) {
+static int dense_sqrt_mass(aehmc_ctx *ctx, const double *imm, int64_t D, double *out, hipStream_t st) {
   const int NB = FACT_NB;
   double *Lw = nullptr, *Li = nullptr, *small = nullptr, *Tt = nullptr;
   int *info = nullptr;
@@ -424,7 +435,6 @@ static int dense_sqrt_mass(aehmc_ctx *ctx, const double *imm, int64_t D, double 
   HIPCHK(hipMalloc((void **)&Tt, (size_t)NB * D * sizeof(double)));
   HIPCHK(hipMalloc((void **)&info, sizeof(int)));
   double *inv = small, *invT = small + NB * NB;
-  hipStream_t st = 0;
   int rc = 0, h_info = 0;
   auto done = [&](int r) {
     (void)hipFree(Lw); (void)hipFree(Li); (void)hipFree(small); (void)hipFree(Tt); (void)hipFree(info);
@@ -467,7 +477,9 @@ static int dense_sqrt_mass(aehmc_ctx *ctx, const double *imm, int64_t D, double 
   if (!rc) {
     dim3 grid((unsigned)((D + 31) / 32), (unsigned)((D + 31) / 32)), block(32, 8);
     hipLaunchKernelGGL(k_transpose, grid, block, 0, st, (const double *)Li, out, (long long)D);
-    if (hipMemcpy(&h_info, info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || hipGetLastError() != hipSuccess) {
+    // (on the caller's stream: an `imm` produced there is complete before it is read, and the factor before return)
+    if (hipMemcpyAsync(&h_info, info, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
       ctx->err = "dense metric: factorisation kernels failed";
       rc = -1;
     } else if (h_info) {
@@ -498,12 +510,13 @@ extern "C" int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *m) {
       HIPCHK(hipMalloc((void **)&ctx->own_sqrt_mass, n * sizeof(double)));
       ctx->own_sqrt_mass_n = n;
     }
+    HIPCHK(hipDeviceSynchronize());  // (no stream argument here: whatever produced `imm`, on any stream, is complete)
     if (m->ndim < 2) {
       hipLaunchKernelGGL(k_sqrt_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, m->imm,
                          ctx->own_sqrt_mass, (long long)n);
       HIPCHK(hipGetLastError());
       HIPCHK(hipDeviceSynchronize());
-    } else if (int rc = dense_sqrt_mass(ctx, m->imm, m->D, ctx->own_sqrt_mass)) {
+    } else if (int rc = dense_sqrt_mass(ctx, m->imm, m->D, ctx->own_sqrt_mass, 0)) {
       return rc;
     }
     met.sqrt_mass = ctx->own_sqrt_mass;
@@ -520,15 +533,16 @@ extern "C" int aehmc_metric_sqrt(aehmc_ctx *ctx, int32_t ndim, int64_t D, const 
   if (ndim < 0 || ndim > 2)
     FAIL("Expected a mass matrix of dimension 1 (diagonal) or 2, got " + std::to_string(ndim));
   if (!imm || !sqrt_mass || D <= 0) FAIL("metric_sqrt: bad arguments");
-  (void)stream;  // (the factorisation runs on the default stream and is complete on return, as in aehmc_set_metric)
+  // on the caller's stream (ordered behind whatever produced `imm` there) and complete on return
+  hipStream_t st = (hipStream_t)stream;
   if (ndim < 2) {
     const int64_t n = ndim == 0 ? 1 : D;
-    hipLaunchKernelGGL(k_sqrt_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, imm, sqrt_mass, (long long)n);
+    hipLaunchKernelGGL(k_sqrt_recip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, imm, sqrt_mass, (long long)n);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(st));
     return 0;
   }
-  return dense_sqrt_mass(ctx, imm, D, sqrt_mass);
+  return dense_sqrt_mass(ctx, imm, D, sqrt_mass, st);
 }
 
 extern "C" int aehmc_metric_sqrt_per_chain(aehmc_ctx *ctx, int64_t C, int64_t D, const double *imm,
@@ -859,7 +873,7 @@ static int gemm(aehmc_ctx *ctx, int64_t M, int64_t N, int64_t K, const double *A
   // grid, from an upper bound: live chains never increase within a transition, so the count seen
   // at the last poll bounds every later launch (few rows left: smaller tiles, no persistent grid)
   if (n_rows && ctx->rows_hint > 0 && ctx->rows_hint < M) M = ctx->rows_hint;
-  HIPCHK(launch_gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st, row_idx, n_rows,
+  HIPCHK(tu::gemm_nt_f64(M, N, K, A, lda, B, ldb, Cm, ldc, st, row_idx, n_rows,
                             p ? ctx->d_flops : nullptr, (use_sk && mode == 0) ? &sk : nullptr, ctx->sk_grid,
                             mode, ctx->opt_streamk == 2 ? ctx->sk_grid_wide : 0, ctx->opt_gemm_small));
   return prof_end(ctx, st, p);
@@ -1155,7 +1169,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     }
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    HIPCHK(launch_nuts_linreg(a, m, st));
+    HIPCHK(tu::nuts_linreg(a, m, st));
     return prof_end(ctx, st, p);
   }
   const int path = nuts_path(ctx, C, max_num_expansions);
@@ -1167,7 +1181,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, a.rng, a.nsites, (long long)C,
                          (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf, a.ldw, 1);
       HIPCHK(hipGetLastError());
-      HIPCHK(launch_nuts_wide(a, st));
+      HIPCHK(tu::nuts_wide(a, st));
     } else {  // teams of <= 64 lanes: any number of transitions in one launch
       NutsSampleArgs m{};
       m.T = 1;
@@ -1181,7 +1195,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
                                  (pl.multi ? "true" : "false") + ", 0, " + (pl.ckl ? "true" : "false") + ">";
         if (int rc = rtc_launch(ctx, "nuts", {name}, name, dim3(pl.grid), dim3(256), pl.dyn, st, a, m)) return rc;
       } else {
-        HIPCHK(launch_nuts_resident(a, m, st, ctx->opt_resident_min_team));
+        HIPCHK(tu::nuts_resident(a, m, st, ctx->opt_resident_min_team));
       }
     }
     return prof_end(ctx, st, p);
@@ -1200,7 +1214,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       if (int rc = fused_dense_workspace(ctx, (size_t)C * a.D * a.D * sizeof(double), &m.imm_ws)) return rc;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    HIPCHK(launch_nuts_resident_dense(a, m, st, md, td, pc));
+    HIPCHK(tu::nuts_resident_dense(a, m, st, md, td, pc));
     return prof_end(ctx, st, p);
   }
   if (path == NUTS_PATH_BLOCK_DENSE) {  // mid-size dense problems: every transition of the call in one launch
@@ -1216,9 +1230,9 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     if (int rc = block_pack_workspace(ctx, a.D, &bp)) return rc;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(launch_nuts_block_roll(a, m, bp, st));
-    else if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(launch_nuts_block_reg(a, m, bp, st));
-    else HIPCHK(launch_nuts_block_dense(a, m, bp, st));
+    if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(tu::nuts_block_roll(a, m, bp, st));
+    else if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(tu::nuts_block_reg(a, m, bp, st));
+    else HIPCHK(tu::nuts_block_dense(a, m, bp, st));
     return prof_end(ctx, st, p);
   }
   if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
@@ -1417,7 +1431,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     f.fc = ctx->opt_fp_contract;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    HIPCHK(launch_hmc_fused(f, st));
+    HIPCHK(tu::hmc_fused(f, st));
     return prof_end(ctx, st, p);
   }
   // user-defined coordinate-wise target: the same fused kernel, compiled against the user's function at run time
@@ -1454,7 +1468,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    HIPCHK(launch_hmc_linreg(f, st));
+    HIPCHK(tu::hmc_linreg(f, st));
     return prof_end(ctx, st, p);
   }
   EngineArgs a;
@@ -1495,7 +1509,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
       f.acc_hist = acc_hist ? acc_hist + (size_t)t0 * C : nullptr;
       f.div_hist = div_hist ? div_hist + (size_t)t0 * C : nullptr;
       f.out.momentum = t0 + nt == T ? out->momentum : nullptr;  // only the last transition's is observable
-      HIPCHK(launch_hmc_resident(f, zall, nt, st));
+      HIPCHK(tu::hmc_resident(f, zall, nt, st));
     }
     if (T > 1 && out->n_leapfrog)
       LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
@@ -1547,9 +1561,9 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
     if (ctx->opt_block_dense != 2 && block_reg_supported(D))
-      HIPCHK(launch_hmc_block_reg(a, ctx->tgt.prec, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist, bp, st));
+      HIPCHK(tu::hmc_block_reg(a, ctx->tgt.prec, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist, bp, st));
     else
-      HIPCHK(launch_hmc_block_dense(a, ctx->tgt.prec, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist, bp, st));
+      HIPCHK(tu::hmc_block_dense(a, ctx->tgt.prec, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist, bp, st));
     if (int rc = prof_end(ctx, st, p)) return rc;
     if (T > 1 && out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
     return 0;

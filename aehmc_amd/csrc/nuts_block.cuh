@@ -59,7 +59,7 @@ inline bool block_dense_supported(int tkind, int met_ndim, int per_chain, long l
 // with predicated loads the compiler waits for ALL outstanding loads before each use (s_waitcnt vmcnt(0)) and the
 // prefetch depth collapses to one tile -- every 16-byte load is aligned whatever D, and rows / columns past D
 // contribute exact zeros.
-__global__ __launch_bounds__(256) void k_blk_pack(const double *src, double *dst, long long D, long long Dp) {
+AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_blk_pack(const double *src, double *dst, long long D, long long Dp) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Dp * Dp) return;
   const long long i = e / Dp, j = e % Dp;

@@ -44,16 +44,51 @@ __device__ __forceinline__ u128 add128(u128 a, u128 b) {
 }
 __device__ __forceinline__ u128 muladd128(u128 a, u128 b, u128 c) { return add128(mul128(a, b), c); }
 
-__constant__ uint64_t c_zig_ki[256] = {AEHMC_ZIG_KI_VALUES};
-__constant__ double c_zig_wi[256] = {AEHMC_ZIG_WI_VALUES};
-__constant__ double c_zig_fi[256] = {AEHMC_ZIG_FI_VALUES};
-// c_pcg_jump[k] = {A^(k+1) hi, lo, G_(k+1) hi, lo} with A the PCG64 multiplier and
-// G_n = 1 + A + ... + A^(n-1):  state_{t+n} = A^n * state_t + G_n * inc   (mod 2^128).
-// Filled by aehmc_create().
-__constant__ uint64_t c_pcg_jump[64][4];
+// One copy per translation unit (the library is several: tu_*.hip) -- internal linkage in the ahead-of-time build;
+// hipRTC programs are single translation units and address the tables by name.
+#ifdef __HIPCC_RTC__
+#define AEHMC_TU_LOCAL
+#else
+#define AEHMC_TU_LOCAL static
+#endif
+AEHMC_TU_LOCAL __constant__ uint64_t c_zig_ki[256] = {AEHMC_ZIG_KI_VALUES};
+AEHMC_TU_LOCAL __constant__ double c_zig_wi[256] = {AEHMC_ZIG_WI_VALUES};
+AEHMC_TU_LOCAL __constant__ double c_zig_fi[256] = {AEHMC_ZIG_FI_VALUES};
 
 #define AEHMC_PCG_MULT_HI 2549297995355413924ULL
 #define AEHMC_PCG_MULT_LO 4865540595714422341ULL
+
+// c_pcg_jump[k] = {A^(k+1) hi, lo, G_(k+1) hi, lo} with A the PCG64 multiplier and
+// G_n = 1 + A + ... + A^(n-1):  state_{t+n} = A^n * state_t + G_n * inc   (mod 2^128).
+// A compile-time table (round 5; until then aehmc_create() filled it in every code object at run time): 128-bit
+// products from 32-bit limbs so that the constant evaluator needs no `__int128`.
+struct PcgJumpTable {
+  uint64_t v[64][4];
+};
+constexpr uint64_t cx_mulhi64(uint64_t a, uint64_t b) {
+  const uint64_t a0 = a & 0xffffffffULL, a1 = a >> 32, b0 = b & 0xffffffffULL, b1 = b >> 32;
+  const uint64_t p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+  const uint64_t mid = (p00 >> 32) + (p01 & 0xffffffffULL) + (p10 & 0xffffffffULL);
+  return p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+}
+constexpr PcgJumpTable make_pcg_jump_table() {
+  PcgJumpTable t{};
+  uint64_t Ah = 0, Al = 1, Gh = 0, Gl = 0;
+  for (int k = 0; k < 64; k++) {
+    // G_{k+1} = G_k * mult + 1,  A_{k+1} = A_k * mult   (low 128 bits)
+    uint64_t h = cx_mulhi64(Gl, AEHMC_PCG_MULT_LO) + Gh * AEHMC_PCG_MULT_LO + Gl * AEHMC_PCG_MULT_HI;
+    uint64_t l = Gl * AEHMC_PCG_MULT_LO;
+    Gl = l + 1;
+    Gh = h + (Gl < l ? 1ULL : 0ULL);
+    h = cx_mulhi64(Al, AEHMC_PCG_MULT_LO) + Ah * AEHMC_PCG_MULT_LO + Al * AEHMC_PCG_MULT_HI;
+    Al = Al * AEHMC_PCG_MULT_LO;
+    Ah = h;
+    t.v[k][0] = Ah; t.v[k][1] = Al; t.v[k][2] = Gh; t.v[k][3] = Gl;
+  }
+  return t;
+}
+AEHMC_TU_LOCAL __constant__ PcgJumpTable c_pcg_jump_table = make_pcg_jump_table();
+#define c_pcg_jump c_pcg_jump_table.v
 
 struct Pcg64 {
   u128 state, inc;

@@ -148,31 +148,33 @@ class Engine:
         # as for the metric below), not by the identity of the Target object
         params = target.params()
         key = (type(target), D, tuple((k, _param_key(v)) for k, v in sorted(params.items())))
+        if getattr(target, "source", None) is not None:
+            key = key + (target.source,)
         if self._target_key == key and not force:
             return
-        p = {k: _dev_f64(v, self.device) for k, v in params.items()}
         if target.dim is not None and target.dim != D:
             raise ValueError(f"target has dimension {target.dim}, position has {D}")
+        p = {k: _dev_f64(v, self.device) for k, v in params.items()}
         if getattr(target, "source", None) is not None:  # user-defined coordinate-wise target: compiled with hipRTC
             import os
-            key = key + (target.source,)
-            if self._target_key == key and not force:
-                return
             arrs = [p[f"p{k}"] for k in range(len(target.param_list))]
             ptrs = (ct.c_void_p * max(len(arrs), 1))(*[a.data_ptr() for a in arrs])
             inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-            self._keep["target"] = (target, p)
+            # a failed compile leaves the ctx bound to what it was bound to (aehmc_set_custom_target is a
+            # transaction): the arrays of THAT binding must stay alive, so `_keep` changes only on success
             if "X" in p:  # row-reduction target over a data matrix
                 X, y = p["X"].contiguous(), p["y"].reshape(-1).contiguous()
                 if X.ndim != 2 or X.shape[1] != D or y.numel() != X.shape[0]:
                     raise ValueError(f"GLM target: X must be [N, {D}] and y [N], got {tuple(X.shape)} and {tuple(y.shape)}")
-                self._keep["target"] = (target, p, X, y)
+                keep = (target, p, X, y)
                 self._check(self.lib.aehmc_set_custom_glm_target(self.ctx, target.source.encode(), D, X.shape[0],
                                                                  X.data_ptr(), y.data_ptr(), ptrs, len(arrs), inc.encode()),
                             "aehmc_set_custom_glm_target")
             else:
+                keep = (target, p)
                 self._check(self.lib.aehmc_set_custom_target(self.ctx, target.source.encode(), D, ptrs, len(arrs),
                                                              inc.encode()), "aehmc_set_custom_target")
+            self._keep["target"] = keep
             self._target_key, self.D = key, D
             self._ws = None
             return
@@ -182,8 +184,8 @@ class Engine:
                 setattr(c, name, p[name].data_ptr())
         if "X" in p:
             c.N = p["X"].numel()
-        self._keep["target"] = (target, p)
         self._check(self.lib.aehmc_set_target(self.ctx, ct.byref(c)), "aehmc_set_target")
+        self._keep["target"] = (target, p)
         self._target_key, self.D = key, D
         self._ws = None
 
