@@ -54,6 +54,12 @@ __device__ __forceinline__ int blk_bernoulli(double *d, int k, double p, int lan
   return r;
 }
 
+// a value the optimizer has to take as it comes (see ATL in nuts_block_flow.cuh)
+__device__ __forceinline__ int blk_opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // dst[16][S] = src[16][S] * Bp^T, both in LDS, for the rows of `rowmask`; the caller places the barriers
 __device__ __forceinline__ void blk_gemm_lds(const double *src, double *dst, int S, const double *Bp, long long D,
                                              int wave, int lane, double *tb, unsigned rowmask = 0xffffu) {

@@ -30,12 +30,6 @@ __device__ __attribute__((noinline)) void blk_draw_normals(double *park, double 
   __threadfence_block();
 }
 
-// a value the optimizer has to take as it comes (see ATL in k_nuts_block_reg)
-__device__ __forceinline__ int blk_opaque(int x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
-
 template <int R, bool TDENSE>
 __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, NutsSampleArgs m) {
   extern __shared__ __attribute__((aligned(16))) double blk_lds[];

@@ -56,3 +56,14 @@ print(f"D={D} C={C} T={T}: {dt*1e3:.3f} ms per transition; leapfrogs/chain/trans
       f"ticks per wave and transition {tot.mean() / T:.0f}")
 for k, n in enumerate(names):
     print(f"  {n:16s} {tim[:, k].mean() / T:10.0f} ticks / transition  {100 * tim[:, k].sum() / tot.sum():5.1f} %")
+if os.environ.get("CENSUS"):
+    nb = (C + 15) // 16
+    bins = ws[off + C * 64: off + C * 64 + nb * 256 * 8].view(torch.float64).reshape(nb, 256).cpu().numpy().sum(axis=0)
+    tt, cnt = bins[:128], bins[128:]
+    names = {1: "finalize", 2: "end", 4: "next", 8: "deeper", 16: "fin-ondemand", 32: "ckpt-from-mem", 64: "take"}
+    print(f"critical path of the bookkeeping phase: {tt.sum() / nb / T:.0f} ticks per transition and workgroup, {cnt.sum() / nb / T:.1f} rounds")
+    order = np.argsort(-tt)
+    for k in order[:14]:
+        if cnt[k] == 0: continue
+        lab = "+".join(n for b, n in names.items() if k & b) or "plain"
+        print(f"  {lab:40s} {100 * tt[k] / tt.sum():5.1f} % of path, {100 * cnt[k] / cnt.sum():5.1f} % of rounds, {tt[k] / cnt[k]:7.0f} ticks each")
