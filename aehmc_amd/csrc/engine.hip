@@ -20,7 +20,6 @@
 #include "nuts_block.cuh"
 #include "nuts_block_reg.cuh"
 #include "nuts_block_roll.cuh"
-#include "nuts_block_flow.cuh"
 #include "nuts_resident.cuh"
 #include "nuts_wide.cuh"
 
@@ -91,9 +90,6 @@ struct aehmc_ctx {
   size_t fd_ws_bytes = 0;
   double *blk_pack = nullptr;  // block-resident dense kernels: the launch's matrices zero-padded to [Dp][Dp] (kept, grown)
   size_t blk_pack_bytes = 0;
-  double *blk_mom = nullptr;  // k_nuts_block_flow: momenta / velocities of a launch's transitions + w0 + the constant 1.0 (kept, grown)
-  size_t blk_mom_bytes = 0;
-  int opt_block_flow = 1;  // mid-size dense NUTS on k_nuts_block_flow (0: round 4's kernels, selected by block_roll)
   // user-defined target (aehmc_set_custom_target): its source, the kernels compiled against it (hipRTC code objects
   // keyed by program + source, kept for the life of the ctx) and the device array of its parameter arrays
   std::string custom_src, custom_inc;
@@ -190,7 +186,6 @@ extern "C" int aehmc_destroy(aehmc_ctx *ctx) {
   if (ctx->pc_work) (void)hipFree(ctx->pc_work);
   if (ctx->fd_ws) (void)hipFree(ctx->fd_ws);
   if (ctx->blk_pack) (void)hipFree(ctx->blk_pack);
-  if (ctx->blk_mom) (void)hipFree(ctx->blk_mom);
   if (ctx->d_cparams) (void)hipFree(ctx->d_cparams);
   if (ctx->glm_XT) (void)hipFree(ctx->glm_XT);
   if (ctx->glm_z) (void)hipFree(ctx->glm_z);
@@ -720,10 +715,6 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
     ctx->opt_block_dense = (int)value;
     return 0;
   }
-  if (!strcmp(name, "block_flow")) {
-    ctx->opt_block_flow = value != 0;
-    return 0;
-  }
   if (!strcmp(name, "block_roll")) {
     if (value < 0 || value > 16) FAIL("block_roll: 0 (default) ... 16");
     ctx->opt_block_roll = (int)value;
@@ -1128,41 +1119,6 @@ static int block_pack_workspace(aehmc_ctx *ctx, int64_t D, double **out) {
   *out = ctx->blk_pack;
   return 0;
 }
-// Mid-size dense NUTS on k_nuts_block_flow (nuts_block_flow.cuh): per launch of up to Tc transitions, the normals of
-// ALL its transitions (site #1 serves nothing else), P = Z L^-1, V = P imm and w0 = dU/dq imm as chain-batched GEMMs --
-// launch_begin's products (metrics.py:65-68, nuts.py:113-125) over (transitions x chains) rows -- then the kernel.
-static int block_flow_run(aehmc_ctx *ctx, const EngineArgs &a, const NutsSampleArgs &m, double *bp, hipStream_t st) {
-  const int64_t C = a.C, D = a.D, T = m.T;
-  const size_t vec = (size_t)C * D;
-  int64_t Tc = (int64_t)(((size_t)2 << 30) / (2 * vec * sizeof(double)));  // momenta + velocities within 2 GiB
-  if (Tc < 1) Tc = 1;
-  if (Tc > T) Tc = T;
-  const size_t need = ((size_t)(2 * Tc + 1) * vec + 1) * sizeof(double);
-  if (ctx->blk_mom_bytes < need) {
-    if (ctx->blk_mom) HIPCHK(hipFree(ctx->blk_mom));
-    ctx->blk_mom = nullptr;
-    ctx->blk_mom_bytes = 0;
-    HIPCHK(hipMalloc((void **)&ctx->blk_mom, need));
-    ctx->blk_mom_bytes = need;
-  }
-  double *const zv = ctx->blk_mom, *const pm = zv + (size_t)Tc * vec, *const w0 = pm + (size_t)Tc * vec, *const one = w0 + vec;
-  const double h_one = 1.0;
-  HIPCHK(hipMemcpyAsync(one, &h_one, sizeof(double), hipMemcpyHostToDevice, st));
-  for (int64_t t0 = 0; t0 < T; t0 += Tc) {
-    const int64_t nt = T - t0 < Tc ? T - t0 : Tc;
-    // raw normals: the scalar-metric form of the draw with sqrt_mass = 1.0 (1.0 * z is z)
-    hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, a.rng, a.nsites, (long long)C, (long long)D,
-                       (const double *)one, 0LL, 0, zv, (long long)D, (int)nt);
-    HIPCHK(hipGetLastError());
-    if (int rc = gemm(ctx, nt * C, D, D, zv, D, ctx->met.sqrt_mass, D, pm, D, st)) return rc;  // p = L^-T z
-    if (int rc = gemm(ctx, nt * C, D, D, pm, D, ctx->met.imm, D, zv, D, st)) return rc;        // v = imm p
-    if (int rc = gemm(ctx, C, D, D, a.g, D, ctx->met.imm, D, w0, D, st)) return rc;            // w0 = imm dU/dq
-    BlkFlowArgs f{pm, zv, w0, (long long)t0, (long long)nt};
-    HIPCHK(tu::nuts_block_flow(a, m, f, bp, st));
-  }
-  return 0;
-}
-
 static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions) {
   const int tkind = ctx->tgt.kind, nd = ctx->met.ndim;
   const int64_t D = ctx->tgt.D;
@@ -1274,9 +1230,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     if (int rc = block_pack_workspace(ctx, a.D, &bp)) return rc;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (ctx->opt_block_dense != 2 && ctx->opt_block_flow && block_reg_supported(a.D)) {
-      if (int rc = block_flow_run(ctx, a, m, bp, st)) return rc;
-    } else if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(tu::nuts_block_roll(a, m, bp, st));
+    if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(tu::nuts_block_roll(a, m, bp, st));
     else if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(tu::nuts_block_reg(a, m, bp, st));
     else HIPCHK(tu::nuts_block_dense(a, m, bp, st));
     return prof_end(ctx, st, p);

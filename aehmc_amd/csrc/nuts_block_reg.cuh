@@ -54,7 +54,17 @@ __device__ __forceinline__ int blk_bernoulli(double *d, int k, double p, int lan
   return r;
 }
 
-// a value the optimizer has to take as it comes (see ATL in nuts_block_flow.cuh)
+// A workgroup barrier that orders LDS traffic only.  The wavefronts of this kernel talk to each other through LDS alone
+// (operand / result rows, status words); what a chain keeps in global memory is never read by another chain.
+// __syncthreads() would also wait for every outstanding GLOBAL access of the wavefront (s_waitcnt vmcnt(0)): the loads
+// that are requested a phase ahead on purpose would be waited for at the very next barrier, by the whole workgroup.
+__device__ __forceinline__ void blk_barrier_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// a value the optimizer has to take as it comes (see ATL in nuts_block_roll.cuh)
 __device__ __forceinline__ int blk_opaque(int x) {
   asm volatile("" : "+v"(x));
   return x;
@@ -122,6 +132,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
     eps = a.eps_c ? a.eps_c[c] : a.eps;
   }
   BlkTimer tm;
+  __shared__ int blk_alive[BLK_CHAINS];  // the round's vote (the barriers order LDS traffic only: blk_barrier_lds)
 
   // first stages of a leapfrog (leap_linear<12>): p_half, v_half, q', the target where it is coordinate-wise, and the
   // operand row of the next product -- r = q' - mu (dense target) or dU/dq' itself -- into this chain's row of xbuf
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
     }
   };
 
-  __syncthreads();
+  blk_barrier_lds();
   for (long long t_idx = 0; t_idx < m.T; t_idx++) {
     // ---- momentum: z (site #1) -> p = L^-T z, v = imm p; w = imm dU/dq (metrics.py:65-68, nuts.py:113-125) ----
     if (valid) {
@@ -413,13 +424,13 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
       __threadfence_block();
     }
     tm.tick(7);
-    __syncthreads();
+    blk_barrier_lds();
     blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb);
-    __syncthreads();
+    blk_barrier_lds();
 #pragma unroll
     for (int r = 0; r < R; r++) p[r] = ok[r] ? yrow[EI(r)] : 0.0;
     blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);
-    __syncthreads();
+    blk_barrier_lds();
 #pragma unroll
     for (int r = 0; r < R; r++) {
       v[r] = ok[r] ? xrow[EI(r)] : 0.0;
@@ -427,10 +438,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
       pb[r] = 0.0;
       if (ok[r]) grow[EI(r)] = AT(a.g, r);  // the operand row of w = imm dU/dq, and dU/dq's home from here on
     }
-    __syncthreads();
+    blk_barrier_lds();
     if (TDENSE) blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);
     else blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);
-    __syncthreads();
+    blk_barrier_lds();
     tm.tick(2);
     if (valid) {  // nuts_init_chain<true>
       double kd = 0.0;
@@ -478,22 +489,27 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
       if (valid && !ct.done) stage12();
       tm.tick(5);
       const bool alive = valid && !ct.done;
-      const int live = __syncthreads_or(alive);
+      if (lane == 0) blk_alive[wave] = alive ? 1 : 0;
+      blk_barrier_lds();
+      int live = 0;
+#pragma unroll
+      for (int k = 0; k < BLK_CHAINS; k++) live |= blk_alive[k];
+      live = __builtin_amdgcn_readfirstlane(live);
       tm.tick(6);  // vote (waits for the slowest chain's bookkeeping)
       if (!live) break;
       if (TDENSE) {
         blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb);  // dU/dq' = P r
         tm.tick(2);
-        __syncthreads();
+        blk_barrier_lds();
         tm.tick(3);
         blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);   // w' = imm dU/dq'
         tm.tick(2);
-        __syncthreads();
+        blk_barrier_lds();
         tm.tick(3);
       } else {
         blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);   // w' = imm dU/dq'
         tm.tick(2);
-        __syncthreads();
+        blk_barrier_lds();
         tm.tick(3);
       }
       if (alive) {
@@ -579,20 +595,20 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
     eps = a.eps_c ? a.eps_c[c] : a.eps;
   }
   const double b = 0.5 * (1.0 * eps), aa = 1 * (1.0 * eps);  // direction +1 (launch_leapfrog: ct.dir = 1)
-  __syncthreads();
+  blk_barrier_lds();
   for (long long tt = 0; tt < nt; tt++) {
     const bool last_t = tt == nt - 1;
     if (valid) {
       wave_normals(g1, D, [=](long long i, double z) { xrow[i] = z; });
       __threadfence_block();
     }
-    __syncthreads();
+    blk_barrier_lds();
     blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb);  // p = L^-T z
-    __syncthreads();
+    blk_barrier_lds();
 #pragma unroll
     for (int r = 0; r < R; r++) p[r] = ok[r] ? yrow[EI(r)] : 0.0;
     blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);        // v = imm p
-    __syncthreads();
+    blk_barrier_lds();
 #pragma unroll
     for (int r = 0; r < R; r++) {
       v[r] = ok[r] ? xrow[EI(r)] : 0.0;
@@ -602,10 +618,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
         if (last_t && a.out.momentum) AT(a.out.momentum, r) = p[r];
       }
     }
-    __syncthreads();
+    blk_barrier_lds();
     if (TDENSE) blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);  // w = imm dU/dq
     else blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);
-    __syncthreads();
+    blk_barrier_lds();
     double kd = 0.0;
 #pragma unroll
     for (int r = 0; r < R; r++)  // hmc_init_chain<true>
@@ -635,15 +651,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
         }
       }
       if (!TDENSE && valid) U_cur = target_finish(a, wave_sum(usum));
-      __syncthreads();
+      blk_barrier_lds();
       if (TDENSE) {
         blk_gemm_lds(xbuf, ybuf, S, prec, D, wave, lane, tb);
-        __syncthreads();
+        blk_barrier_lds();
         blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);
-        __syncthreads();
+        blk_barrier_lds();
       } else {
         blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);
-        __syncthreads();
+        blk_barrier_lds();
       }
       usum = 0.0;
 #pragma unroll

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
     if (phase == PH_RUN) stage12();
     tm.tick(5);
     if (lane == 0) blk_status[wave] = phase;
-    __syncthreads();
+    blk_barrier_lds();
     unsigned runmask = 0, waitmask = 0, drawmask = 0;
 #pragma unroll
     for (int k = 0; k < BLK_CHAINS; k++) {
@@ -526,12 +526,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
     const bool beginning = (bmask >> wave) & 1u;
     if (!(runmask | bmask)) {
       // (the workgroup's last trees have just ended: their chains draw below, the round has no products)
-      __syncthreads();  // (blk_status is rewritten at the head of the next round)
+      blk_barrier_lds();  // (blk_status is rewritten at the head of the next round)
     } else if (TDENSE) {
       if (bmask) blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb, bmask);  // p = L^-T z (metrics.py:66-67)
       if (runmask) blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb, runmask);   // dU/dq' = P r
       tm.tick(2);
-      __syncthreads();
+      blk_barrier_lds();
       tm.tick(3);
       if (__builtin_expect(beginning, 0)) {
 #pragma unroll
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
       }
       blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb, runmask | bmask);          // w' = imm dU/dq' | v = imm p
       tm.tick(2);
-      __syncthreads();
+      blk_barrier_lds();
       tm.tick(3);
       if (__builtin_expect(beginning, 0)) {
 #pragma unroll
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
       if (bmask) blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb, bmask);  // p = L^-T z
       if (runmask) blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb, runmask);    // w' = imm dU/dq'
       tm.tick(2);
-      __syncthreads();
+      blk_barrier_lds();
       tm.tick(3);
       if (__builtin_expect(beginning, 0)) {  // p becomes the operand row of v = imm p
 #pragma unroll
@@ -564,10 +564,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
       tm.tick(4);
     }
     if (!TDENSE && __builtin_expect(bmask != 0, 0)) {  // (the running chains' bookkeeping above filled the wait)
-      __syncthreads();
+      blk_barrier_lds();
       blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb, bmask);  // v = imm p
       tm.tick(2);
-      __syncthreads();
+      blk_barrier_lds();
       tm.tick(3);
       if (beginning) {
 #pragma unroll
@@ -587,10 +587,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
       }
     }
     if (__builtin_expect(first, 0)) {  // w = imm dU/dq (grow's buffer -> wrow's buffer)
-      __syncthreads();
+      blk_barrier_lds();
       if (TDENSE) blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb, bmask);
       else blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb, bmask);
-      __syncthreads();
+      blk_barrier_lds();
       tm.tick(2);
     }
     if (__builtin_expect(phase == PH_DRAW, 0)) {

@@ -11,7 +11,6 @@ struct EngineArgs;
 struct NutsSampleArgs;
 struct HmcFusedArgs;
 struct GemmStreamK;
-struct BlkFlowArgs;
 namespace tu {
 // gemm_f64.cuh
 hipError_t gemm_nt_f64(int64_t M, int64_t N, int64_t K, const double *A, int64_t lda, const double *B, int64_t ldb,
@@ -29,7 +28,6 @@ hipError_t nuts_resident(const EngineArgs &a, const NutsSampleArgs &m, hipStream
 hipError_t nuts_resident_dense(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st, bool md, bool td, bool pc);
 // nuts_block*.cuh
 hipError_t nuts_block_roll(const EngineArgs &a, const NutsSampleArgs &m, double *bp, hipStream_t st);
-hipError_t nuts_block_flow(const EngineArgs &a, const NutsSampleArgs &m, const BlkFlowArgs &f, double *bp, hipStream_t st);
 hipError_t nuts_block_reg(const EngineArgs &a, const NutsSampleArgs &m, double *bp, hipStream_t st);
 hipError_t nuts_block_dense(const EngineArgs &a, const NutsSampleArgs &m, double *bp, hipStream_t st);
 hipError_t hmc_block_reg(const EngineArgs &a, const double *prec, long long L, long long nt, double *samples,

@@ -185,12 +185,7 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   products on fp64 MFMA inside the workgroup, same k-order as the chain-batched GEMM (bitwise
  *                   the lock-step path's results).  1: the chains' moving state in registers up to D = 256, in
  *                   L2-resident work rows above; 2: work rows at every D; 0 = the lock-step path
- *  "block_flow" 1   block-resident NUTS with the state in registers (64 < D <= 256): 1 = csrc/nuts_block_flow.cuh -- the
- *                   momenta, velocities and w = imm dU/dq of all transitions of a launch are formed beforehand as
- *                   chain-batched GEMMs over (transitions x chains) rows, so a chain whose tree has ended is in its
- *                   next transition in the very next round, and the bookkeeping's memory reads are requested a phase
- *                   ahead; 0 = round 4's kernels (selected by "block_roll").  Results do not depend on it (bitwise)
- *  "block_roll" 0   ("block_flow" = 0) block-resident NUTS with the state in registers, launches of several transitions: a chain whose
+ *  "block_roll" 0   block-resident NUTS with the state in registers, launches of several transitions: a chain whose
  *                   tree has ended begins its next transition as soon as this many chains of its workgroup wait
  *                   (one more in-workgroup product in that round: csrc/nuts_block_roll.cuh) instead of waiting for
  *                   the deepest of the 16 trees.  0 = rolling with the kernel's threshold (3 with a dense-precision

@@ -46,24 +46,17 @@ else:
 ws = eng._ws
 vec = ((C * D * 8) + 255) & ~255
 off = (26 + 3 * E) * vec
-tim = ws[off: off + C * 8 * 8].view(torch.float64).reshape(C, 8).cpu().numpy()
+flow = False  # (k_nuts_block_flow: tools/debug/experiments/block_flow)
+nrec = (C + 15) // 16 * 4 if flow else C  # k_nuts_block_flow: one record per wavefront (4 per workgroup)
+tim = ws[off: off + nrec * 8 * 8].view(torch.float64).reshape(nrec, 8).cpu().numpy()
 blocks = nl[: C // 16 * 16].reshape(-1, 16).max(axis=1)
 names = ["rows->LDS", "barrier A", "MFMA", "barrier B", "book", "leap12", "vote", "begin"]
-if D <= 256 and os.environ.get("BLOCK_DENSE", "1") == "1":  # the register kernel's phases
+if flow:
+    names = ["book: pass", "book: sums, scalars, draw, take", "MFMA", "barriers", "book: U-turn levels, expansion, end / next", "stage12", "vote", "begin"]
+elif D <= 256 and os.environ.get("BLOCK_DENSE", "1") == "1":  # the register kernel's phases
     names = ["book: pass", "book: scal", "MFMA", "barriers", "book: rest", "stage12", "vote", "begin/end/draw"]
 tot = tim.sum(axis=1)
 print(f"D={D} C={C} T={T}: {dt*1e3:.3f} ms per transition; leapfrogs/chain/transition mean {nl.mean():.1f}; "
       f"ticks per wave and transition {tot.mean() / T:.0f}")
 for k, n in enumerate(names):
     print(f"  {n:16s} {tim[:, k].mean() / T:10.0f} ticks / transition  {100 * tim[:, k].sum() / tot.sum():5.1f} %")
-if os.environ.get("CENSUS"):
-    nb = (C + 15) // 16
-    bins = ws[off + C * 64: off + C * 64 + nb * 256 * 8].view(torch.float64).reshape(nb, 256).cpu().numpy().sum(axis=0)
-    tt, cnt = bins[:128], bins[128:]
-    names = {1: "finalize", 2: "end", 4: "next", 8: "deeper", 16: "fin-ondemand", 32: "ckpt-from-mem", 64: "take"}
-    print(f"critical path of the bookkeeping phase: {tt.sum() / nb / T:.0f} ticks per transition and workgroup, {cnt.sum() / nb / T:.1f} rounds")
-    order = np.argsort(-tt)
-    for k in order[:14]:
-        if cnt[k] == 0: continue
-        lab = "+".join(n for b, n in names.items() if k & b) or "plain"
-        print(f"  {lab:40s} {100 * tt[k] / tt.sum():5.1f} % of path, {100 * cnt[k] / cnt.sum():5.1f} % of rounds, {tt[k] / cnt[k]:7.0f} ticks each")

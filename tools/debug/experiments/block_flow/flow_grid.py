@@ -21,7 +21,6 @@ def case(D, C, T, td):
     for blk in (1, 0):
         eng.set_option("block_dense", blk)
         eng.set_option("block_roll", int(os.environ.get("DBG", "0")))
-        eng.set_option("block_flow", int(os.environ.get("FLOW", "1")))
         kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=8)
         state = nuts.new_state(q0.clone(), tgt)
         if T == 1:

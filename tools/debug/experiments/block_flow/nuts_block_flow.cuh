@@ -56,16 +56,6 @@ inline size_t blk_flow_lds_bytes(long long D) {  // two row buffers, the staging
   return ((size_t)(2 * BLK_CHAINS + 1) * blk_lds_stride(D) + (size_t)BQ_WAVES * BQ_TILES * BLK_TB + (size_t)BLK_CHAINS * BLK_PARK) * sizeof(double);
 }
 
-// A workgroup barrier that orders LDS traffic only.  The wavefronts of this kernel talk to each other through LDS alone
-// (operand / result rows, status words); what a chain keeps in global memory is never read by another chain.
-// __syncthreads() would also wait for every outstanding GLOBAL access of the wavefront (s_waitcnt vmcnt(0)): the loads
-// that are requested a phase ahead on purpose would be waited for at the very next barrier, by the whole workgroup.
-__device__ __forceinline__ void blk_barrier_lds() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // sum over one DPP row (16 lanes), every lane of the row ends with the same bits: the row stages of wave_sum
 __device__ __forceinline__ double row_allsum(double x) {
   x = dpp_add<0xB1>(x);   // quad_perm [1,0,3,2]
@@ -138,7 +128,8 @@ __device__ __forceinline__ int team_bernoulli(double *d, int k, double p, int tl
 // One wavefront: NB column blocks n0, n0 + 16 nstride, ... of dst[16][S] = src[16][S] * Bp^T (both in LDS) TOGETHER: the A
 // fragments of a K-tile are read once, the blocks' MFMA chains interleave.  Per block exactly blk_wave_tile's loads,
 // staging tile (tb + j * BLK_TB), fragment order and MFMA sequence: the same bits.
-template <int NB>
+static_assert(BLK_PREFETCH == 2, "blk_wave_tiles alternates two register stages");
+template <int NB, int PIPE>
 __device__ __forceinline__ void blk_wave_tiles(const double *abuf, int S, const double *__restrict__ Bp, int Dp, long long N,
                                                int n0, int nstride, double *out, long long ldo, int lane, double *tb) {
   const int fr = lane & 15, fk = lane >> 4;
@@ -161,7 +152,10 @@ __device__ __forceinline__ void blk_wave_tiles(const double *abuf, int S, const 
   const double *pa = abuf + fr * S + fk;
   const int xw = (((r >> 1) & 1) << 3) | ((r >> 2) << 1);    // swizzle of this lane's staging row ...
   const int xr = (((fr >> 1) & 1) << 3) | ((fr >> 2) << 1);  // ... and of its fragment row
-  auto tile = [&](int s, int kt, bool load) __attribute__((always_inline)) {
+  // Software pipeline (one wavefront per SIMD: nothing else hides the LDS round trip of the staging tile): while the
+  // MFMAs of K-tile kt execute from one set of fragment registers, tile kt + 1 goes registers -> staging tile ->
+  // the other set, and the global loads of tile kt + 1 + BLK_PREFETCH are issued.
+  auto stage = [&](int s, int kt, bool load) __attribute__((always_inline)) {  // registers of stage s -> staging tiles; refill
 #pragma unroll
     for (int j = 0; j < NB; j++) {
       double *t = tb + j * BLK_TB;
@@ -173,28 +167,61 @@ __device__ __forceinline__ void blk_wave_tiles(const double *abuf, int S, const 
         gb[j][s][1] = *reinterpret_cast<const d2_t *>(pb[j] + kn * 16 + 8);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // LDS is in order within a wave
-    double af[4], bf[NB][4];
+  };
+  auto frags = [&](int kt, double (&af)[4], double (&bf)[NB][4]) __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the staging writes: LDS is in order within a wave)
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
       af[kk] = pa[kt * 16 + kk * 4];
 #pragma unroll
       for (int j = 0; j < NB; j++) bf[j][kk] = tb[j * BLK_TB + fr * 16 + ((kk * 4 + fk) ^ xr)];
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the tile is free again)
+  };
+  auto mfmas = [&](const double (&af)[4], const double (&bf)[NB][4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < 4; kk++)
 #pragma unroll
       for (int j = 0; j < NB; j++) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[j][kk], acc[j], 0, 0, 0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   };
-  int kt0 = 0;
-  for (; kt0 + BLK_PREFETCH <= nk; kt0 += BLK_PREFETCH) {
-#pragma unroll
-    for (int s = 0; s < BLK_PREFETCH; s++) tile(s, kt0 + s, true);
+  if (PIPE) {
+    double af0[4], bf0[NB][4], af1[4], bf1[NB][4];
+    stage(0, 0, true);
+    frags(0, af0, bf0);
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {  // tiles kt (set 0) and kt + 1 (set 1); set 0 leaves the loop holding tile kt + 2
+      stage(1, kt + 1, true);
+      mfmas(af0, bf0);
+      frags(kt + 1, af1, bf1);
+      stage(0, kt + 2, true);
+      mfmas(af1, bf1);
+      frags(kt + 2, af0, bf0);
+    }
+    if (kt + 1 < nk) {  // two tiles left (wave-uniform)
+      stage(1, kt + 1, false);
+      mfmas(af0, bf0);
+      frags(kt + 1, af1, bf1);
+      mfmas(af1, bf1);
+    } else {
+      mfmas(af0, bf0);
+    }
+  } else {
+    double af[4], bf[NB][4];
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+      stage(0, kt, true);
+      frags(kt, af, bf);
+      mfmas(af, bf);
+      stage(1, kt + 1, true);
+      frags(kt + 1, af, bf);
+      mfmas(af, bf);
+    }
+    if (kt < nk) {
+      stage(0, kt, false);
+      frags(kt, af, bf);
+      mfmas(af, bf);
+    }
   }
-#pragma unroll
-  for (int s = 0; s < BLK_PREFETCH - 1; s++)
-    if (kt0 + s < nk) tile(s, kt0 + s, false);  // wave-uniform
   // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
   for (int j = 0; j < NB; j++) {
@@ -207,15 +234,16 @@ __device__ __forceinline__ void blk_wave_tiles(const double *abuf, int S, const 
   }
 }
 // dst[16][S] = src[16][S] * Bp^T over the workgroup's BQ_WAVES wavefronts; the caller places the barriers
+template <int PIPE = 1>
 __device__ __forceinline__ void blk_gemm_lds4(const double *src, double *dst, int S, const double *Bp, long long D,
                                               int wave, int lane, double *tb) {
   const int NT = (int)((D + 15) / 16);
   const int nb = (NT - wave + BQ_WAVES - 1) / BQ_WAVES;  // this wavefront's blocks: wave, wave + 4, ...
   switch (nb) {
-    case 1: blk_wave_tiles<1>(src, S, Bp, NT * 16, D, wave * 16, BQ_WAVES, dst, S, lane, tb); break;
-    case 2: blk_wave_tiles<2>(src, S, Bp, NT * 16, D, wave * 16, BQ_WAVES, dst, S, lane, tb); break;
-    case 3: blk_wave_tiles<3>(src, S, Bp, NT * 16, D, wave * 16, BQ_WAVES, dst, S, lane, tb); break;
-    case 4: blk_wave_tiles<4>(src, S, Bp, NT * 16, D, wave * 16, BQ_WAVES, dst, S, lane, tb); break;
+    case 1: blk_wave_tiles<1, PIPE>(src, S, Bp, NT * 16, D, wave * 16, BQ_WAVES, dst, S, lane, tb); break;
+    case 2: blk_wave_tiles<2, PIPE>(src, S, Bp, NT * 16, D, wave * 16, BQ_WAVES, dst, S, lane, tb); break;
+    case 3: blk_wave_tiles<3, PIPE>(src, S, Bp, NT * 16, D, wave * 16, BQ_WAVES, dst, S, lane, tb); break;
+    case 4: blk_wave_tiles<4, PIPE>(src, S, Bp, NT * 16, D, wave * 16, BQ_WAVES, dst, S, lane, tb); break;
     default: break;
   }
 }
@@ -281,8 +309,12 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
 #define V_END_W(e) vec(wmd + 4 + NE + (e))
 #define V_SLOT_W(s) vec((s) ? wmd : wmd + 3 + NE)
   const size_t lvl = (size_t)a.C * D;  // checkpoint levels / transitions are C * D doubles apart
-  const int dlim = valid ? (int)D : 0;
-#define OK(r) (EI(r) < dlim)
+  // R = ceil(D / 16) exactly: the slots r < R - 1 are full, only the last one is predicated -- its loads go through a
+  // clamped offset (the lane's slot 0 where its last element is past D) and a select, so that no load sits in a branch
+  const bool okl = valid && EI(R - 1) < D;
+  const int lo = okl ? 16 * (R - 1) : 0;
+#define OK(r) ((r) < R - 1 || okl)
+#define LDG(ptr, r) ((r) < R - 1 ? (ptr)[16 * (r)] : (okl ? (ptr)[lo] : 0.0))
   // q, p, v and the sub-trajectory momentum sum in registers; dU/dq and w = imm dU/dq stay where the products leave
   // them, in the chain's rows of the two LDS buffers (dense target: P r lands in ybuf, imm g' in xbuf; coordinate-wise
   // target: g' is written to xbuf as the operand, imm g' lands in ybuf).
@@ -348,9 +380,9 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
         const double *kp = V_CKP + (size_t)tmax * lvl, *ks = V_CKS + (size_t)tmax * lvl, *kv = V_CKV + (size_t)tmax * lvl;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-          pfp[r] = OK(r) ? EL(kp, r) : 0.0;
-          pfv[r] = OK(r) ? EL(kv, r) : 0.0;
-          pfs[r] = OK(r) ? EL(ks, r) : 0.0;
+          pfp[r] = LDG(kp, r);
+          pfv[r] = LDG(kv, r);
+          pfs[r] = LDG(ks, r);
         }
         pf_kind = 1;
       }
@@ -360,9 +392,9 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
       const double *ep = V_END_P(oth), *ev = V_END_V(oth);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        pfp[r] = OK(r) ? EL(ep, r) : 0.0;
-        pfv[r] = OK(r) ? EL(ev, r) : 0.0;
-        pfs[r] = OK(r) ? EL(ps, r) : 0.0;
+        pfp[r] = LDG(ep, r);
+        pfv[r] = LDG(ev, r);
+        pfs[r] = LDG(ps, r);
       }
       pf_kind = 2;
     } else {
@@ -392,9 +424,9 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
       const double *ep = V_END_P(oth), *ev = V_END_V(oth);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        pfp[r] = OK(r) ? EL(ep, r) : 0.0;
-        pfv[r] = OK(r) ? EL(ev, r) : 0.0;
-        pfs[r] = OK(r) ? EL(ps, r) : 0.0;
+        pfp[r] = LDG(ep, r);
+        pfv[r] = LDG(ev, r);
+        pfs[r] = LDG(ps, r);
       }
     }
     // the state a change of direction continues from, requested before the scalars that decide whether it is needed
@@ -404,9 +436,9 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
       const double *oq = V_END_Q(oth), *og = V_END_G(oth), *ow = V_END_W(oth);
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        eq[r] = (may_go_on && OK(r)) ? EL(oq, r) : 0.0;
-        eg[r] = (may_go_on && OK(r)) ? EL(og, r) : 0.0;
-        ew[r] = (may_go_on && OK(r)) ? EL(ow, r) : 0.0;
+        eq[r] = may_go_on ? LDG(oq, r) : 0.0;
+        eg[r] = may_go_on ? LDG(og, r) : 0.0;
+        ew[r] = may_go_on ? LDG(ow, r) : 0.0;
       }
     }
     double *const dq = V_END_Q(dir), *const dp = V_END_P(dir), *const dg = V_END_G(dir), *const dv = V_END_V(dir),
@@ -505,9 +537,9 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
     double lp[R], lv[R], ls[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      lp[r] = (deeper && OK(r)) ? EL(ckp - lvl, r) : 0.0;
-      lv[r] = (deeper && OK(r)) ? EL(ckv - lvl, r) : 0.0;
-      ls[r] = (deeper && OK(r)) ? EL(cks - lvl, r) : 0.0;
+      lp[r] = deeper ? LDG(ckp - lvl, r) : 0.0;
+      lv[r] = deeper ? LDG(ckv - lvl, r) : 0.0;
+      ls[r] = deeper ? LDG(cks - lvl, r) : 0.0;
     }
     double us[4] = {0.0, 0.0, 0.0, 0.0}, ks[4] = {0.0, 0.0, 0.0, 0.0};
     double fl[4] = {0.0, 0.0, 0.0, 0.0}, fr[4] = {0.0, 0.0, 0.0, 0.0};
@@ -537,6 +569,7 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
         }
       }
     }
+    tm.tick(0);  // (timing build) vector pass
     if (TDENSE) ct.U_cur = target_finish(a, team_sum(us));
     const double kd = team_sum(ks);
     ct.tmin = tmin;
@@ -565,6 +598,7 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
       ct.length += 1;
     }
     if (do_take) take(ct.prop_slot ^ 1);  // sub-trajectory proposal <- moving end
+    tm.tick(1);  // (timing build) reductions, step scalars, accept draw, proposal copy
     if (f_turn) {  // termination.py:133-187: levels tmax, tmax - 1, ... tmin until one of them turns
       auto dots = [&](const double (&kp_)[R], const double (&kv_)[R], const double (&ks_)[R]) __attribute__((always_inline)) {
         double dl[4] = {0.0, 0.0, 0.0, 0.0}, dr[4] = {0.0, 0.0, 0.0, 0.0};
@@ -590,9 +624,9 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
           double xp[R], xv[R], xs[R];
 #pragma unroll
           for (int r = 0; r < R; r++) {
-            xp[r] = OK(r) ? EL(kp, r) : 0.0;
-            xv[r] = OK(r) ? EL(kv, r) : 0.0;
-            xs[r] = OK(r) ? EL(kss, r) : 0.0;
+            xp[r] = LDG(kp, r);
+            xv[r] = LDG(kv, r);
+            xs[r] = LDG(kss, r);
           }
           crit = dots(xp, xv, xs);
         }
@@ -702,11 +736,11 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
     const double *sq = V_SLOT_Q(s), *sg = V_SLOT_G(s), *sw = V_SLOT_W(s);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      q[r] = OK(r) ? EL(sq, r) : 0.0;
-      pfp[r] = OK(r) ? EL(sg, r) : 0.0;
-      pfv[r] = (!last && OK(r)) ? EL(sw, r) : 0.0;
-      p[r] = OK(r) ? EL(pn, r) : 0.0;
-      v[r] = (!last && OK(r)) ? EL(vn, r) : 0.0;
+      q[r] = LDG(sq, r);
+      pfp[r] = LDG(sg, r);
+      pfv[r] = !last ? LDG(sw, r) : 0.0;
+      p[r] = LDG(pn, r);
+      v[r] = !last ? LDG(vn, r) : 0.0;
     }
     run = false;
     pending = true;
@@ -759,9 +793,9 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
     double *const sq = V_SLOT_Q(0), *const sg = V_SLOT_G(0), *const sw = V_SLOT_W(0);
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      q[r] = OK(r) ? EL(iq, r) : 0.0;
-      p[r] = OK(r) ? EL(ip, r) : 0.0;
-      v[r] = OK(r) ? EL(iv, r) : 0.0;
+      q[r] = LDG(iq, r);
+      p[r] = LDG(ip, r);
+      v[r] = LDG(iv, r);
       if (OK(r)) {
         const double g0 = EL(ig, r), w0 = EL(iw, r);
         grow[EI(r)] = g0;
@@ -826,6 +860,7 @@ __global__ __launch_bounds__(BQ_THREADS) void k_nuts_block_flow(EngineArgs a, Nu
 #undef EI
 #undef EL
 #undef OK
+#undef LDG
 #undef COLD
 #undef V_END_Q
 #undef V_END_P
@@ -878,11 +913,21 @@ inline hipError_t launch_nuts_block_flow(EngineArgs a, NutsSampleArgs m, const B
   BlkMats mats;
   if (hipError_t e = blk_pack_matrices(a, m.prec, bp, mats, st)) return e;
   a.imm = mats.imm; a.sqrt_mass = mats.sqrt_mass; m.prec = mats.prec;
-  if (a.D <= 112) return launch_nuts_block_flow_r<7>(a, m, f, st);
-  if (a.D <= 128) return launch_nuts_block_flow_r<8>(a, m, f, st);
-  if (a.D <= 160) return launch_nuts_block_flow_r<10>(a, m, f, st);
-  if (a.D <= 208) return launch_nuts_block_flow_r<13>(a, m, f, st);
-  return launch_nuts_block_flow_r<16>(a, m, f, st);
+  switch ((int)((a.D + 15) / 16)) {  // elements per lane, exactly
+    case 5: return launch_nuts_block_flow_r<5>(a, m, f, st);
+    case 6: return launch_nuts_block_flow_r<6>(a, m, f, st);
+    case 7: return launch_nuts_block_flow_r<7>(a, m, f, st);
+    case 8: return launch_nuts_block_flow_r<8>(a, m, f, st);
+    case 9: return launch_nuts_block_flow_r<9>(a, m, f, st);
+    case 10: return launch_nuts_block_flow_r<10>(a, m, f, st);
+    case 11: return launch_nuts_block_flow_r<11>(a, m, f, st);
+    case 12: return launch_nuts_block_flow_r<12>(a, m, f, st);
+    case 13: return launch_nuts_block_flow_r<13>(a, m, f, st);
+    case 14: return launch_nuts_block_flow_r<14>(a, m, f, st);
+    case 15: return launch_nuts_block_flow_r<15>(a, m, f, st);
+    case 16: return launch_nuts_block_flow_r<16>(a, m, f, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace aehmc
