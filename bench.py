@@ -48,6 +48,51 @@ def lib_sha256():
     return _LIB_SHA
 
 
+LINE_LIMIT = 8000  # the driver keeps about this much of stdout's tail: the WHOLE line, secondaries included, must fit
+
+
+def compact(obj, verbose=False):
+    """The JSON line without prose: `note` / `parity_note` strings (DESIGN.md section 4 has them) and null-valued keys of
+    nested objects are dropped, floats keep 6 significant digits.  `--verbose` prints everything."""
+    if verbose:
+        return obj
+
+    def walk(x, top):
+        if isinstance(x, dict):
+            out = {}
+            for k, v in x.items():
+                if k in ("note", "parity_note"):
+                    continue
+                if v is None and not top:
+                    continue
+                out[k] = walk(v, False)
+            return out
+        if isinstance(x, list):
+            return [walk(v, False) for v in x]
+        if isinstance(x, float):
+            return float(f"{x:.6g}")
+        return x
+    return walk(obj, True)
+
+
+def emit(obj, verbose=False):
+    """Print THE line.  Should it still exceed LINE_LIMIT, the secondaries lose their least important keys first --
+    never their value / frac -- so that the driver's record holds every number."""
+    obj = compact(obj, verbose)
+    line = json.dumps(obj, separators=(",", ":"))
+    if not verbose and len(line) > LINE_LIMIT and obj.get("secondary"):
+        for drop in ("workload", "traffic_source", "counters", "hbm", "valu", "fp64_flops", "launches", "avg_launch_ms"):
+            for e in obj["secondary"]:
+                e.pop(drop, None)
+                if isinstance(e.get("roofline"), dict):
+                    e["roofline"].pop(drop, None)
+            line = json.dumps(obj, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+    print(line)
+    return line
+
+
 PMC_STALE = {}  # summary name -> why its counters were NOT used in this run's line
 
 
@@ -59,7 +104,7 @@ def pmc_summary(name):
     profiles/rN/<name>, and only if it was measured on the very binary this run loads -- every summary stores the
     sha256 of the libaehmc_hip.so it profiled (`lib_sha256`); one without it, or with another hash, is NOT used:
     peak / frac / traffic derived from it are dropped from the line and `counters_dropped` says why."""
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         path = os.path.join(PROFILES_DIR, rnd, name)
         if os.path.exists(path):
             summ = json.load(open(path))
@@ -69,7 +114,7 @@ def pmc_summary(name):
                                    f"(summary: {str(have)[:16]}, loaded: {lib_sha256()[:16]}): counter-derived "
                                    "peak / frac / traffic dropped")
                 return None, None
-            return summ, f"profiles/{rnd}/{name} (separate rocprofv3 --pmc passes of the same workload, lib_sha256 {have[:16]})"
+            return summ, f"profiles/{rnd}/{name}"  # (separate rocprofv3 --pmc passes of the same workload, same lib_sha256)
     PMC_STALE[name] = f"no profiles/rN/{name}"
     return None, None
 
@@ -242,12 +287,15 @@ def dense_mid_secondary(eng, device, C=4096, T=10):
                     "launches": 1, "avg_launch_ms": best * 1e3, "traffic": None,
                     "note": "4 D^2 flop per leapfrog and chain; every chain of a 16-chain workgroup steps through its own "
                             "tree, so the products of a round also carry the rows of chains that have finished"}
-            if D == 200:
-                pmc, src = pmc_summary(os.path.join("dense", "mid200_pmc_summary.json"))
-                if pmc:
-                    roof["counters"] = {"mfma_busy_fraction": pmc["derived"]["mfma_busy_fraction"],
-                                        "wait_any_fraction_of_wave_cycles": pmc["derived"]["wait_any_frac"], "source": src}
-                roof["counters_dropped"] = PMC_STALE.get(os.path.join("dense", "mid200_pmc_summary.json"))
+            name = os.path.join("dense", f"mid{D}_pmc_summary.json")
+            pmc, src = pmc_summary(name)
+            if pmc:  # (separate rocprofv3 --pmc passes of tools/debug/mid_dense.py D 4096 10: the same call)
+                dv = pmc["derived"]
+                roof["traffic"] = dv.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = src
+                roof["counters"] = {"mfma_busy_fraction": dv["mfma_busy_fraction"],
+                                    "wait_any_fraction_of_wave_cycles": dv["wait_any_frac"]}
+            roof["counters_dropped"] = PMC_STALE.get(name)
             out.append({"config": f"dense-nuts-d{D}",
                         "workload": f"{D}-dim correlated MVN (dense precision), dense inverse mass matrix, NUTS depth 10, {C} chains, "
                                     f"sample({T}) in one launch",
@@ -339,6 +387,8 @@ def main():
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the diagonal-mass secondary lines")
+    ap.add_argument("--verbose", action="store_true", help="print the line with its explanatory `note` strings (longer than "
+                                                           "the driver's stdout tail keeps)")
     ap.add_argument("--fp-contract", action="store_true",
                     help="engine option fp_contract=1: fast arithmetic in the leapfrog bodies of the register-resident HMC "
                          "kernels (1e-6 relative instead of bit parity with the oracle; c2 and the diagonal-mass HMC line)")
@@ -500,25 +550,29 @@ def main():
         if not (pj and D == 100 and C == 4096):
             pj, src = None, None
         flop_rate = value / world * 9.0 * D / 1e12  # ~9 D flop per leapfrog
-        roofline = {"bound": "valu", "unit": "leapfrog-steps/s", "kernel": "k_hmc_fused", "avg_launch_ms": avg_s * 1e3,
-                    "launches": kern_n, "achieved": value / world, "peak": None, "frac": None, "traffic": None,
+        # `frac` is against SURVEY.md 8d's FIXED ceiling -- 9 D flop per leapfrog against the fp64 vector peak -- so that it
+        # measures efficiency; the ceiling derived from the kernel's own counted instructions (how stall-free the issue is)
+        # is reported beside it as valu.issue_ceiling / valu.issue_frac (round 4 printed that one as `frac`).
+        roofline = {"bound": "valu", "unit": "TFLOP/s", "kernel": "k_hmc_fused", "avg_launch_ms": avg_s * 1e3,
+                    "launches": kern_n, "achieved": flop_rate, "peak": PEAK_FP64_VALU_TFLOPS,
+                    "frac": flop_rate / PEAK_FP64_VALU_TFLOPS, "flop_per_leapfrog": 9.0 * D, "traffic": None,
                     "traffic_source": src, "counters_dropped": PMC_STALE.get(c2_name),
-                    "fp64_flops": {"achieved": flop_rate, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": flop_rate / PEAK_FP64_VALU_TFLOPS,
-                                   "note": "9 D flop per leapfrog (SURVEY.md 8d) against the fp64 vector peak"}}
+                    "note": "9 D flop per leapfrog (SURVEY.md 8d) against the fp64 vector peak"}
         if pj:
             d = pj["derived"]
             ceil = d["valu_issue_ceiling_leapfrogs_per_s_at_this_instruction_count"]
             roofline.update({
-                "peak": ceil, "frac": value / world / ceil, "traffic": d["hbm_bytes_per_launch"],
+                "traffic": d["hbm_bytes_per_launch"],
                 "hbm": {"achieved": d["hbm_bytes_per_launch"] / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": d["hbm_bytes_per_launch"] / avg_s / 1e9 / PEAK_HBM_GBS,
                         "note": "q, dU/dq in and out once per launch of 100 transitions: HBM is idle"},
-                "valu": {"instructions_per_wave_per_transition": d["valu_instructions_per_wave_per_transition"],
+                "valu": {"issue_ceiling": ceil, "issue_frac": value / world / ceil, "unit": "leapfrog-steps/s",
+                         "instructions_per_wave_per_transition": d["valu_instructions_per_wave_per_transition"],
                          "leapfrog_fp64_instructions_per_transition": d["leapfrog_fp64_instructions_per_transition"],
-                         "busy_fraction_rocprof": d["valu_busy_fraction_of_kernel_time_at_2.4GHz"]},
-                "note": "one wavefront per chain, 4 per SIMD; a 64-lane fp64 VALU instruction occupies its 16-lane SIMD for "
-                        "4 cycles; peak = the issue ceiling at the counted instruction count, frac = achieved / peak"})
+                         "busy_fraction_rocprof": d["valu_busy_fraction_of_kernel_time_at_2.4GHz"],
+                         "note": "one wavefront per chain, 4 per SIMD; a 64-lane fp64 VALU instruction occupies its 16-lane "
+                                 "SIMD for 4 cycles; issue_ceiling = 1024 SIMDs x 2.4 GHz / (4 waves x 4 cycles x counted "
+                                 "instructions per wave and transition)"}})
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -531,7 +585,7 @@ def main():
         secondary += dense_mid_secondary(eng, device)
         secondary += other_configs()
 
-    print(json.dumps({
+    emit({
         "metric": "leapfrog-steps/sec across all chains", "value": value, "unit": "leapfrog-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -542,7 +596,7 @@ def main():
                    "leapfrogs_per_step": total_leap / args.steps, "ranks_seen": ranks_seen,
                    "gather": {"to": "rank 0", "bytes": (world - 1) * C * D * 8, "ms": t_g * 1e3,
                               "backend": dist_backend, "rows_match_ranks_bitwise": rows_match}},
-        "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}))
+        "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary}, args.verbose)
 
 
 def bench_c1(args):
@@ -589,14 +643,14 @@ def bench_c1(args):
                          "valu_instructions_per_leapfrog": d["valu_instructions_per_leapfrog"],
                          "salu_instructions_per_leapfrog": d["salu_instructions_per_leapfrog"],
                          "clock_GHz_during_the_profiled_launch": d.get("clock_GHz_grbm")})
-    print(json.dumps({
+    emit({
         "metric": "leapfrog-steps/sec across all chains", "value": nl / dt, "unit": "leapfrog-steps/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "c1: README example, 1-D standard normal, NUTS, step_size=1e-2, single chain",
                    "position": pos, "matches_readme_value": pos == 1.1034719409361107, "leapfrogs": nl,
                    "lib_sha256": lib_sha256()},
-        "roofline": roofline, "cpu_baseline": None}))
+        "roofline": roofline, "cpu_baseline": None}, args.verbose)
 
 
 def bench_c5(args, rank, world, device):
@@ -658,7 +712,7 @@ def bench_c5(args, rank, world, device):
                     "note": "3 FMAs per row, chain and leapfrog against the fp64 vector peak; the sweep of a 4-chain "
                             "workgroup also pulls 16 B per row through its CU's 64 B/clk vector-memory path (rows beyond "
                             "the 10176 kept in LDS), which bounds a sweep at about the same time as the FMAs: DESIGN.md"}
-        print(json.dumps({
+        emit({
             "metric": "leapfrog-steps/sec across all chains", "value": rate, "unit": "leapfrog-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -666,7 +720,7 @@ def bench_c5(args, rank, world, device):
                                    f"window-adaptation steps ({t_w:.2f} s, one launch), {C} chains/GPU",
                        "chains_total": chains_total, "data_rows_per_s": rate * N,
                        "leapfrogs_per_step": total / args.steps},
-            "roofline": roofline, "cpu_baseline": cpu}))
+            "roofline": roofline, "cpu_baseline": cpu}, args.verbose)
 
 
 def cpu_baseline_c5(X, y, info, eps, imm):

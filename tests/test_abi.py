@@ -190,3 +190,26 @@ def test_random_stream_from_state_for_a_later_kernel_and_dtype_checks():
     for bad in (np.zeros((1, 2, 4)), np.zeros((1, 2, 4), dtype=np.int32), [[[2 ** 64, 0, 0, 0], [0, 0, 0, 0]]]):
         with pytest.raises(ValueError):
             RandomStream.from_state(bad)
+
+
+def test_bench_line_fits_the_drivers_stdout_tail(capsys):
+    """The driver keeps ~8 kB of bench.py's stdout: the whole JSON line -- all secondary entries with their values and
+    roofline fractions -- has to fit.  Round 4's line (13 kB with its `note` strings: profiles/r4/bench_default.json)
+    goes through bench.emit() and must come out below the limit with every number still in it."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r4", "bench_default.json")))
+    assert len(json.dumps(full)) > bench.LINE_LIMIT  # (the fixture is a line that did NOT fit)
+    line = bench.emit(full)
+    assert len(line) < bench.LINE_LIMIT, len(line)
+    got = json.loads(line)
+    assert capsys.readouterr().out.strip() == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in got, k  # the contract's keys survive (vs_baseline: null stays)
+    assert got["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
+    assert [e["config"] for e in got["secondary"]] == [e["config"] for e in full["secondary"]]
+    for e, f in zip(got["secondary"], full["secondary"]):
+        assert e["value"] == pytest.approx(f["value"], rel=1e-5) and "frac" in e["roofline"]
+    assert "note" not in line
+    assert len(bench.emit(full, verbose=True)) > bench.LINE_LIMIT  # --verbose keeps the prose
