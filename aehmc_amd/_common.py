@@ -66,6 +66,9 @@ def new_state(q, logprob_fn, num_chains=None) -> IntegratorState:
         # new_state needs no metric; bind a unit one so that the ctx is complete
         eng.set_metric(torch.ones(layout.D, dtype=torch.float64, device=eng.device), layout.D)
     eng.ensure_workspace(layout.C, 1)
+    if not getattr(logprob_fn, "gradient_checked", True):  # a hand-written gradient: verified where it is first evaluated
+        eng.check_gradient(rows)
+        logprob_fn.gradient_checked = True
     U, g = eng.new_state(rows)
     return IntegratorState(position=layout.vec(rows), momentum=None,
                            potential_energy=layout.per_chain(U),

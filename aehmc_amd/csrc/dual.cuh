@@ -1,0 +1,147 @@
+// Forward-mode differentiation of user-defined log-densities (gfx950; also compiles as plain C++ for the CPU tests).
+//
+// The reference takes any `logprob_fn` and differentiates it symbolically (aehmc/hmc.py:33-34: aesara.grad of the
+// potential; integrators.py:61-65).  Here the user writes the log-density ONCE, as a function template over its
+// arithmetic type, and the engine instantiates it with `aehmc::Dual` (value + one directional derivative) inside the
+// run-time compiled kernels:
+//   * coordinate-wise targets (targets.Custom):    template <class T> T aehmc_logp(T q, long long i, const double *const *prm)
+//     -- coordinate i's term; one Dual evaluation per element gives u_i = -logp_i and du_i/dq_i;
+//   * row-reduction targets (targets.CustomGLM):   template <class T> T aehmc_glm_loglik(T z, double y, long long n, prm)
+//                                                  template <class T> T aehmc_glm_logprior(T q, long long i, prm);
+//   * joint (non-separable) targets, D <= 64 (targets.CustomJoint):
+//                                                  template <class V> auto aehmc_logp(const V &q, const double *const *prm)
+//     with q[i] the coordinates and q.size() their number: lane i of the chain's wavefront holds q_i and evaluates the
+//     density with the derivative seeded at ITS coordinate -- the D forward passes of the gradient run side by side
+//     in the lanes, every lane ends with the same value and with dlogp/dq_lane (JointArg below).
+// Supported: + - * / (Dual with Dual or double), unary -, comparisons (on the value), exp, log, log1p, expm1, sqrt,
+// pow(x, double), pow(x, y), sin, cos, tanh, fabs, erf, lgamma is NOT (no digamma on the device), square(x).
+#pragma once
+#if defined(__HIPCC_RTC__) || defined(__HIPCC__)
+#ifndef __HIPCC_RTC__  /* (hipRTC supplies the runtime and the math functions itself) */
+#include <hip/hip_runtime.h>
+#endif
+#define AEHMC_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#include <cmath>
+#define AEHMC_HD inline
+#endif
+
+namespace aehmc {
+namespace ad {  // (its own namespace: found by argument-dependent lookup from user code, invisible to the engine's own exp / log1p calls)
+
+struct Dual {
+  double v, d;
+  AEHMC_HD Dual() : v(0.0), d(0.0) {}
+  AEHMC_HD Dual(double value) : v(value), d(0.0) {}  // a constant
+  AEHMC_HD Dual(double value, double deriv) : v(value), d(deriv) {}
+};
+
+AEHMC_HD Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+AEHMC_HD Dual operator+(Dual a) { return a; }
+AEHMC_HD Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+AEHMC_HD Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+AEHMC_HD Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
+AEHMC_HD Dual operator/(Dual a, Dual b) {
+  const double q = a.v / b.v;
+  return Dual(q, (a.d - q * b.d) / b.v);
+}
+AEHMC_HD Dual operator+(Dual a, double b) { return Dual(a.v + b, a.d); }
+AEHMC_HD Dual operator+(double a, Dual b) { return Dual(a + b.v, b.d); }
+AEHMC_HD Dual operator-(Dual a, double b) { return Dual(a.v - b, a.d); }
+AEHMC_HD Dual operator-(double a, Dual b) { return Dual(a - b.v, -b.d); }
+AEHMC_HD Dual operator*(Dual a, double b) { return Dual(a.v * b, a.d * b); }
+AEHMC_HD Dual operator*(double a, Dual b) { return Dual(a * b.v, a * b.d); }
+AEHMC_HD Dual operator/(Dual a, double b) { return Dual(a.v / b, a.d / b); }
+AEHMC_HD Dual operator/(double a, Dual b) {
+  const double q = a / b.v;
+  return Dual(q, -q * b.d / b.v);
+}
+AEHMC_HD Dual &operator+=(Dual &a, Dual b) { a = a + b; return a; }
+AEHMC_HD Dual &operator-=(Dual &a, Dual b) { a = a - b; return a; }
+AEHMC_HD Dual &operator*=(Dual &a, Dual b) { a = a * b; return a; }
+AEHMC_HD Dual &operator/=(Dual &a, Dual b) { a = a / b; return a; }
+AEHMC_HD Dual &operator+=(Dual &a, double b) { a.v += b; return a; }
+AEHMC_HD Dual &operator-=(Dual &a, double b) { a.v -= b; return a; }
+AEHMC_HD Dual &operator*=(Dual &a, double b) { a = a * b; return a; }
+AEHMC_HD Dual &operator/=(Dual &a, double b) { a = a / b; return a; }
+#define AEHMC_DUAL_CMP(op)                                            \
+  AEHMC_HD bool operator op(Dual a, Dual b) { return a.v op b.v; }    \
+  AEHMC_HD bool operator op(Dual a, double b) { return a.v op b; }    \
+  AEHMC_HD bool operator op(double a, Dual b) { return a op b.v; }
+AEHMC_DUAL_CMP(<)
+AEHMC_DUAL_CMP(>)
+AEHMC_DUAL_CMP(<=)
+AEHMC_DUAL_CMP(>=)
+AEHMC_DUAL_CMP(==)
+AEHMC_DUAL_CMP(!=)
+#undef AEHMC_DUAL_CMP
+
+// elementary functions; the double overloads let one template body serve both instantiations
+AEHMC_HD double square(double x) { return x * x; }
+AEHMC_HD Dual square(Dual x) { return Dual(x.v * x.v, 2.0 * x.v * x.d); }
+AEHMC_HD Dual exp(Dual x) {
+  const double e = ::exp(x.v);
+  return Dual(e, e * x.d);
+}
+AEHMC_HD Dual expm1(Dual x) { return Dual(::expm1(x.v), ::exp(x.v) * x.d); }
+AEHMC_HD Dual log(Dual x) { return Dual(::log(x.v), x.d / x.v); }
+AEHMC_HD Dual log1p(Dual x) { return Dual(::log1p(x.v), x.d / (1.0 + x.v)); }
+AEHMC_HD Dual sqrt(Dual x) {
+  const double s = ::sqrt(x.v);
+  return Dual(s, 0.5 * x.d / s);
+}
+AEHMC_HD Dual pow(Dual x, double p) { return Dual(::pow(x.v, p), p * ::pow(x.v, p - 1.0) * x.d); }
+AEHMC_HD Dual pow(Dual x, Dual y) {
+  const double f = ::pow(x.v, y.v);
+  return Dual(f, f * (y.d * ::log(x.v) + y.v * x.d / x.v));
+}
+AEHMC_HD Dual sin(Dual x) { return Dual(::sin(x.v), ::cos(x.v) * x.d); }
+AEHMC_HD Dual cos(Dual x) { return Dual(::cos(x.v), -::sin(x.v) * x.d); }
+AEHMC_HD Dual tanh(Dual x) {
+  const double t = ::tanh(x.v);
+  return Dual(t, (1.0 - t * t) * x.d);
+}
+AEHMC_HD Dual fabs(Dual x) { return x.v < 0 ? -x : x; }
+AEHMC_HD Dual erf(Dual x) { return Dual(::erf(x.v), 1.1283791670955126 * ::exp(-x.v * x.v) * x.d); }
+// log(1 + exp(x)) without overflow (the logistic log-likelihood's building block) and the logistic function
+AEHMC_HD double softplus(double x) { return x > 0 ? x + ::log1p(::exp(-x)) : ::log1p(::exp(x)); }
+AEHMC_HD Dual softplus(Dual x) { return Dual(softplus(x.v), x.d / (1.0 + ::exp(-x.v))); }
+AEHMC_HD double value_of(double x) { return x; }
+AEHMC_HD double value_of(Dual x) { return x.v; }
+
+}  // namespace ad
+using ad::Dual;
+
+#if defined(__HIPCC_RTC__) || defined(__HIPCC__)
+// The coordinates of a chain as a joint density sees them: lane i of the wavefront holds q_i in `ql` (D <= 64).
+// JointArg<Dual>::operator[](i) is q_i with derivative 1 in the lane that owns coordinate i (0 elsewhere): after one
+// evaluation of the density every lane holds logp (the same bits) and dlogp/dq_lane.  Indices must be uniform over the
+// wavefront -- they are in any density: its control flow depends on values, which are the same in every lane.
+__device__ inline __attribute__((always_inline)) double joint_lane_read(double x, int i) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), i), __builtin_amdgcn_readlane(__double2loint(x), i));
+}
+template <class T>
+struct JointArg;
+template <>
+struct JointArg<double> {
+  double ql;
+  int lane, D;
+  __device__ inline __attribute__((always_inline)) double operator[](int i) const { return joint_lane_read(ql, i); }
+  __device__ inline __attribute__((always_inline)) int size() const { return D; }
+};
+template <>
+struct JointArg<Dual> {
+  double ql;
+  int lane, D;
+  __device__ inline __attribute__((always_inline)) Dual operator[](int i) const { return Dual(joint_lane_read(ql, i), i == lane ? 1.0 : 0.0); }
+  __device__ inline __attribute__((always_inline)) int size() const { return D; }
+};
+#endif
+
+}  // namespace aehmc
+
+// unqualified calls in user code (exp(x), log1p(x), ...) with x a Dual resolve by argument-dependent lookup; for T =
+// double they are the device library's own functions
+using aehmc::ad::square;
+using aehmc::ad::softplus;
+using aehmc::ad::value_of;

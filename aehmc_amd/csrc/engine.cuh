@@ -225,6 +225,16 @@ __device__ __forceinline__ void target_elem(const EngineArgs &a, long long i, do
     }
   }
 }
+#ifdef AEHMC_JOINT_TARGET  // run-time compiled copy (aehmc_set_custom_joint_target): the user's joint log-density
+// Wave-wide evaluation (D <= 64): lane i holds q_i; returns U = -logp (the same bits in every lane) and this lane's
+// dU/dq_i -- forward mode, the derivative seeded at the lane's own coordinate (dual.cuh: JointArg<Dual>).
+__device__ __forceinline__ double target_joint(const EngineArgs &a, int lane, int D, double q, double &g) {
+  const JointArg<Dual> arg{q, lane, D};
+  const Dual r = aehmc_logp(arg, a.cparams);
+  g = -r.d;
+  return -r.v;
+}
+#endif
 __device__ __forceinline__ double target_finish(const EngineArgs &a, double usum) {
   return (a.tkind == AEHMC_T_ISO_GAUSSIAN || a.tkind == AEHMC_T_DENSE_MVN) ? 0.5 * usum : usum;
 }
@@ -871,6 +881,13 @@ __device__ __forceinline__ double leap_small_dense(const EngineArgs &a, long lon
   const double v = MD ? wave_matvec_reg(immW, p, D, lane) : vel_diag(a, c, il, p);
   q = q + aa * v;
   double u;
+#ifdef AEHMC_JOINT_TARGET
+  if (!TD && a.tkind == AEHMC_T_JOINT) {  // the whole density in one wave-wide evaluation
+    const double U = target_joint(a, lane, D, q, g);
+    p = p - b * g;
+    return U;
+  }
+#endif
   if (TD) {
     const double r = q - a.mu[il];
     g = wave_matvec_reg(PT, r, D, lane);  // dU/dq = P r
@@ -1190,6 +1207,17 @@ AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_new_state_elem(EngineArg
   usum = wave_sum(usum);
   if (lane == 0) a.U[c] = target_finish(a, usum);
 }
+#ifdef AEHMC_JOINT_TARGET
+__global__ __launch_bounds__(256) void k_new_state_joint(EngineArgs a) {  // hmc.py:16-40 for a joint target
+  AEHMC_CHAIN_OF_WAVE();
+  const int D = (int)a.D;
+  const bool on = lane < D;
+  double g = 0.0;
+  const double U = target_joint(a, lane, D, on ? a.q[c * a.D + lane] : 0.0, g);
+  if (on) a.g[c * a.D + lane] = g;
+  if (lane == 0) a.U[c] = U;
+}
+#endif
 AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_residual(EngineArgs a, const double *q, double *r) {
   AEHMC_CHAIN_OF_WAVE();
   const size_t row = (size_t)c * a.D;

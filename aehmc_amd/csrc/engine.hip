@@ -250,15 +250,19 @@ static const char *RTC_PROLOGUE =
     "#define INFINITY __builtin_huge_val()\n";
 static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vector<std::string> &names,
                         const std::string &want, hipFunction_t *out) {
-  const std::string key = which + "|" + ((which == "base" || which == "glm") ? std::string() : want);
+  // "j*": the programs of a joint target (engine.cuh: AEHMC_JOINT_TARGET) -- "jbase" new_state, "jnuts" / "jhmc" one
+  // instantiation of the small-problem kernels each
+  const bool joint = which[0] == 'j';
+  const std::string key = which + "|" + ((which == "base" || which == "glm" || which == "jbase") ? std::string() : want);
   auto it = ctx->rtc.find(key);
   if (it == ctx->rtc.end()) {
     if (ctx->custom_src.empty()) FAIL("internal: no user-defined target source");
     std::string src = RTC_PROLOGUE;
-    if (which != "glm") src += "#define AEHMC_CUSTOM_TARGET 1\n";  // (engine.cuh: target_elem calls aehmc_custom_elem)
+    if (joint) src += "#define AEHMC_JOINT_TARGET 1\n";  // (engine.cuh: leap_small_dense calls aehmc_logp through dual.cuh)
+    else if (which != "glm") src += "#define AEHMC_CUSTOM_TARGET 1\n";  // (engine.cuh: target_elem calls aehmc_custom_elem)
     src += "#line 1 \"custom_target\"\n" + ctx->custom_src + "\n";
     src += "#include \"engine.cuh\"\n";
-    if (which == "nuts") src += "#include \"nuts_resident.cuh\"\n";
+    if (which == "nuts" || which == "jnuts") src += "#include \"nuts_resident.cuh\"\n";
     if (which == "hmc") src += "#include \"hmc_fused.cuh\"\n";
     if (which == "glm") src += "#include \"glm_rows.cuh\"\n";
     hiprtcProgram prog;
@@ -398,6 +402,22 @@ extern "C" int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, i
   ctx->glm_X = X; ctx->glm_y = y; ctx->glm_N = N;
   aehmc_target t{};
   t.kind = AEHMC_T_GLM;
+  t.D = D;
+  ctx->tgt = t;
+  ctx->has_tgt = true;
+  return 0;
+}
+
+static const std::vector<std::string> RTC_JBASE = {"aehmc::k_new_state_joint"};
+extern "C" int aehmc_set_custom_joint_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
+                                             int32_t n_params, const char *include_dir) {
+  if (!ctx || !source || !include_dir) return -2;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (D <= 0 || D > FUSED_DENSE_MAX_D)
+    FAIL("joint target: D must be in [1, " + std::to_string(FUSED_DENSE_MAX_D) + "] (one coordinate per lane of the chain's wavefront)");
+  if (int rc = custom_bind(ctx, source, include_dir, params, n_params, "jbase", RTC_JBASE)) return rc;
+  aehmc_target t{};
+  t.kind = AEHMC_T_JOINT;
   t.D = D;
   ctx->tgt = t;
   ctx->has_tgt = true;
@@ -1077,6 +1097,13 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
     LAUNCH_T("aehmc::k_new_state_elem", k_new_state_elem, C, st, a);
     return 0;
   }
+  if (ctx->has_tgt && ctx->tgt.kind == AEHMC_T_JOINT) {
+    memset(&a, 0, sizeof(a));
+    a.C = C; a.D = ctx->tgt.D; a.tkind = ctx->tgt.kind;
+    a.cparams = ctx->d_cparams;
+    a.q = const_cast<double *>(q); a.U = U; a.g = g;
+    return rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[0], chain_grid(C), dim3(256), 0, st, a);
+  }
   if (int rc = fill_args(ctx, C, 1, a, false)) return rc;
   if (a.tkind == AEHMC_T_DENSE_MVN) {
     LAUNCH(k_residual, C, st, a, q, a.rbuf);
@@ -1133,6 +1160,7 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
+  if (want_resident && tkind == AEHMC_T_JOINT) return NUTS_PATH_FUSED_DENSE;  // (run-time compiled, D <= 64)
   if (want_resident && nuts_resident_dense_supported(tkind, nd, D))
     return NUTS_PATH_FUSED_DENSE;  // (per-chain dense metrics included: each wavefront reads its own matrices)
   // mid-size dense problems (shared dense metric, 64 < D <= 512, linear dense mode): a workgroup per 16 chains runs
@@ -1214,7 +1242,17 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       if (int rc = fused_dense_workspace(ctx, (size_t)C * a.D * a.D * sizeof(double), &m.imm_ws)) return rc;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    HIPCHK(tu::nuts_resident_dense(a, m, st, md, td, pc));
+    if (a.tkind == AEHMC_T_JOINT) {  // the same kernel, compiled against the user's density (DENSE bit 8: joint target)
+      const int dense = (md ? RES_DENSE_METRIC : 0) | (pc ? RES_DENSE_PER_CHAIN : 0) | RES_DENSE_JOINT;
+      const bool mlt = m.T > 1 || m.samples || m.acc_hist || m.div_hist || m.nleap_total || m.adapt;
+      const std::string name = "aehmc::k_nuts_resident<64, 1, " + std::string(mlt ? "true" : "false") + ", " +
+                               std::to_string(dense) + ", false>";
+      const size_t dyn = (size_t)(md && !pc ? 2 : 0) * a.D * a.D * sizeof(double);
+      const unsigned grid = (unsigned)((C + RES_DENSE_BLOCK / 64 - 1) / (RES_DENSE_BLOCK / 64));
+      if (int rc = rtc_launch(ctx, "jnuts", {name}, name, dim3(grid), dim3(RES_DENSE_BLOCK), dyn, st, a, m)) return rc;
+    } else {
+      HIPCHK(tu::nuts_resident_dense(a, m, st, md, td, pc));
+    }
     return prof_end(ctx, st, p);
   }
   if (path == NUTS_PATH_BLOCK_DENSE) {  // mid-size dense problems: every transition of the call in one launch
@@ -1235,6 +1273,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     else HIPCHK(tu::nuts_block_dense(a, m, bp, st));
     return prof_end(ctx, st, p);
   }
+  if (a.tkind == AEHMC_T_JOINT) FAIL("joint targets run on the single-launch kernels only (option resident_nuts must not be 0)");
   if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
@@ -1520,9 +1559,11 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   a.q = q; a.U = U; a.g = g; a.out = *out;
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): the transition in one
   // launch with the products inside the wavefront (k_hmc_fused_dense), as for NUTS
+  const bool tjoint = a.tkind == AEHMC_T_JOINT;
+  if (tjoint && !ctx->opt_fused_hmc) FAIL("joint targets run on the single-launch kernels only (option fused_hmc must not be 0)");
   const bool fused_dense = ctx->opt_fused_hmc && D <= FUSED_DENSE_MAX_D &&
-                           (a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN) &&
-                           (target_is_elem_host(a.tkind) || a.tkind == AEHMC_T_DENSE_MVN);
+                           (tjoint || ((a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN) &&
+                                       (target_is_elem_host(a.tkind) || a.tkind == AEHMC_T_DENSE_MVN)));
   if (fused_dense) {  // all T transitions in one launch
     const bool md = a.met_ndim == 2, td = a.tkind == AEHMC_T_DENSE_MVN, pc = md && ctx->met.per_chain;
     EngineArgs b = a;
@@ -1541,7 +1582,14 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     hipLaunchKernelGGL((k_hmc_fused_dense<MDV, TDV, PCV>), grid, block, dyn, st, b, ctx->tgt.prec, imm_ws,      \
                        (long long)L, (long long)T, samples, acc_hist, (int *)div_hist);                        \
   } while (0)
-    if (md && td && pc) AEHMC_FD_LAUNCH(true, true, true);
+    if (tjoint) {  // the same kernel, compiled against the user's density
+      const std::string name = "aehmc::k_hmc_fused_dense<" + std::string(md ? "true" : "false") + ", false, " +
+                               (pc ? "true" : "false") + ">";
+      const double *noprec = nullptr;
+      if (int rc = rtc_launch(ctx, "jhmc", {name}, name, grid, block, dyn, st, b, noprec, imm_ws, (long long)L, (long long)T,
+                              samples, acc_hist, (int *)div_hist))
+        return rc;
+    } else if (md && td && pc) AEHMC_FD_LAUNCH(true, true, true);
     else if (md && td) AEHMC_FD_LAUNCH(true, true, false);
     else if (md && pc) AEHMC_FD_LAUNCH(true, false, true);
     else if (md) AEHMC_FD_LAUNCH(true, false, false);

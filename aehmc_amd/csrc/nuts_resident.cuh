@@ -44,6 +44,7 @@ struct Team {
 };
 // DENSE bits of k_nuts_resident
 constexpr int RES_DENSE_METRIC = 1, RES_DENSE_TARGET = 2, RES_DENSE_PER_CHAIN = 4;
+constexpr int RES_DENSE_JOINT = 8;  // a joint (non-separable) user-defined target: the leapfrog of the DENSE path, no matrix of its own
 constexpr int RES_DENSE_BLOCK = 512;  // eight chains share the matrices in LDS (up to 96 KB at D = 64)
 
 // butterfly sum over the T (< 64) consecutive lanes of a sub-wavefront team

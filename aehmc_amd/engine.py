@@ -170,6 +170,10 @@ class Engine:
                 self._check(self.lib.aehmc_set_custom_glm_target(self.ctx, target.source.encode(), D, X.shape[0],
                                                                  X.data_ptr(), y.data_ptr(), ptrs, len(arrs), inc.encode()),
                             "aehmc_set_custom_glm_target")
+            elif target.kind == 7:  # targets.T_JOINT: a joint density, differentiated by the engine (D <= 64)
+                keep = (target, p)
+                self._check(self.lib.aehmc_set_custom_joint_target(self.ctx, target.source.encode(), D, ptrs, len(arrs),
+                                                                   inc.encode()), "aehmc_set_custom_joint_target")
             else:
                 keep = (target, p)
                 self._check(self.lib.aehmc_set_custom_target(self.ctx, target.source.encode(), D, ptrs, len(arrs),
@@ -321,6 +325,39 @@ class Engine:
         self._check(self.lib.aehmc_new_state(self.ctx, C, q.data_ptr(), U.data_ptr(), g.data_ptr(),
                                              self.stream), "aehmc_new_state")
         return U, g
+
+    def check_gradient(self, q, rtol=1e-5, max_coordinates=32):
+        """A hand-written gradient of a user-defined target against central differences of its own potential, at the
+        first chains of ``q`` (the reference differentiates ``logprob_fn`` itself, hmc.py:33-34: there a wrong gradient
+        cannot exist; here it would sample the wrong distribution silently).  Raises ValueError."""
+        C, D = q.shape
+        qs = q[:min(C, 2)].detach()
+        self.ensure_workspace(max(C, 2 * min(D, max_coordinates)), 1)  # (the perturbed positions are evaluated as chains)
+        U0, g = self.new_state(qs.contiguous())
+        gen = np.random.default_rng(12345)
+        idx = np.arange(D) if D <= max_coordinates else np.sort(gen.choice(D, max_coordinates, replace=False))
+        cols = torch.as_tensor(idx, device=self.device)
+        rows = torch.arange(len(idx), device=self.device)
+        worst = 0.0
+        for c in range(qs.shape[0]):
+            h = 1e-6 * torch.clamp(qs[c].abs(), min=1.0)[cols]
+            pert = qs[c].repeat(2 * len(idx), 1)
+            pert[rows, cols] += h
+            pert[rows + len(idx), cols] -= h
+            Up, _ = self.new_state(pert.contiguous())
+            fd = (Up[:len(idx)] - Up[len(idx):]) / (2 * h)
+            ga = g[c][cols]
+            # (central differences: truncation of order h^2, rounding of order eps |U| / h)
+            tol = rtol * torch.clamp(ga.abs(), min=1.0) + 1e-9 * U0[c].abs() / h
+            err = (fd - ga).abs() / tol
+            k = int(torch.argmax(err))
+            worst = max(worst, float(err[k]))
+            if not float(err[k]) <= 1.0:
+                raise ValueError(
+                    f"user-defined target: the hand-written gradient disagrees with central differences of the potential at "
+                    f"coordinate {int(idx[k])} (gradient {float(ga[k]):.9g}, finite difference {float(fd[k]):.9g}); write the "
+                    "log-density only (aehmc_logp / aehmc_glm_loglik + aehmc_glm_logprior) and let the engine differentiate it")
+        return worst
 
     def _diag(self, C, D, nuts):
         # every array is fully written by the kernels: no memset launches

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 # must match enum aehmc_target_kind in include/aehmc_hip.h
-T_STD_NORMAL, T_ISO_GAUSSIAN, T_DIAG_GAUSSIAN, T_DENSE_MVN, T_LINREG, T_CUSTOM, T_GLM = range(7)
+T_STD_NORMAL, T_ISO_GAUSSIAN, T_DIAG_GAUSSIAN, T_DENSE_MVN, T_LINREG, T_CUSTOM, T_GLM, T_JOINT = range(8)
 
 
 class Target:
@@ -75,28 +75,106 @@ class LinearRegression(Target):
         return {"X": self.X, "y": self.y}
 
 
+_DUAL = '#include "dual.cuh"\n'
+# the engine's entry points over a density written ONCE as a template: instantiated with aehmc::Dual (csrc/dual.cuh)
+_ELEM_FROM_LOGP = """
+__device__ void aehmc_custom_elem(double q, long long i, const double *const *prm, double &u, double &g) {
+  const aehmc::Dual r = aehmc_logp(aehmc::Dual(q, 1.0), i, prm);
+  u = -r.v;
+  g = -r.d;
+}
+"""
+_GLM_FROM_LOGP = """
+__device__ void aehmc_glm_row(double z, double y, long long n, const double *const *prm, double &loss, double &dloss) {
+  const aehmc::Dual r = aehmc_glm_loglik(aehmc::Dual(z, 1.0), y, n, prm);
+  loss = -r.v;
+  dloss = -r.d;
+}
+__device__ void aehmc_glm_prior(double q, long long i, const double *const *prm, double &u, double &g) {
+  const aehmc::Dual r = aehmc_glm_logprior(aehmc::Dual(q, 1.0), i, prm);
+  u = -r.v;
+  g = -r.d;
+}
+"""
+
+
 class Custom(Target):
     """A user-defined coordinate-wise ``logprob_fn`` (reference: aehmc/hmc.py:16-40 takes any callable and
-    differentiates it, integrators.py:61-65).  ``source`` is HIP source defining
+    differentiates it, hmc.py:33-34, integrators.py:61-65).  ``source`` is HIP source in ONE of two forms:
 
-        __device__ void aehmc_custom_elem(double q, long long i, const double *const *prm, double &u, double &g)
+    * the log-density only -- the engine differentiates it (forward mode, ``csrc/dual.cuh``): a function template over
+      its arithmetic type,
 
-    -- ``u`` = coordinate i's contribution to the potential energy U = -logprob(q) = sum_i u_i, ``g`` = du_i/dq_i --
-    with ``prm[k]`` the k-th array of ``params`` (device float64 arrays, e.g. one value per coordinate).  The engine
-    compiles its kernel templates against it with hipRTC on first use (a few seconds; cached per source): the lock-step
-    engine for any metric and dimension, the register-resident NUTS kernel (D <= 512) and the fused HMC kernel
-    (D <= 1024) for diagonal / scalar metrics.  Example (independent Student-t coordinates, nu_i = prm[0][i]):
+          template <class T> __device__ T aehmc_logp(T q, long long i, const double *const *prm)
 
-        Custom('''__device__ void aehmc_custom_elem(double q, long long i, const double *const *prm, double &u, double &g) {
-                     const double nu = prm[0][i];
-                     u = 0.5 * (nu + 1.0) * log1p(q * q / nu);
-                     g = (nu + 1.0) * q / (nu + q * q);
-                   }''', params=[nu])"""
+      returning coordinate i's term of logprob(q) = sum_i logp_i(q_i); ``prm[k]`` is the k-th array of ``params``
+      (device float64 arrays, e.g. one value per coordinate).  Independent Student-t coordinates, nu_i = prm[0][i]:
+
+          Custom('''template <class T> __device__ T aehmc_logp(T q, long long i, const double *const *prm) {
+                       const double nu = prm[0][i];
+                       return -0.5 * (nu + 1.0) * log1p(q * q / nu);
+                     }''', params=[nu])
+
+    * potential and gradient by hand,
+
+          __device__ void aehmc_custom_elem(double q, long long i, const double *const *prm, double &u, double &g)
+
+      -- ``u`` = coordinate i's contribution to U = -logprob(q), ``g`` = du_i/dq_i.  A hand-written gradient is checked
+      against central differences of ``u`` at the first position it is evaluated at (``new_state``): a wrong one is an
+      error, not a wrong posterior.
+
+    The engine compiles its kernel templates against the source with hipRTC on first use (a few seconds; cached per
+    source): the lock-step engine for any metric and dimension, the register-resident NUTS kernel (D <= 512) and the
+    fused HMC kernel (D <= 1024) for diagonal / scalar metrics."""
 
     kind = T_CUSTOM
 
     def __init__(self, source: str, params=(), dim=None):
-        self.source, self.param_list, self.dim = str(source), list(params), dim
+        self.user_source = str(source)
+        self.hand_gradient = "aehmc_custom_elem" in self.user_source
+        if not self.hand_gradient and "aehmc_logp" not in self.user_source:
+            raise ValueError("Custom: the source must define aehmc_logp (log-density, differentiated by the engine) or "
+                             "aehmc_custom_elem (potential and gradient by hand)")
+        self.source = self.user_source if self.hand_gradient else _DUAL + self.user_source + _ELEM_FROM_LOGP
+        self.param_list, self.dim = list(params), dim
+        self.gradient_checked = not self.hand_gradient
+
+    def params(self):
+        return {f"p{k}": v for k, v in enumerate(self.param_list)}
+
+
+class CustomJoint(Target):
+    """A user-defined JOINT (non-separable) ``logprob_fn`` of up to 64 coordinates -- hierarchical models, funnels:
+    what the reference samples through aeppl's ``joint_logprob`` (tests/test_hmc.py:170-264).  ``source`` is HIP source
+    defining the log-DENSITY only,
+
+        template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm)
+
+    with ``q[i]`` the coordinates and ``q.size()`` their number; the engine differentiates it in forward mode
+    (``csrc/dual.cuh``): lane i of the chain's wavefront evaluates the density with the derivative seeded at coordinate
+    i, so one evaluation per leapfrog gives U = -logp and the whole gradient.  Neal's funnel (v = q[0], x = q[1:]):
+
+        CustomJoint('''template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm) {
+                            auto v = q[0];
+                            auto lp = -v * v / 18.0;
+                            for (int i = 1; i < q.size(); i++) lp += -0.5 * q[i] * q[i] * exp(-v) - 0.5 * v;
+                            return lp;
+                          }''', dim=10)
+
+    Runs NUTS and HMC in single launches (any number of transitions) with a scalar, diagonal or dense metric, shared or
+    per chain, and under ``window_adaptation``."""
+
+    kind = T_JOINT
+
+    def __init__(self, source: str, dim: int, params=()):
+        if "aehmc_logp" not in source:
+            raise ValueError("CustomJoint: the source must define aehmc_logp(const V &q, const double *const *prm)")
+        if not 1 <= int(dim) <= 64:
+            raise ValueError("CustomJoint: 1 <= dim <= 64 (one coordinate per lane of the chain's wavefront)")
+        self.user_source = str(source)
+        self.source = _DUAL + self.user_source
+        self.param_list, self.dim = list(params), int(dim)
+        self.hand_gradient, self.gradient_checked = False, True
 
     def params(self):
         return {f"p{k}": v for k, v in enumerate(self.param_list)}
@@ -121,12 +199,27 @@ class CustomGLM(Target):
             const double tau = prm[0][0];
             u = 0.5 * q * q / (tau * tau);
             g = q / (tau * tau);
-          }''', X, y, params=[[2.0]])"""
+          }''', X, y, params=[[2.0]])
+
+    The density-only form (the engine differentiates: ``csrc/dual.cuh``) defines instead
+
+        template <class T> __device__ T aehmc_glm_loglik(T z, double y, long long n, const double *const *prm)
+        template <class T> __device__ T aehmc_glm_logprior(T q, long long i, const double *const *prm)
+
+    e.g. ``return y * z - softplus(z);`` and ``return -0.5 * q * q / (tau * tau);`` for the model above.  A hand-written
+    pair of gradients is checked against central differences at the first ``new_state``."""
 
     kind = T_GLM
 
     def __init__(self, source: str, X, y, params=()):
-        self.source, self.X, self.y, self.param_list = str(source), X, y, list(params)
+        self.user_source = str(source)
+        self.hand_gradient = "aehmc_glm_row" in self.user_source
+        if not self.hand_gradient and not ("aehmc_glm_loglik" in self.user_source and "aehmc_glm_logprior" in self.user_source):
+            raise ValueError("CustomGLM: the source must define aehmc_glm_loglik and aehmc_glm_logprior (log-densities, "
+                             "differentiated by the engine) or aehmc_glm_row and aehmc_glm_prior (losses and gradients by hand)")
+        self.source = self.user_source if self.hand_gradient else _DUAL + self.user_source + _GLM_FROM_LOGP
+        self.X, self.y, self.param_list = X, y, list(params)
+        self.gradient_checked = not self.hand_gradient
         self.dim = int(X.shape[1])
 
     def params(self):

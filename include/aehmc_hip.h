@@ -49,7 +49,9 @@ enum aehmc_target_kind {
   AEHMC_T_DENSE_MVN = 3,    /* U = 0.5 (q-mu)^T P (q-mu), P dense symmetric [D,D] */
   AEHMC_T_LINREG = 4,       /* examples/LinearRegression.ipynb:126-166, q = [w, log n] */
   AEHMC_T_CUSTOM = 5,       /* user-defined coordinate-wise target, compiled at run time: aehmc_set_custom_target */
-  AEHMC_T_GLM = 6           /* user-defined row-reduction target over a data matrix: aehmc_set_custom_glm_target */
+  AEHMC_T_GLM = 6,          /* user-defined row-reduction target over a data matrix: aehmc_set_custom_glm_target */
+  AEHMC_T_JOINT = 7         /* user-defined JOINT (non-separable) log-density, D <= 64, differentiated by the engine:
+                               aehmc_set_custom_joint_target */
 };
 
 typedef struct {
@@ -144,6 +146,19 @@ int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64_t D, const
 int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, int64_t N, const double *X,
                                 const double *y, const double *const *params, int32_t n_params,
                                 const char *include_dir);
+
+/* A user-defined JOINT logprob_fn (reference: aehmc/hmc.py:16-40 takes any callable and differentiates it,
+ * hmc.py:33-34, integrators.py:61-65): the user writes the log-DENSITY only, the engine differentiates it.  `source`
+ * is HIP source that includes "dual.cuh" and defines
+ *     template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm)
+ * with q[i] the coordinates (i wave-uniform) and q.size() = D <= 64 -- hierarchical models, funnels, anything that is
+ * not a sum over coordinates or data rows.  Forward mode: lane i of the chain's wavefront evaluates the density with
+ * the derivative seeded at coordinate i (csrc/dual.cuh), so one evaluation per leapfrog yields U = -logp and the whole
+ * gradient.  Runs on the single-launch kernels of small problems (k_nuts_resident / k_hmc_fused_dense compiled against
+ * it: scalar, diagonal or dense metric, shared or per chain, any number of transitions per launch) and in new_state;
+ * the lock-step engine (options resident_nuts / fused_hmc = 0) does not take joint targets. */
+int aehmc_set_custom_joint_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
+                                  int32_t n_params, const char *include_dir);
 int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
 
 /* engine options (name, default):

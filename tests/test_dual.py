@@ -1,0 +1,51 @@
+"""csrc/dual.cuh (forward-mode differentiation of user-defined log-densities) compiled as plain C++ on the CPU: every
+overloaded operator / function against central differences, and a template density instantiated with double and with
+Dual (the way the run-time compiled kernels use it).  Reference: aehmc/hmc.py:33-34 (aesara.grad of the potential)."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SRC = r"""
+#include <cstdio>
+#include <cmath>
+#include "dual.cuh"
+using aehmc::Dual;
+template <class T> T density(T q, double a) {   // a user-style template body: mixes T and double, uses ADL for the functions
+  T z = (q - a) / 1.5;
+  T lp = -0.5 * z * z - log1p(exp(-q)) + sqrt(1.0 + square(z)) * 0.25 - softplus(z) + 0.1 * tanh(q) - erf(z) * 0.2;
+  lp += pow(1.0 + q * q, 0.3) - log(2.0 + cos(q)) + sin(z) / (2.0 + z * z) - expm1(-z * z) + fabs(q - 0.2);
+  lp -= pow(1.0 + z * z, z * 0.1);
+  if (q > 10.0) lp = lp * 2.0;
+  return lp;
+}
+int main() {
+  int bad = 0;
+  for (double q = -2.0; q <= 2.0; q += 0.37) {
+    const double h = 1e-6;
+    const Dual r = density(Dual(q, 1.0), 0.3);
+    const double v = density(q, 0.3), fd = (density(q + h, 0.3) - density(q - h, 0.3)) / (2 * h);
+    if (std::fabs(r.v - v) > 1e-14 * (1 + std::fabs(v)) || std::fabs(r.d - fd) > 2e-8 * (1 + std::fabs(fd))) {
+      std::printf("q=%g value %g / %g derivative %.12g / %.12g\n", q, r.v, v, r.d, fd);
+      bad++;
+    }
+  }
+  // quotient, compound assignment, comparisons
+  Dual a(2.0, 1.0), b(3.0, 0.0);
+  Dual c = a / b; c += a; c *= 2.0; c -= 1.0; c /= b;     // ((a/3 + a) * 2 - 1) / 3 -> d/da = (1/3 + 1) * 2 / 3
+  if (std::fabs(c.d - (1.0 / 3 + 1) * 2 / 3) > 1e-15 || !(a < b) || !(b >= a) || a == b || !(a != 3.0) || !(1.0 < a)) bad++;
+  Dual d = 5.0 / a;                                        // -5 / a^2
+  if (std::fabs(d.d + 5.0 / 4.0) > 1e-15 || std::fabs(aehmc::ad::value_of(d) - 2.5) > 1e-15) bad++;
+  std::printf("bad=%d\n", bad);
+  return bad;
+}
+"""
+
+
+def test_dual_numbers_against_finite_differences(tmp_path):
+    src = tmp_path / "dual_test.cpp"
+    src.write_text(SRC)
+    exe = tmp_path / "dual_test"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "aehmc_amd", "csrc"), "-o", str(exe), str(src)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout
