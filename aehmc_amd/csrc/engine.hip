@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -93,6 +95,7 @@ struct aehmc_ctx {
   // user-defined target (aehmc_set_custom_target): its source, the kernels compiled against it (hipRTC code objects
   // keyed by program + source, kept for the life of the ctx) and the device array of its parameter arrays
   std::string custom_src, custom_inc;
+  std::string rtc_cache_dir;  // compiled code objects of user-defined targets, kept across processes (aehmc_set_rtc_cache)
   const double **d_cparams = nullptr;
   int n_cparams = 0;
   // user-defined row-reduction target: data matrix X [N,D], its transpose (owned), responses, [C,N] / [C] work arrays (owned)
@@ -248,6 +251,60 @@ static const char *RTC_PROLOGUE =
     "typedef signed int int32_t; typedef unsigned int uint32_t; typedef long long int64_t;\n"
     "typedef unsigned long long uint64_t; typedef unsigned long long uintptr_t; typedef unsigned long size_t;\n"
     "#define INFINITY __builtin_huge_val()\n";
+// ---- code objects of run-time compiled programs on disk (aehmc_set_rtc_cache): a second process that binds the same
+// user-defined target starts without recompiling.  File = the code object + the lowered names of its kernels; its name
+// is a hash of everything the compiler saw (source, options, kernel names); the DIRECTORY is chosen by the caller and
+// carries the hash of the library's own sources (the headers the program includes), see aehmc_amd/engine.py.
+static uint64_t fnv1a64(const std::string &s, uint64_t h = 1469598103934665603ULL) {
+  for (unsigned char ch : s) {
+    h ^= ch;
+    h *= 1099511628211ULL;
+  }
+  return h;
+}
+static bool rtc_cache_load(const std::string &path, const std::vector<std::string> &names, std::vector<char> &code,
+                           std::vector<std::string> &lowered) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  bool ok = false;
+  uint64_t head[3];
+  if (fread(head, sizeof(uint64_t), 3, f) == 3 && head[0] == 0x61656863724b4f31ULL && head[1] == names.size()) {
+    lowered.clear();
+    ok = true;
+    for (size_t k = 0; ok && k < names.size(); k++) {
+      uint64_t n = 0;
+      ok = fread(&n, sizeof(n), 1, f) == 1 && n < 4096;
+      std::string low(ok ? n : 0, '\0');
+      ok = ok && (n == 0 || fread(&low[0], 1, n, f) == n);
+      lowered.push_back(low);
+    }
+    code.resize(ok ? head[2] : 0);
+    ok = ok && head[2] > 0 && fread(code.data(), 1, head[2], f) == head[2];
+  }
+  fclose(f);
+  return ok;
+}
+static void rtc_cache_store(const std::string &path, const std::vector<std::string> &lowered, const std::vector<char> &code) {
+  const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) return;  // (an unwritable cache is not an error)
+  const uint64_t head[3] = {0x61656863724b4f31ULL, lowered.size(), code.size()};
+  bool ok = fwrite(head, sizeof(uint64_t), 3, f) == 3;
+  for (const auto &low : lowered) {
+    const uint64_t n = low.size();
+    ok = ok && fwrite(&n, sizeof(n), 1, f) == 1 && (n == 0 || fwrite(low.data(), 1, n, f) == n);
+  }
+  ok = ok && fwrite(code.data(), 1, code.size(), f) == code.size();
+  ok = (fclose(f) == 0) && ok;
+  if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;  // (atomic: a concurrent reader sees the old file or the new one)
+  if (!ok) remove(tmp.c_str());
+}
+extern "C" int aehmc_set_rtc_cache(aehmc_ctx *ctx, const char *dir) {
+  if (!ctx) return -2;
+  ctx->rtc_cache_dir = dir ? dir : "";
+  return 0;
+}
+
 static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vector<std::string> &names,
                         const std::string &want, hipFunction_t *out) {
   // "j*": the programs of a joint target (engine.cuh: AEHMC_JOINT_TARGET) -- "jbase" new_state, "jnuts" / "jhmc" one
@@ -265,43 +322,67 @@ static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vec
     if (which == "nuts" || which == "jnuts") src += "#include \"nuts_resident.cuh\"\n";
     if (which == "hmc") src += "#include \"hmc_fused.cuh\"\n";
     if (which == "glm") src += "#include \"glm_rows.cuh\"\n";
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "aehmc_custom.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-      FAIL("hiprtcCreateProgram failed");
-    for (const auto &n : names) hiprtcAddNameExpression(prog, n.c_str());
     const std::string inc = "-I" + ctx->custom_inc;
     const char *opts[] = {"--offload-arch=" AEHMC_GPU_ARCH, "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str(),
                           "-mllvm", "-disable-machine-licm"};  // (the flags of csrc/Makefile)
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 7, opts);
-    if (rc != HIPRTC_SUCCESS) {
-      size_t n = 0;
-      hiprtcGetProgramLogSize(prog, &n);
-      std::string log(n, '\0');
-      if (n) hiprtcGetProgramLog(prog, &log[0]);
-      hiprtcDestroyProgram(&prog);
-      ctx->err = std::string("user-defined target: compilation failed (") + hiprtcGetErrorString(rc) + ")\n" + log;
-      return -3;
+    std::vector<char> code;
+    std::vector<std::string> lowered;
+    std::string cache_path;
+    if (!ctx->rtc_cache_dir.empty()) {
+      std::string all = src;
+      for (const char *o : opts)
+        if (o != inc.c_str()) all += std::string("\n") + o;
+      for (const auto &n : names) all += "\n" + n;
+      char name[40];
+      snprintf(name, sizeof(name), "/%016llx.aehmcco", (unsigned long long)fnv1a64(all));
+      cache_path = ctx->rtc_cache_dir + name;
     }
-    size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
-    hiprtcGetCode(prog, code.data());
+    const bool cached = !cache_path.empty() && rtc_cache_load(cache_path, names, code, lowered);
+    if (!cached) {
+      hiprtcProgram prog;
+      if (hiprtcCreateProgram(&prog, src.c_str(), "aehmc_custom.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        FAIL("hiprtcCreateProgram failed");
+      for (const auto &n : names) hiprtcAddNameExpression(prog, n.c_str());
+      const hiprtcResult rc = hiprtcCompileProgram(prog, 7, opts);
+      if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        ctx->err = std::string("user-defined target: compilation failed (") + hiprtcGetErrorString(rc) + ")\n" + log;
+        return -3;
+      }
+      size_t cs = 0;
+      hiprtcGetCodeSize(prog, &cs);
+      code.resize(cs);
+      hiprtcGetCode(prog, code.data());
+      lowered.clear();
+      for (const auto &n : names) {
+        const char *low = nullptr;
+        if (hiprtcGetLoweredName(prog, n.c_str(), &low) != HIPRTC_SUCCESS || !low) {
+          hiprtcDestroyProgram(&prog);
+          FAIL("user-defined target: kernel " + n + " not found in the compiled program");
+        }
+        lowered.push_back(low);
+      }
+      hiprtcDestroyProgram(&prog);
+      if (!cache_path.empty()) rtc_cache_store(cache_path, lowered, code);
+    }
     aehmc_ctx::RtcProgram rp;
     if (hipModuleLoadData(&rp.mod, code.data()) != hipSuccess) {
-      hiprtcDestroyProgram(&prog);
+      if (cached) remove(cache_path.c_str());  // (a damaged file: compiled afresh by the next call)
       FAIL("user-defined target: hipModuleLoadData failed");
     }
-    for (const auto &n : names) {
-      const char *low = nullptr;
+    for (size_t k = 0; k < names.size(); k++) {
       hipFunction_t f = nullptr;
-      if (hiprtcGetLoweredName(prog, n.c_str(), &low) != HIPRTC_SUCCESS ||
-          hipModuleGetFunction(&f, rp.mod, low) != hipSuccess) {
-        hiprtcDestroyProgram(&prog);
-        FAIL("user-defined target: kernel " + n + " not found in the compiled code object");
+      if (hipModuleGetFunction(&f, rp.mod, lowered[k].c_str()) != hipSuccess) {
+        (void)hipModuleUnload(rp.mod);
+        if (cached) remove(cache_path.c_str());
+        FAIL("user-defined target: kernel " + names[k] + " not found in the code object");
       }
-      rp.fn[n] = f;
+      rp.fn[names[k]] = f;
     }
-    hiprtcDestroyProgram(&prog);
     it = ctx->rtc.emplace(key, rp).first;
   }
   auto f = it->second.fn.find(want);

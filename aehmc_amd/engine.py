@@ -112,6 +112,9 @@ class Engine:
             raise EngineError(f"aehmc_create failed: {self._err()}")
         self._target_key = None
         self._metric_key = None
+        self.rtc_cache_dir = self._rtc_cache_dir()
+        if self.rtc_cache_dir:
+            self._check(self.lib.aehmc_set_rtc_cache(self.ctx, self.rtc_cache_dir.encode()), "aehmc_set_rtc_cache")
         # metric handles: (device imm, device sqrt-mass) per metric content, so that kernels which alternate between
         # metrics on one device (each kernel its own dense mass matrix) factor every matrix ONCE
         self._metric_cache = collections.OrderedDict()
@@ -122,6 +125,24 @@ class Engine:
         self.D = None
         self.metric_ndim = None
         self.metric_D = None
+
+    @staticmethod
+    def _rtc_cache_dir():
+        """Where the compiled code objects of user-defined targets are kept across processes: AEHMC_AMD_RTC_CACHE (a
+        directory; "0" / "" = off), default ~/.cache/aehmc_amd/rtc-<hash of the library's sources> -- the headers a
+        run-time compiled program includes are part of what it was compiled from."""
+        import os
+        from . import _build
+        where = os.environ.get("AEHMC_AMD_RTC_CACHE")
+        if where is not None and where in ("", "0"):
+            return None
+        try:
+            base = where or os.path.join(os.path.expanduser("~"), ".cache", "aehmc_amd")
+            path = os.path.join(base, "rtc-" + _build.source_hash()[:16])
+            os.makedirs(path, exist_ok=True)
+            return path
+        except OSError:
+            return None
 
     def __del__(self):
         try:

@@ -159,6 +159,12 @@ int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, i
  * the lock-step engine (options resident_nuts / fused_hmc = 0) does not take joint targets. */
 int aehmc_set_custom_joint_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
                                   int32_t n_params, const char *include_dir);
+
+/* Code objects of run-time compiled programs (the three entry points above) are kept in `dir` across processes: a file
+ * per program, named by a hash of everything the compiler saw (source, options, kernel names).  The caller chooses a
+ * directory that is specific to the library's own sources -- the headers a program includes (aehmc_amd/engine.py uses
+ * ~/.cache/aehmc_amd/rtc-<source hash>).  NULL or "" switches the cache off (default). */
+int aehmc_set_rtc_cache(aehmc_ctx *ctx, const char *dir);
 int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
 
 /* engine options (name, default):
