@@ -150,7 +150,8 @@ int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, i
 /* A user-defined JOINT logprob_fn (reference: aehmc/hmc.py:16-40 takes any callable and differentiates it,
  * hmc.py:33-34, integrators.py:61-65): the user writes the log-DENSITY only, the engine differentiates it.  `source`
  * is HIP source that includes "dual.cuh" and defines
- *     template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm)
+ *     template <class V> __device__ auto aehmc_logp
+ *         (const V &q, const double *const *prm)
  * with q[i] the coordinates (i wave-uniform) and q.size() = D <= 64 -- hierarchical models, funnels, anything that is
  * not a sum over coordinates or data rows.  Forward mode: lane i of the chain's wavefront evaluates the density with
  * the derivative seeded at coordinate i (csrc/dual.cuh), so one evaluation per leapfrog yields U = -logp and the whole
