@@ -24,6 +24,7 @@
 #include "nuts_block_roll.cuh"
 #include "nuts_resident.cuh"
 #include "nuts_wide.cuh"
+#include "nuts_pc_dense.cuh"
 
 using namespace aehmc;
 
@@ -61,6 +62,7 @@ struct aehmc_ctx {
   bool opt_dense_linear = true;  // one metric GEMM per leapfrog (v carried by linearity)
   bool opt_compact = true;       // finished chains drop out of the GEMMs
   int opt_block_roll = 0;        // block-resident NUTS: waiting chains that trigger a begin round (0: kernel default)
+  bool opt_pc_dense = true;      // per-chain dense metrics, 64 < D <= 512: NUTS in one launch, a wavefront per chain streams its matrix
   int opt_block_dense = 1;       // mid-size dense problems (64 < D <= 512): one workgroup per 16 chains, whole call in one launch
                                  // (1: chain state in registers up to D = 256, in L2-resident work rows above; 2: always work rows)
   bool opt_fp_contract = false;  // fast arithmetic in the leapfrog bodies of the register-resident kernels (1e-6, not bit parity)
@@ -816,6 +818,10 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
     ctx->opt_block_dense = (int)value;
     return 0;
   }
+  if (!strcmp(name, "pc_dense")) {
+    ctx->opt_pc_dense = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "block_roll")) {
     if (value < 0 || value > 16) FAIL("block_roll: 0 (default) ... 16");
     ctx->opt_block_roll = (int)value;
@@ -1202,7 +1208,7 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
 // which kernel family a NUTS call takes (one place: aehmc_nuts_warmup asks before it commits to a
 // single-launch warm-up)
 enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE, NUTS_PATH_FUSED_DENSE,
-       NUTS_PATH_BLOCK_DENSE };
+       NUTS_PATH_BLOCK_DENSE, NUTS_PATH_PC_DENSE };
 // workspace of the small-dense kernels with per-chain metrics (hipFree waits for earlier launches that use it)
 static int fused_dense_workspace(aehmc_ctx *ctx, size_t need, double **out) {
   if (ctx->fd_ws_bytes < need) {
@@ -1249,6 +1255,11 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   if (want_resident && ctx->opt_block_dense && ctx->opt_dense_linear &&
       block_dense_supported(tkind, nd, ctx->met.per_chain, D))
     return NUTS_PATH_BLOCK_DENSE;
+  // one dense metric per chain (what full-matrix window adaptation returns), 64 < D <= 512, coordinate-wise target: a
+  // wavefront per chain runs the whole call and streams its own matrix (nuts_pc_dense.cuh)
+  if (want_resident && ctx->opt_pc_dense && ctx->opt_dense_linear &&
+      nuts_pc_dense_supported(tkind, nd, ctx->met.per_chain, D))
+    return NUTS_PATH_PC_DENSE;
   return NUTS_PATH_LOCKSTEP;
 }
 
@@ -1352,6 +1363,18 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(tu::nuts_block_roll(a, m, bp, st));
     else if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(tu::nuts_block_reg(a, m, bp, st));
     else HIPCHK(tu::nuts_block_dense(a, m, bp, st));
+    return prof_end(ctx, st, p);
+  }
+  if (path == NUTS_PATH_PC_DENSE) {  // per-chain dense metrics, 64 < D <= 512: every transition of the call in one launch
+    NutsSampleArgs m{};
+    m.T = 1;
+    if (multi && multi_done && !multi->adapt) {
+      m = *multi;
+      *multi_done = true;
+    }
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    HIPCHK(tu::nuts_pc_dense(a, m, st));
     return prof_end(ctx, st, p);
   }
   if (a.tkind == AEHMC_T_JOINT) FAIL("joint targets run on the single-launch kernels only (option resident_nuts must not be 0)");
@@ -1679,6 +1702,17 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     HIPCHK(hipGetLastError());
     if (int rc = prof_end(ctx, st, p)) return rc;
     if (T > 1 && out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
+    return 0;
+  }
+  // one dense metric per chain, 64 < D <= 512, coordinate-wise target, linear dense mode: all T transitions in one
+  // launch, the wavefront that owns a chain streaming its matrix (nuts_pc_dense.cuh)
+  if (ctx->opt_fused_hmc && ctx->opt_pc_dense && a.linear &&
+      nuts_pc_dense_supported(a.tkind, a.met_ndim, ctx->met.per_chain, D)) {
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    HIPCHK(tu::hmc_pc_dense(a, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist, st));
+    if (int rc = prof_end(ctx, st, p)) return rc;
+    if (out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
     return 0;
   }
   // mid-size dense problems (shared dense metric, 64 < D <= 512, linear dense mode): all T transitions in one launch,

@@ -34,6 +34,10 @@ hipError_t hmc_block_reg(const EngineArgs &a, const double *prec, long long L, l
                          double *acc_hist, int *div_hist, double *bp, hipStream_t st);
 hipError_t hmc_block_dense(const EngineArgs &a, const double *prec, long long L, long long nt, double *samples,
                            double *acc_hist, int *div_hist, double *bp, hipStream_t st);
+// nuts_pc_dense.cuh
+hipError_t nuts_pc_dense(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st);
+hipError_t hmc_pc_dense(const EngineArgs &a, long long L, long long nt, double *samples, double *acc_hist, int *div_hist,
+                        hipStream_t st);
 // hmc_fused.cuh
 hipError_t hmc_fused(const HmcFusedArgs &a, hipStream_t st);
 hipError_t hmc_resident(const HmcFusedArgs &a, const double *zbuf, int nt, hipStream_t st);

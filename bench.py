@@ -306,6 +306,52 @@ def dense_mid_secondary(eng, device, C=4096, T=10):
     return out
 
 
+def pc_dense_secondary(eng, device, D=200, C=4096, T=10):
+    """One dense inverse mass matrix PER CHAIN (what window_adaptation.run(is_mass_matrix_full=True) returns), D = 200,
+    coordinate-wise target: csrc/nuts_pc_dense.cuh, one launch per sample(T) call, the wavefront that owns a chain streams
+    its matrix once per leapfrog (linear dense mode) + three times at the start of a transition.  Bound: HBM on those bytes
+    (D^2 x 8 per product and chain); `traffic` = the counted bytes of the same call when a stamped summary exists."""
+    from aehmc_amd import PerChain, RandomStream, nuts, targets
+    try:
+        g = torch.Generator(device=device).manual_seed(0)
+        A = torch.randn(C, D, D, dtype=torch.float64, device=device, generator=g)
+        imm = torch.baddbmm(0.3 * torch.eye(D, dtype=torch.float64, device=device).expand(C, D, D), A, A.transpose(1, 2), alpha=1.0 / D)
+        imm = 0.5 * (imm + imm.transpose(1, 2))
+        del A
+        r = np.random.default_rng(0)
+        tgt = targets.DiagGaussian(r.normal(size=D), 0.5 + r.random(D))
+        q0 = torch.as_tensor(r.standard_normal((C, D)), device=device)
+        kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        eps, pi = 0.25 * D ** -0.25, PerChain(imm)
+        info = kernel.sample(nuts.new_state(q0, tgt), eps, pi, 2)[1]
+        best, nl = None, 0
+        for _ in range(3):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            info = kernel.sample(info.state._replace(momentum=None), eps, pi, T)[1]
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, nl = dt, int(info.n_leapfrog.sum().item())
+        alg = (nl + 3.0 * C * T) * D * D * 8.0
+        roof = {"bound": "hbm", "unit": "GB/s", "achieved": alg / best / 1e9, "peak": PEAK_HBM_GBS,
+                "frac": alg / best / 1e9 / PEAK_HBM_GBS, "kernel": "k_nuts_pc_dense", "launches": 1, "avg_launch_ms": best * 1e3,
+                "algorithmic_bytes_per_launch": alg, "traffic": None,
+                "note": "D^2 x 8 bytes per product and chain: one product per leapfrog + three per transition"}
+        name = os.path.join("dense", "pc200_pmc_summary.json")
+        pmc, src = pmc_summary(name)
+        if pmc:
+            roof["traffic"] = pmc["derived"].get("hbm_bytes_per_launch")
+            roof["traffic_source"] = src
+        roof["counters_dropped"] = PMC_STALE.get(name)
+        return [{"config": f"pc-dense-nuts-d{D}",
+                 "workload": f"{D}-dim Gaussian, one dense inverse mass matrix per chain, NUTS depth 10, {C} chains, sample({T}) in one launch",
+                 "value": nl / best, "unit": "leapfrog-steps/s", "ms_per_transition": best / T * 1e3,
+                 "leapfrogs_per_transition": nl / T, "roofline": roof}]
+    except Exception as e:  # a failing side measurement must not cost the main line
+        return [{"config": f"pc-dense-nuts-d{D}", "error": repr(e)[:300]}]
+
+
 def launch_ranks(n, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one process per
     GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches
@@ -583,6 +629,8 @@ def main():
         torch.cuda.empty_cache()
         secondary = bench_secondary(eng, device, max(args.steps, 3), 2)
         secondary += dense_mid_secondary(eng, device)
+        secondary += pc_dense_secondary(eng, device)
+        torch.cuda.empty_cache()
         secondary += other_configs()
 
     emit({

@@ -207,6 +207,10 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   products on fp64 MFMA inside the workgroup, same k-order as the chain-batched GEMM (bitwise
  *                   the lock-step path's results).  1: the chains' moving state in registers up to D = 256, in
  *                   L2-resident work rows above; 2: work rows at every D; 0 = the lock-step path
+ *  "pc_dense" 1     one dense inverse mass matrix PER CHAIN (full-matrix window adaptation), 64 < D <= 512, coordinate-wise
+ *                   target, "dense_linear" = 1: NUTS runs the whole call in one launch, the wavefront that owns a chain
+ *                   streaming its matrix once per leapfrog (csrc/nuts_pc_dense.cuh; bitwise the lock-step path); 0 =
+ *                   the lock-step path (per-chain mat-vec launches between the stage kernels)
  *  "block_roll" 0   block-resident NUTS with the state in registers, launches of several transitions: a chain whose
  *                   tree has ended begins its next transition as soon as this many chains of its workgroup wait
  *                   (one more in-workgroup product in that round: csrc/nuts_block_roll.cuh) instead of waiting for

@@ -139,7 +139,7 @@ def test_bench_default_line_has_its_good_secondary_entries():
     assert d["config"]["dim"] == 10_000 and d["config"]["chains_total"] == 4096
     sec = d["secondary"]
     assert [e["config"] for e in sec] == ["diag-nuts", "diag-hmc", "diag-hmc-fp_contract", "dense-nuts-d100", "dense-nuts-d200",
-                                          "c2", "c2-fp_contract", "c5", "c1"]
+                                          "pc-dense-nuts-d200", "c2", "c2-fp_contract", "c5", "c1"]
     for e in sec:
         assert "error" not in e and e["value"] > 0, e
     by = {e["config"]: e for e in sec}
@@ -148,6 +148,8 @@ def test_bench_default_line_has_its_good_secondary_entries():
     for k in ("dense-nuts-d100", "dense-nuts-d200"):  # block-resident kernels: one launch per sample() call
         r = by[k]["roofline"]
         assert r["bound"] == "mfma" and r["launches"] == 1 and 0 < r["frac"] < 1 and by[k]["ms_per_transition"] < 1.5
+    r = by["pc-dense-nuts-d200"]["roofline"]  # one dense metric per chain: bound by streaming the matrices
+    assert r["bound"] == "hbm" and r["launches"] == 1 and 0.3 < r["frac"] < 1
     # the fast-arithmetic mode is faster where the leapfrog loop dominates, and says that it is not the bit-exact mode
     assert by["diag-hmc-fp_contract"]["value"] > 1.15 * by["diag-hmc"]["value"]
     assert "fp_contract=1" in by["c2-fp_contract"]["workload"] and "fp_contract" not in by["c2"]["workload"]
