@@ -322,6 +322,7 @@ static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vec
     src += "#line 1 \"custom_target\"\n" + ctx->custom_src + "\n";
     src += "#include \"engine.cuh\"\n";
     if (which == "nuts" || which == "jnuts") src += "#include \"nuts_resident.cuh\"\n";
+    if (which == "wide") src += "#include \"nuts_wide.cuh\"\n";
     if (which == "hmc") src += "#include \"hmc_fused.cuh\"\n";
     if (which == "glm") src += "#include \"glm_rows.cuh\"\n";
     const std::string inc = "-I" + ctx->custom_inc;
@@ -402,6 +403,8 @@ static int rtc_launch(aehmc_ctx *ctx, const std::string &which, const std::vecto
   hipFunction_t f = nullptr;
   if (int rc = rtc_function(ctx, which, names, want, &f)) return rc;
   void *params[] = {(void *)&args...};
+  if (dyn > 65536)  // (more dynamic LDS than the default limit: allowed per function)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
   HIPCHK(hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)dyn, st, params, nullptr));
   return 0;
 }
@@ -1244,6 +1247,7 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   (void)C;
   if (want_resident && nuts_resident_supported(tkind, nd, D)) return NUTS_PATH_TEAMS;  // D <= 512
   if (want_resident && tkind == AEHMC_T_CUSTOM && nd < 2 && D <= 512) return NUTS_PATH_TEAMS;  // (run-time compiled)
+  if (want_resident && tkind == AEHMC_T_CUSTOM && nd < 2 && D <= 10176) return NUTS_PATH_WIDE;  // (run-time compiled)
   if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
@@ -1301,7 +1305,17 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       hipLaunchKernelGGL(k_draw_momentum, chain_grid(C), dim3(256), 0, st, a.rng, a.nsites, (long long)C,
                          (long long)a.D, a.sqrt_mass, (long long)a.imm_cs, a.met_ndim, a.zbuf, a.ldw, 1);
       HIPCHK(hipGetLastError());
-      HIPCHK(tu::nuts_wide(a, st));
+      if (a.tkind == AEHMC_T_CUSTOM) {  // the same instantiation (launch_nuts_wide's table), compiled against the user's function
+        const long long D = a.D;
+        const int T = D <= 2048 ? 256 : 512, R = D <= 1024 ? 4 : (D <= 4096 ? 8 : (D <= 8192 ? 16 : 20));
+        const bool qgl = D > 4096;
+        const std::string name = "aehmc::k_nuts_wide<" + std::to_string(T) + ", " + std::to_string(R) + ", " +
+                                 (qgl ? "true" : "false") + ", " + std::to_string((int)AEHMC_T_CUSTOM) + ">";
+        const size_t dyn = qgl ? (size_t)2 * (D + 1) * sizeof(double) : 0;  // (q and dU/dq in LDS)
+        if (int rc = rtc_launch(ctx, "wide", {name}, name, dim3((unsigned)C), dim3(T), dyn, st, a)) return rc;
+      } else {
+        HIPCHK(tu::nuts_wide(a, st));
+      }
     } else {  // teams of <= 64 lanes: any number of transitions in one launch
       NutsSampleArgs m{};
       m.T = 1;

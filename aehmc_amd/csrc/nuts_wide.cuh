@@ -36,14 +36,17 @@
 // Reference: nuts.py:56-153, trajectory.py:154-374,428-714, termination.py:85-235,
 // proposals.py:19-174, integrators.py:54-73, metrics.py:44-104.
 #pragma once
+#ifndef __HIPCC_RTC__  /* (hipRTC supplies the runtime itself) */
 #include <hip/hip_runtime.h>
-
-#include <type_traits>
+#endif
 
 #include "engine.cuh"
 #include "linreg_rows.cuh"  // dpp_xor1 / dpp_xor2
 
 namespace aehmc {
+
+struct WideTagTrue { static constexpr bool value = true; };    // (compile-time switches of the pass below;
+struct WideTagFalse { static constexpr bool value = false; };  //  no <type_traits> under hipRTC)
 
 // Developer instrumentation (make timing): shader-clock cycles per phase of the per-leapfrog
 // loop, accumulated by every thread, written by thread 0 to a.linreg_part[c * 8 + phase]
@@ -62,7 +65,10 @@ namespace aehmc {
 template <int T, int R, bool QGL, int TK>
 __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
   constexpr int NW = T / 64;
-  constexpr bool DG = TK == AEHMC_T_DIAG_GAUSSIAN;  // otherwise dU/dq == q: no separate copy
+  // TK == AEHMC_T_CUSTOM exists only in the run-time compiled copy (aehmc_set_custom_target): the user's aehmc_custom_elem,
+  // dU/dq kept beside q as for the diagonal Gaussian, no parameters of the engine's own to stream
+  constexpr bool CU = TK == AEHMC_T_CUSTOM;
+  constexpr bool DG = TK == AEHMC_T_DIAG_GAUSSIAN || CU;  // otherwise dU/dq == q: no separate copy
   constexpr bool ISO = TK == AEHMC_T_ISO_GAUSSIAN;
   constexpr bool PAR_REG = R <= 8;          // per-element parameters live in VGPRs
   constexpr bool IM_LDS = !PAR_REG && !DG;  // imm in the LDS half that dU/dq does not need
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     const bool on = ON(r);
     const double im = imrow[im_scalar ? 0u : i];
     x.im = on ? im : 1.0;
-    if (DG) {
+    if (DG && !CU) {
       const double mu = a.mu[i], sd = a.sigma[i], ls = a.log_sigma[i];
       x.mu = on ? mu : 0.0;
       x.sd = on ? sd : 1.0;
@@ -286,6 +292,13 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
             } else if (ISO) {
               uu = qq * qq;
               gg = qq;
+            } else if (CU) {
+#ifdef AEHMC_CUSTOM_TARGET
+              aehmc_custom_elem(qq, (long long)EC(r), a.cparams, uu, gg);
+#else
+              uu = gg = 0.0;
+#endif
+              gg = ON(r) ? gg : 0.0;  // (a slot past D stays at the fixed point q = p = 0)
             } else {
               const double z = (qq - x.mu) / x.sd;
               uu = 0.5 * (z * z) + x.ls + AEHMC_LOG_SQRT_2PI;
@@ -316,8 +329,8 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
         if (R > 8) __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if (fwd) pass(std::true_type{});
-    else pass(std::false_type{});
+    if (fwd) pass(WideTagTrue{});
+    else pass(WideTagFalse{});
     if (ck_store) {  // every fourth step: the checkpoint pair, straight from the registers
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -598,6 +611,7 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
 #undef IMOF
 }
 
+#ifndef __HIPCC_RTC__  // (host side)
 inline bool nuts_wide_supported(int tkind, int met_ndim, long long D) {
   // (D = 1e4 with a diagonal-Gaussian target needs 160 000 of the CU's 163 840 bytes of LDS for q
   //  and dU/dq; the kernel's small static arrays leave room for D up to 10176)
@@ -638,5 +652,6 @@ inline hipError_t launch_nuts_wide(const EngineArgs &a, hipStream_t st) {
   if (D <= 8192) return launch_nuts_wide_tr<512, 16, true>(a, st);
   return launch_nuts_wide_tr<512, 20, true>(a, st);
 }
+#endif  // __HIPCC_RTC__
 
 }  // namespace aehmc

@@ -67,10 +67,12 @@ def oracle_nuts(tgt, seeds, q0, eps, imm, max_exp, n):
 
 
 @pytest.mark.parametrize("D,metric,resident", [(10, "diag", 2), (10, "diag", 0), (70, "diag", 2), (300, "diag", 2),
-                                               (40, "dense", 2), (90, "dense", 2), (600, "diag", 2)])
+                                               (40, "dense", 2), (90, "dense", 2), (600, "diag", 2), (600, "diag", 0),
+                                               (1500, "diag", 2), (5000, "diag", 2)])
 def test_custom_target_nuts_matches_numpy(eng, D, metric, resident):
-    """register-resident kernel (D <= 512, diagonal / scalar metric), lock-step engine (resident_nuts = 0, dense metrics
-    in both dense modes' default, D > 512): all compiled at run time against the user's function"""
+    """register-resident kernel (D <= 512, diagonal / scalar metric), workgroup-per-chain kernel (512 < D <= 10176:
+    k_nuts_wide, q and dU/dq in LDS above D = 4096; round 5), lock-step engine (resident_nuts = 0, dense metrics): all
+    compiled at run time against the user's function"""
     from aehmc_amd import RandomStream, nuts, targets
     eng.set_option("resident_nuts", resident)
     r = np.random.default_rng(D + len(metric))
