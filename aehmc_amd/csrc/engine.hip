@@ -323,6 +323,7 @@ static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vec
     src += "#include \"engine.cuh\"\n";
     if (which == "nuts" || which == "jnuts") src += "#include \"nuts_resident.cuh\"\n";
     if (which == "wide") src += "#include \"nuts_wide.cuh\"\n";
+    if (which == "block") src += "#include \"nuts_block_reg.cuh\"\n";
     if (which == "hmc") src += "#include \"hmc_fused.cuh\"\n";
     if (which == "glm") src += "#include \"glm_rows.cuh\"\n";
     const std::string inc = "-I" + ctx->custom_inc;
@@ -1257,7 +1258,8 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   // mid-size dense problems (shared dense metric, 64 < D <= 512, linear dense mode): a workgroup per 16 chains runs
   // the lock-step loop itself, products on MFMA inside the workgroup (nuts_block.cuh)
   if (want_resident && ctx->opt_block_dense && ctx->opt_dense_linear &&
-      block_dense_supported(tkind, nd, ctx->met.per_chain, D))
+      (block_dense_supported(tkind, nd, ctx->met.per_chain, D) ||
+       (tkind == AEHMC_T_CUSTOM && nd == 2 && !ctx->met.per_chain && D >= BLK_MIN_D && D <= BLK_MAX_D)))  // (run-time compiled)
     return NUTS_PATH_BLOCK_DENSE;
   // one dense metric per chain (what full-matrix window adaptation returns), 64 < D <= 512, coordinate-wise target: a
   // wavefront per chain runs the whole call and streams its own matrix (nuts_pc_dense.cuh)
@@ -1374,7 +1376,19 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     if (int rc = block_pack_workspace(ctx, a.D, &bp)) return rc;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(tu::nuts_block_roll(a, m, bp, st));
+    if (a.tkind == AEHMC_T_CUSTOM) {  // the transition-by-transition kernels, compiled against the user's function
+      BlkMats mats;
+      HIPCHK(blk_pack_matrices(a, nullptr, bp, mats, st));
+      EngineArgs b = a;
+      b.imm = mats.imm; b.sqrt_mass = mats.sqrt_mass;
+      const bool reg = ctx->opt_block_dense != 2 && block_reg_supported(a.D);
+      const std::string name = reg ? "aehmc::k_nuts_block_reg<" + std::string(a.D <= 128 ? "2" : "4") + ", false>"
+                                   : std::string("aehmc::k_nuts_block_dense<false>");
+      const size_t dyn = reg ? blk_reg_lds_bytes(a.D) : blk_lds_bytes(a.D);
+      if (int rc = rtc_launch(ctx, "block", {name}, name, dim3((unsigned)((C + BLK_CHAINS - 1) / BLK_CHAINS)),
+                              dim3(BLK_THREADS), dyn, st, b, m))
+        return rc;
+    } else if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(tu::nuts_block_roll(a, m, bp, st));
     else if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(tu::nuts_block_reg(a, m, bp, st));
     else HIPCHK(tu::nuts_block_dense(a, m, bp, st));
     return prof_end(ctx, st, p);

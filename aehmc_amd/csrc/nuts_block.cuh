@@ -27,10 +27,17 @@
 // Reference: nuts.py:56-153, trajectory.py:154-374,428-714, termination.py:85-235, hmc.py:77-204,
 // integrators.py:54-73, metrics.py:44-104.
 #pragma once
+#ifndef __HIPCC_RTC__  /* (hipRTC supplies the runtime itself) */
 #include <hip/hip_runtime.h>
+#endif
 
 #include "engine.cuh"
+#ifndef __HIPCC_RTC__
 #include "gemm_f64.cuh"
+#else  // run-time compiled copy (user-defined target with a dense metric): only the vector types of gemm_f64.cuh
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+#endif
 
 namespace aehmc {
 
@@ -45,6 +52,7 @@ constexpr int BLK_PREFETCH = AEHMC_BLK_PREFETCH;  // K-tiles of the matrix in fl
 __host__ __device__ inline long long blk_lds_stride(long long D) { return (D + 15) / 16 * 16 + 2; }  // = 2 mod 4: fragment reads hit every bank twice
 constexpr int BLK_TB = 16 * 16;  // doubles of a wavefront's B staging tile ([16 rows][16], columns swizzled)
 // operand rows [16][S] + one staging tile per wavefront
+#ifndef __HIPCC_RTC__  // (host side)
 inline size_t blk_lds_bytes(long long D) {
   return ((size_t)BLK_CHAINS * blk_lds_stride(D) + (size_t)BLK_CHAINS * BLK_TB) * sizeof(double);
 }
@@ -53,6 +61,7 @@ inline bool block_dense_supported(int tkind, int met_ndim, int per_chain, long l
   const bool elem = tkind == AEHMC_T_STD_NORMAL || tkind == AEHMC_T_ISO_GAUSSIAN || tkind == AEHMC_T_DIAG_GAUSSIAN;
   return met_ndim == 2 && !per_chain && (elem || tkind == AEHMC_T_DENSE_MVN) && D >= BLK_MIN_D && D <= BLK_MAX_D;
 }
+#endif  // __HIPCC_RTC__
 
 // The matrices of a launch, zero-padded to [Dp][Dp] with Dp = D rounded up to 16 (a ctx-owned copy, rewritten by
 // every call: the caller's matrices may have changed): the product loop then needs no bounds predicates at all --
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_dense(EngineArgs a, c
   }
 }
 
+#ifndef __HIPCC_RTC__  // (host side)
 // bp: the packed matrices [3][Dp][Dp] -- inverse mass matrix, L^-T, precision (dense target only)
 struct BlkMats {
   const double *imm, *sqrt_mass, *prec;
@@ -373,5 +383,6 @@ inline hipError_t launch_hmc_block_dense(EngineArgs a, const double *prec, long 
 #undef AEHMC_BLK
   return hipGetLastError();
 }
+#endif  // __HIPCC_RTC__
 
 }  // namespace aehmc

@@ -16,20 +16,24 @@
 // Reference: nuts.py:56-153, trajectory.py:154-374,428-714, termination.py:85-235, proposals.py:19-174,
 // hmc.py:77-204, integrators.py:54-73, metrics.py:44-104.
 #pragma once
+#ifndef __HIPCC_RTC__  /* (hipRTC supplies the runtime itself) */
 #include <hip/hip_runtime.h>
+#endif
 
 #include "nuts_block.cuh"
 
 namespace aehmc {
 
 constexpr int BLK_REG_MAX_D = 256;
-inline bool block_reg_supported(long long D) { return D >= BLK_MIN_D && D <= BLK_REG_MAX_D; }
 constexpr int BLK_PARK = 20;  // doubles per wavefront: the chain's four generators (see k_nuts_block_reg) + the rolling kernel's between-transition scalars
+#ifndef __HIPCC_RTC__  // (host side)
+inline bool block_reg_supported(long long D) { return D >= BLK_MIN_D && D <= BLK_REG_MAX_D; }
 // two row buffers [16][S] (operand / result, swapping roles from product to product) + one staging tile per wavefront
 // + the target's mean [S] + the parking areas
 inline size_t blk_reg_lds_bytes(long long D) {
   return ((size_t)(2 * BLK_CHAINS + 1) * blk_lds_stride(D) + (size_t)BLK_CHAINS * (BLK_TB + BLK_PARK)) * sizeof(double);
 }
+#endif  // __HIPCC_RTC__
 
 // the chain's four generators have their home in LDS (d + 4 k): a draw loads ONE of them, advances it and puts it
 // back -- 8 registers for the duration of the draw instead of 32 for the duration of the launch
@@ -206,16 +210,22 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
     d_r = wave_sum(d_r);
     const bool turning = (d_l <= 0) | (d_r <= 0);
     put2(ct.U_end, dir, ct.U_cur);
-    ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;  // trajectory.py:551-553
-    double pbias = exp(ct.sub_w - ct.prop_w);            // proposals.py:130 (always drawn)
+    // trajectory.py:551-553, proposals.py:130 (always drawn), 141-144, trajectory.py:560-564: the four transcendental
+    // chains -- two exponentials, two logaddexp -- in four lanes at once (engine.cuh nuts_expansion_scalars: the same
+    // instruction sequences, the same bits; round 5: five inlined exp / log1p expansions were ~40 % of this lambda's
+    // vector instructions, and the wavefront that runs it is the one its whole workgroup waits for)
+    const bool keep = is_div || has_term;
+    const ExpansionScalars es = nuts_expansion_scalars(ct.sub_w, ct.prop_w, ct.sub_slpa, ct.prop_slpa, keep, lane);
+    ct.acc_prob = es.e_slpa / (double)ct.length;
+    double pbias = es.e_ratio;
     if (pbias > 1.0) pbias = 1.0;
     if (pbias < 0.0) pbias = 0.0;
     const int acc_b = blk_bernoulli(park, 3, pbias, lane);
-    if (is_div || has_term) {
-      ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);  // trajectory.py:560-564
+    if (keep) {
+      ct.prop_slpa = es.la_slpa;
     } else {
-      ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);           // proposals.py:141-144
-      ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
+      ct.prop_w = es.la_w;
+      ct.prop_slpa = es.la_slpa;
       if (acc_b) {
         ct.prop_slot ^= 1;
         ct.prop_E = ct.sub_E;
@@ -731,6 +741,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_hmc_block_reg(EngineArgs a, con
 #undef AT
 }
 
+#ifndef __HIPCC_RTC__  // (host side)
 template <int R>
 inline hipError_t launch_nuts_block_reg_r(const EngineArgs &a, const NutsSampleArgs &m, hipStream_t st) {
   const size_t dyn = blk_reg_lds_bytes(a.D);
@@ -780,5 +791,6 @@ inline hipError_t launch_hmc_block_reg(EngineArgs a, const double *prec, long lo
   return a.D <= 128 ? launch_hmc_block_reg_r<2>(a, mats.prec, L, nt, samples, acc_hist, div_hist, st)
                     : launch_hmc_block_reg_r<4>(a, mats.prec, L, nt, samples, acc_hist, div_hist, st);
 }
+#endif  // __HIPCC_RTC__
 
 }  // namespace aehmc

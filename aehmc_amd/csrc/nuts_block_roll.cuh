@@ -206,16 +206,22 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
     d_r = wave_sum(d_r);
     const bool turning = (d_l <= 0) | (d_r <= 0);
     put2(ct.U_end, dir, ct.U_cur);
-    ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;  // trajectory.py:551-553
-    double pbias = exp(ct.sub_w - ct.prop_w);            // proposals.py:130 (always drawn)
+    // trajectory.py:551-553, proposals.py:130 (always drawn), 141-144, trajectory.py:560-564: the four transcendental
+    // chains -- two exponentials, two logaddexp -- in four lanes at once (engine.cuh nuts_expansion_scalars: the same
+    // instruction sequences, the same bits; round 5: five inlined exp / log1p expansions were ~40 % of this lambda's
+    // vector instructions, and the wavefront that runs it is the one its whole workgroup waits for)
+    const bool keep = is_div || has_term;
+    const ExpansionScalars es = nuts_expansion_scalars(ct.sub_w, ct.prop_w, ct.sub_slpa, ct.prop_slpa, keep, lane);
+    ct.acc_prob = es.e_slpa / (double)ct.length;
+    double pbias = es.e_ratio;
     if (pbias > 1.0) pbias = 1.0;
     if (pbias < 0.0) pbias = 0.0;
     const int acc_b = blk_bernoulli(park, 3, pbias, lane);
-    if (is_div || has_term) {
-      ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);  // trajectory.py:560-564
+    if (keep) {
+      ct.prop_slpa = es.la_slpa;
     } else {
-      ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);           // proposals.py:141-144
-      ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
+      ct.prop_w = es.la_w;
+      ct.prop_slpa = es.la_slpa;
       if (acc_b) {
         ct.prop_slot ^= 1;
         ct.prop_E = ct.sub_E;

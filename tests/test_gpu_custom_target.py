@@ -67,11 +67,13 @@ def oracle_nuts(tgt, seeds, q0, eps, imm, max_exp, n):
 
 
 @pytest.mark.parametrize("D,metric,resident", [(10, "diag", 2), (10, "diag", 0), (70, "diag", 2), (300, "diag", 2),
-                                               (40, "dense", 2), (90, "dense", 2), (600, "diag", 2), (600, "diag", 0),
+                                               (40, "dense", 2), (90, "dense", 2), (200, "dense", 2), (300, "dense", 2),
+                                               (600, "diag", 2), (600, "diag", 0),
                                                (1500, "diag", 2), (5000, "diag", 2)])
 def test_custom_target_nuts_matches_numpy(eng, D, metric, resident):
     """register-resident kernel (D <= 512, diagonal / scalar metric), workgroup-per-chain kernel (512 < D <= 10176:
-    k_nuts_wide, q and dU/dq in LDS above D = 4096; round 5), lock-step engine (resident_nuts = 0, dense metrics): all
+    k_nuts_wide, q and dU/dq in LDS above D = 4096; round 5), block-resident kernels (shared dense metric, 64 < D <= 512:
+    k_nuts_block_reg / k_nuts_block_dense; round 5), lock-step engine (resident_nuts = 0, small dense problems): all
     compiled at run time against the user's function"""
     from aehmc_amd import RandomStream, nuts, targets
     eng.set_option("resident_nuts", resident)
