@@ -16,6 +16,11 @@ STAMP = LIB + ".srchash"
 
 
 def source_files():
+    for d in (CSRC, INCLUDE):
+        if not os.path.isdir(d):  # (an installed copy without the repository's include/ or csrc/ directory)
+            raise RuntimeError(f"aehmc_amd: {d} is missing -- the library is built from, and checked against, the sources "
+                               "in aehmc_amd/csrc and include/ of its repository checkout (run from the checkout, or set "
+                               "AEHMC_AMD_LIB to a library you built yourself)")
     files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
              if f.endswith((".hip", ".cuh", ".h")) or f == "Makefile"]
     files += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]

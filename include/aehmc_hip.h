@@ -21,7 +21,10 @@
  *  - `stream` is a hipStream_t passed as void*; work is enqueued on it in order.  NUTS
  *    polls a pinned "chains still active" word to stop launching early, so a NUTS call
  *    may block the host for part of its duration; results are complete on `stream`.
- *  - a ctx is not thread-safe; distinct ctxs are independent; no global state.
+ *  - a ctx is not thread-safe; distinct ctxs are independent; no global state.  ONE STREAM PER CTX at a time: the
+ *    ctx owns scratch that every call rewrites on the call's stream (the packed matrices of the block-resident dense
+ *    kernels, per-chain factorisation scratch, the GLM work arrays), so calls on two streams may only share a ctx if
+ *    the caller orders them (events); use one ctx per stream otherwise.
  *  - RNG ("scheme A"): per chain, one PCG64 per RNG call site of the
  *    reference graph, in graph-construction order; rng is uint64 [C, n_sites, 4] =
  *    (state_hi, state_lo, inc_hi, inc_lo), advanced in place exactly as numpy's
