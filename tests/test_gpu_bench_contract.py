@@ -80,7 +80,7 @@ def test_bench_c3_small_line():
     d = _run("--steps", "2", "--warmup", "1", "--chains", "256", "--dim", "1024", "--no-cpu-baseline")
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["launches"] > 0
-    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac"] < 1
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4) and 0 < r["frac"] < 1
     assert d["config"]["leapfrogs_per_step"] > 0 and d["value"] > 0
 
 
@@ -127,7 +127,7 @@ def test_bench_c4_and_c5_two_rank_dry_runs():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["chains_total"] == 128 and d["value"] > 0
     r = d["roofline"]
     assert r["bound"] == "valu" and r["kernel"] == "k_nuts_linreg" and r["launches"] == 1
-    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0 < r["frac"] < 1
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4) and 0 < r["frac"] < 1
 
 
 def test_bench_default_line_has_its_good_secondary_entries():
