@@ -22,7 +22,7 @@ def source_files():
                                "in aehmc_amd/csrc and include/ of its repository checkout (run from the checkout, or set "
                                "AEHMC_AMD_LIB to a library you built yourself)")
     files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
-             if f.endswith((".hip", ".cuh", ".h")) or f == "Makefile"]
+             if f.endswith((".hip", ".cuh", ".h", ".inc")) or f == "Makefile"]
     files += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
     return sorted(files)
 

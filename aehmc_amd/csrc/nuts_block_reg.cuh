@@ -138,291 +138,49 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
   BlkTimer tm;
   __shared__ int blk_alive[BLK_CHAINS];  // the round's vote (the barriers order LDS traffic only: blk_barrier_lds)
 
-  // first stages of a leapfrog (leap_linear<12>): p_half, v_half, q', the target where it is coordinate-wise, and the
-  // operand row of the next product -- r = q' - mu (dense target) or dU/dq' itself -- into this chain's row of xbuf
-  auto stage12 = [&]() __attribute__((always_inline)) {
-    const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
-    const double b = 0.5 * step_size, aa = 1 * step_size;
-    double usum = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (ok[r]) {
-        const double pp = p[r] - b * grow[EI(r)];
-        const double vv = v[r] - b * wrow[EI(r)];
-        p[r] = pp;
-        v[r] = vv;
-        const double qq = q[r] + aa * vv;
-        q[r] = qq;
-        if (!TDENSE) {
-          double u, gnew;
-          target_elem(a, EI(r), qq, u, gnew);
-          usum += u;
-          xrow[EI(r)] = gnew;  // (= grow: the new gradient over the old one, and the next product's operand)
-        } else {
-          xrow[EI(r)] = qq - mus[EI(r)];
-        }
-      }
-    }
-    if (!TDENSE) ct.U_cur = target_finish(a, wave_sum(usum));
-  };
-  // sub-trajectory proposal <- moving end (copy_cur_to_slot)
-  auto take = [&](int slot) __attribute__((always_inline)) {
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (ok[r]) {
-        AT(pick2(a.slot_q, slot), r) = q[r];
-        AT(pick2(a.slot_p, slot), r) = p[r];
-        AT(pick2(a.slot_g, slot), r) = grow[EI(r)];
-      }
-    }
-    put2(ct.U_slot, slot, ct.U_cur);
-  };
-  // expand_once after integrate() returned (nuts_finalize_expansion<true> + nuts_write_outputs / nuts_begin_expansion)
-  auto finalize = [&](bool is_div, bool has_term) __attribute__((always_inline)) {
-    const int dir = ct.dir, oth = 1 - dir;
-    double d_l = 0.0, d_r = 0.0;
-    double pov[R], vov[R], psv[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      pov[r] = ok[r] ? AT(pick2(a.end_p, oth), r) : 0.0;
-      vov[r] = ok[r] ? AT(pick2(a.end_v, oth), r) : 0.0;
-      psv[r] = ok[r] ? AT(a.psum, r) : 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (ok[r]) {
-        const double pc = p[r], po = pov[r], vc = v[r], vo = vov[r];
-        const double s = psv[r] + pb[r];
-        AT(a.psum, r) = s;
-        const double pl = dir ? po : pc, pr = dir ? pc : po;
-        const double vl = dir ? vo : vc, vr = dir ? vc : vo;
-        const double rho = s - (pr + pl) / 2;
-        d_l += vl * rho;
-        d_r += vr * rho;
-        AT(pick2(a.end_q, dir), r) = q[r];
-        AT(pick2(a.end_p, dir), r) = pc;
-        AT(pick2(a.end_g, dir), r) = grow[EI(r)];
-        AT(pick2(a.end_v, dir), r) = vc;
-        AT(pick2(a.end_w, dir), r) = wrow[EI(r)];
-      }
-    }
-    d_l = wave_sum(d_l);
-    d_r = wave_sum(d_r);
-    const bool turning = (d_l <= 0) | (d_r <= 0);
-    put2(ct.U_end, dir, ct.U_cur);
-    // trajectory.py:551-553, proposals.py:130 (always drawn), 141-144, trajectory.py:560-564: the four transcendental
-    // chains -- two exponentials, two logaddexp -- in four lanes at once (engine.cuh nuts_expansion_scalars: the same
-    // instruction sequences, the same bits; round 5: five inlined exp / log1p expansions were ~40 % of this lambda's
-    // vector instructions, and the wavefront that runs it is the one its whole workgroup waits for)
-    const bool keep = is_div || has_term;
-    const ExpansionScalars es = nuts_expansion_scalars(ct.sub_w, ct.prop_w, ct.sub_slpa, ct.prop_slpa, keep, lane);
-    ct.acc_prob = es.e_slpa / (double)ct.length;
-    double pbias = es.e_ratio;
-    if (pbias > 1.0) pbias = 1.0;
-    if (pbias < 0.0) pbias = 0.0;
-    const int acc_b = blk_bernoulli(park, 3, pbias, lane);
-    if (keep) {
-      ct.prop_slpa = es.la_slpa;
-    } else {
-      ct.prop_w = es.la_w;
-      ct.prop_slpa = es.la_slpa;
-      if (acc_b) {
-        ct.prop_slot ^= 1;
-        ct.prop_E = ct.sub_E;
-      }
-    }
-    ct.ndoubl = ct.j + 1;
-    ct.out_div = is_div;
-    ct.out_turn = turning;
-    const bool end_transition = is_div || turning || has_term || (ct.j + 1 == a.max_exp);
-    if (end_transition) {  // nuts_write_outputs
-      const int s = ct.prop_slot;
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (ok[r]) {
-          AT(a.q, r) = AT(pick2(a.slot_q, s), r);
-          AT(a.g, r) = AT(pick2(a.slot_g, s), r);
-          if (a.out.momentum) AT(a.out.momentum, r) = AT(pick2(a.slot_p, s), r);
-        }
-      }
-      if (lane == 0) {
-        a.U[c] = pick2(ct.U_slot, s);
-        a.out.acceptance_probability[c] = ct.acc_prob;
-        if (a.out.num_doublings) a.out.num_doublings[c] = ct.ndoubl;
-        if (a.out.is_turning) a.out.is_turning[c] = ct.out_turn;
-        a.out.is_diverging[c] = ct.out_div;
-        if (a.out.n_leapfrog) a.out.n_leapfrog[c] = ct.nleap;
-      }
-      ct.done = 1;  // (the caller keeps the chain alive while a phantom scan is pending)
-    } else {        // nuts_begin_expansion
-      ct.j += 1;
-      const int go_right = blk_bernoulli(park, 1, 0.5, lane);  // trajectory.py:516
-      ct.dir = go_right;
-      ct.step = 0;
-      if (dir != go_right) {  // cur <- the other end (trajectory.py:518)
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          if (ok[r]) {
-            q[r] = AT(pick2(a.end_q, go_right), r);
-            p[r] = AT(pick2(a.end_p, go_right), r);
-            grow[EI(r)] = AT(pick2(a.end_g, go_right), r);
-            v[r] = AT(pick2(a.end_v, go_right), r);
-            wrow[EI(r)] = AT(pick2(a.end_w, go_right), r);
-          }
-        }
-        ct.U_cur = pick2(ct.U_end, go_right);
-      }
-    }
-  };
-  // last stage of the leapfrog + one iteration of dynamic_integration's scan (nuts_book<true, 1>)
-  auto book = [&]() __attribute__((always_inline)) {
-    const int step = ct.step;
-    if (!ct.phantom) ct.nleap += 1;
-    int tmin, tmax;
-    if (step == 0) {  // termination.py:109-113: indices inherited from the previous sub-trajectory
-      tmin = ct.tmin;
-      tmax = ct.tmax;
-    } else {          // termination.py:192-235 in closed form
-      const int n1 = __ffs(~step) - 1;
-      tmax = __popc(step >> 1);
-      tmin = tmax - n1 + 1;
-    }
-    const bool even = (step & 1) == 0;
-    const bool f_turn = step >= 1 && tmax >= tmin;
-    const double step_size = (ct.dir ? 1.0 : -1.0) * eps;
-    const double b = 0.5 * step_size;
-    double *const ckp = a.ckp + ((size_t)tmax * a.C + c) * D;
-    double *const cks = a.cks + ((size_t)tmax * a.C + c) * D;
-    double *const ckv = a.ckv + ((size_t)tmax * a.C + c) * D;
-    double kpv[R], kvv[R], ksv[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {  // (loaded before this step's pair is stored over them)
-      kpv[r] = (f_turn && ok[r]) ? ckp[EI(r)] : 0.0;
-      kvv[r] = (f_turn && ok[r]) ? ckv[EI(r)] : 0.0;
-      ksv[r] = (f_turn && ok[r]) ? cks[EI(r)] : 0.0;
-    }
-    double usum = 0.0, kd = 0.0, f_dl = 0.0, f_dr = 0.0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      if (ok[r]) {
-        const double gr = grow[EI(r)], wr = wrow[EI(r)];
-        if (TDENSE) usum += (q[r] - mus[EI(r)]) * gr;  // leap_linear<3>
-        const double pn = p[r] - b * gr;
-        const double vn = v[r] - b * wr;
-        p[r] = pn;
-        v[r] = vn;
-        kd += vn * pn;                                            // bookkeeping
-        const double s = (step == 0) ? pn : pb[r] + pn;
-        pb[r] = s;
-        if (even) {
-          ckp[EI(r)] = pn;
-          cks[EI(r)] = s;
-          ckv[EI(r)] = vn;
-        }
-        if (f_turn) {                                             // first level of is_iterative_turning
-          const double pl = kpv[r], vl = kvv[r];
-          const double sub = s - ksv[r] + pl;
-          const double rho = sub - (pn + pl) / 2;
-          f_dl += vl * rho;
-          f_dr += vn * rho;
-        }
-      }
-    }
-    tm.tick(0);  // (timing build) vector pass incl. the first-level checkpoint loads
-    if (TDENSE) ct.U_cur = target_finish(a, wave_sum(usum));
-    kd = wave_sum(kd);
-    ct.tmin = tmin;
-    ct.tmax = tmax;
-    const double E = ct.U_cur + 0.5 * kd;  // proposals.py:19-62
-    double delta = ct.H0 - E;
-    if (isnan(delta)) delta = -INFINITY;
-    const bool div = fabs(delta) > a.thr;
-    const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
-    bool term = false, do_take = false;
-    if (step == 0) {
-      ct.sub_E = E;
-      ct.sub_w = np_w;
-      ct.sub_slpa = np_slpa;
-      ct.length = 1;
-      do_take = true;
-    } else {
-      const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
-      const int acc = blk_bernoulli(park, 2, sc.pa, lane);
-      ct.sub_w = sc.sub_w;
-      ct.sub_slpa = sc.sub_slpa;
-      if (acc) {
-        ct.sub_E = E;
-        do_take = !ct.phantom;
-      }
-      ct.length += 1;
-    }
-    if (do_take) take(ct.prop_slot ^ 1);  // sub-trajectory proposal <- moving end (one call site: the copy is inlined once)
-    tm.tick(1);  // (timing build) reductions, step scalars, accept draw, proposal copy
-    if (step >= 1) {
-      if (tmax >= tmin) {  // termination.py:133-187
-        int idx = tmax;
-        bool crit = false;
-        for (;;) {
-          double d_l = 0.0, d_r = 0.0;
-          if (idx == tmax) {
-            d_l = f_dl;
-            d_r = f_dr;
-          } else {
-            const double *kp = a.ckp + ((size_t)idx * a.C + c) * D;
-            const double *ks = a.cks + ((size_t)idx * a.C + c) * D;
-            const double *kv = a.ckv + ((size_t)idx * a.C + c) * D;
-            double lp[R], lv[R], ls[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-              lp[r] = ok[r] ? kp[EI(r)] : 0.0;
-              lv[r] = ok[r] ? kv[EI(r)] : 0.0;
-              ls[r] = ok[r] ? ks[EI(r)] : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-              if (ok[r]) {
-                const double pl = lp[r], pr = p[r], vl = lv[r], vr = v[r];
-                const double sub = pb[r] - ls[r] + pl;
-                const double rho = sub - (pr + pl) / 2;
-                d_l += vl * rho;
-                d_r += vr * rho;
-              }
-            }
-          }
-          d_l = wave_sum(d_l);
-          d_r = wave_sum(d_r);
-          crit = (d_l <= 0) | (d_r <= 0);
-          const bool reached = (idx - 1) < tmin;
-          idx -= 1;
-          if (crit || reached) break;
-        }
-        term = crit;
-      }
-    }
-    bool fin = false, fin_div = false, fin_term = false, to_phantom = false;
-    if (step == 0 && div && !ct.phantom) {
-      // trajectory.py:336: integrate() returns the first-step tuple, yet the scan still executes (and draws from
-      // site #3): finalize now, keep stepping as a phantom
-      fin = fin_div = to_phantom = true;
-    } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
-      if (ct.phantom) ct.done = 1;
-      else {
-        fin = true;
-        fin_div = div;
-        fin_term = term;
-      }
-    } else {
-      ct.step = step + 1;
-    }
-    if (fin) {  // (one call site: the expansion code is inlined once)
-      finalize(fin_div, fin_term);
-      if (to_phantom) {
-        ct.done = 0;
-        ct.phantom = 1;
-        ct.step = 1;
-      }
-    }
-  };
+#define BT_LC lane
+#define BTA(ptr, r) ((ptr) + row)[lc + 64 * (r)]
+#define BT_SLOT_Q(s) pick2(a.slot_q, s)
+#define BT_SLOT_P(s) pick2(a.slot_p, s)
+#define BT_SLOT_G(s) pick2(a.slot_g, s)
+#define BT_END_Q(e) pick2(a.end_q, e)
+#define BT_END_P(e) pick2(a.end_p, e)
+#define BT_END_G(e) pick2(a.end_g, e)
+#define BT_END_V(e) pick2(a.end_v, e)
+#define BT_END_W(e) pick2(a.end_w, e)
+#define BT_PSUM a.psum
+#define BT_TAKE_W(slot, r) (void)0
+#define BT_OUT_Q a.q
+#define BT_OUT_G a.g
+#define BT_OUT_U a.U
+#define BT_OUT_MOM a.out.momentum
+#define BT_OUT_ACC a.out.acceptance_probability
+#define BT_OUT_NDOUBL a.out.num_doublings
+#define BT_OUT_TURN a.out.is_turning
+#define BT_OUT_DIV a.out.is_diverging
+#define BT_OUT_NLEAP a.out.n_leapfrog
+#include "nuts_block_tree.inc"
+#undef BT_LC
+#undef BTA
+#undef BT_SLOT_Q
+#undef BT_SLOT_P
+#undef BT_SLOT_G
+#undef BT_END_Q
+#undef BT_END_P
+#undef BT_END_G
+#undef BT_END_V
+#undef BT_END_W
+#undef BT_PSUM
+#undef BT_TAKE_W
+#undef BT_OUT_Q
+#undef BT_OUT_G
+#undef BT_OUT_U
+#undef BT_OUT_MOM
+#undef BT_OUT_ACC
+#undef BT_OUT_NDOUBL
+#undef BT_OUT_TURN
+#undef BT_OUT_DIV
+#undef BT_OUT_NLEAP
 
   blk_barrier_lds();
   for (long long t_idx = 0; t_idx < m.T; t_idx++) {
