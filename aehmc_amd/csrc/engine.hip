@@ -1644,13 +1644,16 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   }
   EngineArgs a;
   if (int rc = fill_args(ctx, C, 1, a)) return rc;
-  if (ctx->opt_fused_hmc && hmc_resident_supported(ctx->tgt.kind, ctx->met.ndim, D)) {
+  // (a user-defined coordinate-wise target: the same kernel compiled against the user's function at run time, round 5)
+  const bool custom_wide = ctx->tgt.kind == AEHMC_T_CUSTOM && ctx->met.ndim < 2 && D > 1024 && D <= 10240;
+  if (ctx->opt_fused_hmc && (custom_wide || hmc_resident_supported(ctx->tgt.kind, ctx->met.ndim, D))) {
     HmcFusedArgs f{};
     f.C = C; f.D = D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
     f.met_ndim = ctx->met.ndim; f.imm = ctx->met.imm; f.sqrt_mass = ctx->met.sqrt_mass;
     f.imm_cs = ctx->met.per_chain ? (ctx->met.ndim == 0 ? 1 : D) : 0;
     f.eps_c = ctx->eps_c;
     f.tkind = ctx->tgt.kind; f.mu = ctx->tgt.mu; f.sigma = ctx->tgt.sigma; f.log_sigma = ctx->log_sigma;
+    f.cparams = ctx->d_cparams;
     f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
     f.fc = ctx->opt_fp_contract;
     // A launch pair per CHUNK of transitions: the momenta of the chunk are drawn first, at one wavefront per
@@ -1680,7 +1683,15 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
       f.acc_hist = acc_hist ? acc_hist + (size_t)t0 * C : nullptr;
       f.div_hist = div_hist ? div_hist + (size_t)t0 * C : nullptr;
       f.out.momentum = t0 + nt == T ? out->momentum : nullptr;  // only the last transition's is observable
-      HIPCHK(tu::hmc_resident(f, zall, nt, st));
+      if (custom_wide) {  // launch_hmc_resident's table
+        const int TT = D <= 2048 ? 256 : (D <= 4096 ? 512 : 1024), R = D <= 8192 ? 8 : 10;
+        const std::string name = "aehmc::k_hmc_wide<" + std::to_string(TT) + ", " + std::to_string(R) + ", " +
+                                 std::to_string((int)AEHMC_T_CUSTOM) + ", " + (f.fc ? "true" : "false") + ">";
+        if (int rc = rtc_launch(ctx, "hmc", {name}, name, dim3((unsigned)C), dim3(TT), 0, st, f, (const double *)zall, nt))
+          return rc;
+      } else {
+        HIPCHK(tu::hmc_resident(f, zall, nt, st));
+      }
     }
     if (T > 1 && out->n_leapfrog)
       LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
@@ -1745,13 +1756,26 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   }
   // mid-size dense problems (shared dense metric, 64 < D <= 512, linear dense mode): all T transitions in one launch,
   // a workgroup per 16 chains, products on MFMA inside the workgroup (nuts_block.cuh)
+  const bool custom_block = a.tkind == AEHMC_T_CUSTOM && a.met_ndim == 2 && !ctx->met.per_chain && D >= BLK_MIN_D && D <= BLK_MAX_D;
   if (ctx->opt_fused_hmc && ctx->opt_block_dense && a.linear &&
-      block_dense_supported(a.tkind, a.met_ndim, ctx->met.per_chain, D)) {
+      (custom_block || block_dense_supported(a.tkind, a.met_ndim, ctx->met.per_chain, D))) {
     double *bp = nullptr;
     if (int rc = block_pack_workspace(ctx, D, &bp)) return rc;
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (ctx->opt_block_dense != 2 && block_reg_supported(D))
+    if (custom_block) {  // user-defined coordinate-wise target: the same kernels, compiled against the user's function (round 5)
+      BlkMats mats;
+      HIPCHK(blk_pack_matrices(a, nullptr, bp, mats, st));
+      EngineArgs b = a;
+      b.imm = mats.imm; b.sqrt_mass = mats.sqrt_mass;
+      const bool reg = ctx->opt_block_dense != 2 && block_reg_supported(D);
+      const std::string name = reg ? "aehmc::k_hmc_block_reg<" + std::string(D <= 128 ? "2" : "4") + ", false>"
+                                   : std::string("aehmc::k_hmc_block_dense<false>");
+      const size_t dyn = reg ? blk_reg_lds_bytes(D) : blk_lds_bytes(D);
+      if (int rc = rtc_launch(ctx, "block", {name}, name, dim3((unsigned)((C + BLK_CHAINS - 1) / BLK_CHAINS)), dim3(BLK_THREADS),
+                              dyn, st, b, (const double *)nullptr, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist))
+        return rc;
+    } else if (ctx->opt_block_dense != 2 && block_reg_supported(D))
       HIPCHK(tu::hmc_block_reg(a, ctx->tgt.prec, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist, bp, st));
     else
       HIPCHK(tu::hmc_block_dense(a, ctx->tgt.prec, (long long)L, (long long)T, samples, acc_hist, (int *)div_hist, bp, st));

@@ -291,7 +291,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(hmc_fused_m
 template <int T, int R, int TK, bool FC = false>
 __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zbuf, int nt) {
   constexpr int NW = T / 64;
-  constexpr bool DG = TK == AEHMC_T_DIAG_GAUSSIAN;  // otherwise dU/dq == q, no separate copy
+  // TK == AEHMC_T_CUSTOM exists only in the run-time compiled copy (aehmc_set_custom_target, round 5): the user's
+  // aehmc_custom_elem; dU/dq kept beside q and the caller's arrays as the fall-back state, as for the diagonal
+  // Gaussian, but no parameters of the engine's own in LDS
+  constexpr bool CU = TK == AEHMC_T_CUSTOM;
+  constexpr bool DG = TK == AEHMC_T_DIAG_GAUSSIAN || CU;  // otherwise dU/dq == q, no separate copy
+  constexpr bool DGP = DG && !CU;                          // sigma / mu in LDS
   __shared__ double red[2][2 * NW];
   extern __shared__ __attribute__((aligned(16))) double wide_save[];  // q [D] at the transition's start; DG: sigma [D], mu [D]
   double *const psig = wide_save, *const pmu = wide_save + a.D;       // (diagonal-Gaussian target only)
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
     p[r] = zrow[EI(r)];
     if (DG) g[r] = grow[EI(r)];
     im[r] = a.imm[imo + (a.met_ndim == 0 ? 0 : EI(r))];
-    if (DG) {  // (a thread reads back only the entries it wrote: no barrier)
+    if (DGP) {  // (a thread reads back only the entries it wrote: no barrier)
       const double sd0 = a.sigma[EI(r)];
       psig[EI(r)] = FC ? 1.0 / (sd0 * sd0) : sd0;  // FC: the reciprocal variance, formed once
       pmu[EI(r)] = a.mu[EI(r)];
@@ -382,7 +387,12 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
 #pragma unroll
           for (int r = 0; r < R; r++) {
             q[r] = __builtin_fma(aim[FC ? r : 0], p[r], q[r]);
-            if (DG) g[DG ? r : 0] = (q[r] - pmu[EI(r)]) * psig[EI(r)];  // psig holds 1 / sigma^2 in this mode
+            if (CU) {
+              double u_;
+              AEHMC_CUSTOM_ELEM(q[r], (long long)EI(r), u_, g[DG ? r : 0]);
+            } else if (DG) {
+              g[DG ? r : 0] = (q[r] - pmu[EI(r)]) * psig[EI(r)];  // psig holds 1 / sigma^2 in this mode
+            }
             p[r] = __builtin_fma(neg_eps, GR(r), p[r]);
           }
         }
@@ -390,7 +400,12 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
 #pragma unroll
         for (int r = 0; r < R; r++) {  // last drift, half kick
           q[r] = __builtin_fma(aim[FC ? r : 0], p[r], q[r]);
-          if (DG) g[DG ? r : 0] = (q[r] - pmu[EI(r)]) * psig[EI(r)];
+          if (CU) {
+            double u_;
+            AEHMC_CUSTOM_ELEM(q[r], (long long)EI(r), u_, g[DG ? r : 0]);
+          } else if (DG) {
+            g[DG ? r : 0] = (q[r] - pmu[EI(r)]) * psig[EI(r)];
+          }
           p[r] = __builtin_fma(-b, GR(r), p[r]);
         }
       }
@@ -401,8 +416,14 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
         for (int r = 0; r < R; r++) {
           double pp = p[r] - b * GR(r);
           const double qq = q[r] + aa * (im[r] * pp);
-          const double sd = psig[EI(r)];
-          const double gg = ((qq - pmu[EI(r)]) / sd) / sd;
+          double gg;
+          if (CU) {
+            double u_;
+            AEHMC_CUSTOM_ELEM(qq, (long long)EI(r), u_, gg);
+          } else {
+            const double sd = psig[EI(r)];
+            gg = ((qq - pmu[EI(r)]) / sd) / sd;
+          }
           pp = pp - b * gg;
           q[r] = qq;
           g[DG ? r : 0] = gg;
@@ -432,7 +453,10 @@ __global__ __launch_bounds__(T) void k_hmc_wide(HmcFusedArgs a, const double *zb
       double u;
       if (TK == AEHMC_T_STD_NORMAL) u = 0.5 * (qq * qq) + AEHMC_LOG_SQRT_2PI;
       else if (TK == AEHMC_T_ISO_GAUSSIAN) u = qq * qq;
-      else if (FC) {  // z^2 = d^2 / sigma^2 with the reciprocal variance in LDS
+      else if (CU) {  // (the potential is needed at the trajectory's end only: one more evaluation per transition)
+        double g_;
+        AEHMC_CUSTOM_ELEM(qq, (long long)EI(r), u, g_);
+      } else if (FC) {  // z^2 = d^2 / sigma^2 with the reciprocal variance in LDS
         const double d = qq - pmu[EI(r)];
         u = 0.5 * ((d * d) * psig[EI(r)]) + a.log_sigma[EI(r)] + AEHMC_LOG_SQRT_2PI;
       } else {

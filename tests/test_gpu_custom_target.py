@@ -109,15 +109,27 @@ def test_custom_target_nuts_matches_numpy(eng, D, metric, resident):
             assert bool(info.is_turning[c]) == bool(o.is_turning) and bool(info.is_diverging[c]) == bool(o.is_diverging)
 
 
-@pytest.mark.parametrize("D,fused", [(10, 1), (10, 0), (200, 1), (1500, 1)])
-def test_custom_target_hmc_matches_numpy(eng, D, fused):
-    """fused register-resident HMC (D <= 1024) and the lock-step engine"""
+@pytest.mark.parametrize("D,fused,metric", [(10, 1, "diag"), (10, 0, "diag"), (200, 1, "diag"), (1500, 1, "diag"),
+                                            (3000, 1, "diag"), (5000, 1, "diag"), (9000, 1, "diag"),
+                                            (100, 1, "dense"), (200, 1, "dense"), (300, 1, "dense"), (200, 0, "dense")])
+def test_custom_target_hmc_matches_numpy(eng, D, fused, metric):
+    """fused register-resident HMC (D <= 1024), the workgroup-per-chain kernel (1024 < D <= 10240: k_hmc_wide at 256 /
+    512 / 1024 threads; round 5), the block-resident kernels (shared dense metric, 64 < D <= 512: k_hmc_block_reg /
+    k_hmc_block_dense; round 5) and the lock-step engine, all compiled at run time against the user's function"""
     from aehmc_amd import RandomStream, hmc, targets
     eng.set_option("fused_hmc", fused)
     r = np.random.default_rng(D)
     nu, s = 3.0 + 5 * r.random(D), 0.5 + r.random(D)
     C, n, L, eps = 3, 3, 7, 0.2
-    q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
+    q0 = r.normal(size=(C, D))
+    if metric == "scalar":
+        imm = np.float64(0.8)
+    elif metric == "diag":
+        imm = 0.5 + r.random(D)
+    else:
+        A = r.normal(size=(D, D))
+        imm = A @ A.T / D + np.eye(D)
+        imm = 0.5 * (imm + imm.T)
     seeds = [90 + c for c in range(C)]
     tgt, otgt = targets.Custom(STUDENT_T, params=[nu, s]), StudentT(nu, s)
     kern = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
@@ -125,15 +137,48 @@ def test_custom_target_hmc_matches_numpy(eng, D, fused):
     okern = [no.hmc_kernel(no.RandomStream(sd), otgt) for sd in seeds]
     ostate = [no.new_state(q0[c].copy(), otgt) for c in range(C)]
     for _ in range(n):
-        info, _ = kern(state, eps, imm, L)
+        info, _ = kern(state, eps, dev(imm) if metric == "dense" else imm, L)
         state = info.state._replace(momentum=None)
         for c in range(C):
             o = okern[c](ostate[c], eps, imm, L)
             ostate[c] = o.state._replace(momentum=None)
             np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-12)
             np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL)
+            np.testing.assert_allclose(info.state.potential_energy_grad[c].cpu().numpy(), o.state.potential_energy_grad,
+                                       rtol=RTOL, atol=1e-12)
             np.testing.assert_allclose(info.acceptance_probability[c].item(), o.acceptance_probability, rtol=1e-8)
             assert bool(info.is_diverging[c]) == bool(o.is_diverging)
+
+
+@pytest.mark.parametrize("D,metric", [(1500, "diag"), (200, "dense")])
+def test_custom_target_wide_and_block_hmc_sample_equals_lockstep(eng, D, metric):
+    """sample(T) of a user-defined target on k_hmc_wide / k_hmc_block_reg against the lock-step engine with the same user
+    function: same accept decisions and generator states, positions to rounding (the cross-wavefront sums of the
+    workgroup-per-chain kernel are ordered differently) / bit for bit (block kernels)"""
+    from aehmc_amd import RandomStream, hmc, targets
+    r = np.random.default_rng(D + 1)
+    C = 5
+    nu, s = 4.0 + r.random(D), 0.7 + r.random(D)
+    q0 = r.normal(size=(C, D))
+    if metric == "diag":
+        imm = 0.5 + r.random(D)
+    else:
+        A = r.normal(size=(D, D))
+        imm = dev(A @ A.T / D + np.eye(D))
+    tgt = targets.Custom(STUDENT_T, params=[dev(nu), dev(s)])
+    outs = []
+    for fast in (1, 0):
+        eng.set_option("fused_hmc", fast)
+        kern = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        res = kern.sample(hmc.new_state(dev(q0), tgt), 0.15, imm, 6, 5)
+        outs.append((res[0], res[2], kern._hmc["holder"]["rng"].cpu().numpy().copy()))
+    (s1, a1, g1), (s0, a0, g0) = outs
+    assert np.array_equal(g1, g0)
+    if metric == "dense":
+        assert torch.equal(s1, s0) and torch.equal(a1, a0)
+    else:
+        np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=1e-9)
 
 
 def test_custom_target_fused_paths_equal_lockstep_bitwise(eng):
@@ -209,18 +254,19 @@ def test_custom_target_compile_error_is_reported(eng):
 def test_custom_target_fp_contract_hmc(eng):
     """the fast-arithmetic mode of the fused HMC kernel with a user-defined target: within 1e-6 of the default mode"""
     from aehmc_amd import RandomStream, hmc, targets
-    r = np.random.default_rng(3)
-    D, C = 64, 5
-    nu, s = 4.0 + r.random(D), 0.7 + r.random(D)
-    q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
-    tgt = targets.Custom(STUDENT_T, params=[nu, s])
-    outs = []
-    for fc in (0, 1):
-        eng.set_option("fp_contract", fc)
-        kern = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
-        outs.append(kern.sample(hmc.new_state(dev(q0), tgt), 0.1, imm, 20, 3)[0])
-    assert not torch.equal(outs[0], outs[1])
-    np.testing.assert_allclose(outs[1].cpu().numpy(), outs[0].cpu().numpy(), rtol=1e-6, atol=1e-9)
+    for D in (64, 1500):  # k_hmc_fused, k_hmc_wide (round 5)
+        r = np.random.default_rng(3)
+        C = 5
+        nu, s = 4.0 + r.random(D), 0.7 + r.random(D)
+        q0, imm = r.normal(size=(C, D)), 0.5 + r.random(D)
+        tgt = targets.Custom(STUDENT_T, params=[nu, s])
+        outs = []
+        for fc in (0, 1):
+            eng.set_option("fp_contract", fc)
+            kern = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+            outs.append(kern.sample(hmc.new_state(dev(q0), tgt), 0.1 if D == 64 else 0.05, imm, 20, 3)[0])
+        assert not torch.equal(outs[0], outs[1])
+        np.testing.assert_allclose(outs[1].cpu().numpy(), outs[0].cpu().numpy(), rtol=1e-6, atol=1e-9)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
