@@ -147,58 +147,9 @@ __device__ __forceinline__ double np_logaddexp(double x, double y) {  // numpy n
   return tmp;
 }
 
-// The per-leapfrog scalars of dynamic_integration (proposals.py:96-99, 141-144): the acceptance
-// probability expit(w_new - w_sub) and the two running logaddexp's.  All inputs are wave-uniform
-// and the three results are independent given the new weight, so they are evaluated in three
-// LANES of the wave at once -- one vector exp and one vector log1p instead of three and two
-// scalar ones (the 64-wide redundant evaluation of the same scalar costs exactly as much as a
-// lane-varying one).  Each lane runs the very instruction sequence of np_logaddexp / the scalar
-// expression, so the results are the same bits.  Valid when one wavefront (or more) owns the chain.
-struct StepScalars {
-  double pa, sub_w, sub_slpa;
-};
-__device__ __forceinline__ StepScalars nuts_step_scalars(double sub_w, double np_w, double sub_slpa,
-                                                         double np_slpa, int lane) {
-  const double x = lane == 1 ? sub_w : sub_slpa, y = lane == 1 ? np_w : np_slpa;  // lanes 1, 2: logaddexp(x, y)
-  const double tmp = x - y;
-  const double earg = lane == 0 ? -(np_w - sub_w) : (tmp > 0 ? -tmp : tmp);
-  const double e = exp(earg);
-  const double l = log1p(e);
-  double la = (x == y) ? x + 0.693147180559945309417232121458176568 : (tmp > 0 ? x + l : (tmp <= 0 ? y + l : tmp));
-  double pa = 1.0 / (1.0 + e);
-  if (isnan(pa)) pa = 0.0;
-  const double r = lane == 0 ? pa : la;
-  StepScalars o;
-  o.pa = read_lane_f64(r, 0);
-  o.sub_w = read_lane_f64(r, 1);
-  o.sub_slpa = read_lane_f64(r, 2);
-  return o;
-}
-
-// The scalars at the end of a sub-trajectory (trajectory.py:537-608, proposals.py:105-174): the
-// acceptance statistic exp(slpa_sub), the biased-sampling ratio exp(w_sub - w_prop) and the two
-// logaddexp's that merge the sub-trajectory into the proposal, in four lanes at once.  `swap`
-// (a diverged or U-turned sub-trajectory) only changes the argument order of the slpa merge.
-struct ExpansionScalars {
-  double e_slpa, e_ratio, la_w, la_slpa;
-};
-__device__ __forceinline__ ExpansionScalars nuts_expansion_scalars(double sub_w, double prop_w, double sub_slpa,
-                                                                   double prop_slpa, bool swap, int lane) {
-  const double x = lane == 2 ? prop_w : (swap ? sub_slpa : prop_slpa);   // lanes 2, 3: logaddexp(x, y)
-  const double y = lane == 2 ? sub_w : (swap ? prop_slpa : sub_slpa);
-  const double tmp = x - y;
-  const double earg = lane == 0 ? sub_slpa : lane == 1 ? sub_w - prop_w : (tmp > 0 ? -tmp : tmp);
-  const double e = exp(earg);
-  const double l = log1p(e);
-  const double la = (x == y) ? x + 0.693147180559945309417232121458176568 : (tmp > 0 ? x + l : (tmp <= 0 ? y + l : tmp));
-  const double r = lane < 2 ? e : la;
-  ExpansionScalars o;
-  o.e_slpa = read_lane_f64(r, 0);
-  o.e_ratio = read_lane_f64(r, 1);
-  o.la_w = read_lane_f64(r, 2);
-  o.la_slpa = read_lane_f64(r, 3);
-  return o;
-}
+}  // namespace aehmc
+#include "nuts_tree.cuh"  // the scalar state machine of a NUTS transition, shared by all kernel families
+namespace aehmc {
 
 // coordinate-wise targets: contribution to U and dU/dq_i
 __device__ __forceinline__ void target_elem(const EngineArgs &a, long long i, double q,
@@ -483,26 +434,10 @@ __device__ inline void nuts_finalize_expansion(const EngineArgs &a, long long c,
   const bool turning = (d_l <= 0) | (d_r <= 0);
   put2(ct.U_end, dir, ct.U_cur);
 
-  ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;  // trajectory.py:551-553
-  double pb = exp(ct.sub_w - ct.prop_w);               // proposals.py:130 (always drawn)
-  if (pb > 1.0) pb = 1.0;
-  if (pb < 0.0) pb = 0.0;
-  int acc_b = rng_bernoulli(rng.g[3], pb);
-  if (is_div || has_term) {
-    ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);  // trajectory.py:560-564
-  } else {
-    ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);           // proposals.py:141-144
-    ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
-    if (acc_b) {
-      ct.prop_slot ^= 1;
-      ct.prop_E = ct.sub_E;
-    }
-  }
-  ct.ndoubl = ct.j + 1;
-  ct.out_div = is_div;
-  ct.out_turn = turning;
-  const bool end_transition = is_div || turning || has_term || (ct.j + 1 == a.max_exp);
-  if (end_transition) {
+  // trajectory.py:551-564, proposals.py:105-174 (nuts_tree.cuh)
+  if (tree_merge_expansion<true>(ct, is_div, has_term, lane, [&](double pr) { return rng_bernoulli(rng.g[3], pr); }))
+    ct.prop_slot ^= 1;
+  if (tree_expansion_outcome(ct, is_div, has_term, turning, a.max_exp)) {
     nuts_write_outputs(a, c, lane, ct);
     ct.done = 1;  // caller keeps the chain alive while a phantom scan is pending
   } else {
@@ -525,15 +460,8 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
   const size_t row = (size_t)c * a.D;
   const int step = ct.step;
   if (!ct.phantom) ct.nleap += 1;
-  int tmin, tmax;
-  if (step == 0) {  // termination.py:109-113: indices inherited from the previous sub-trajectory
-    tmin = ct.tmin;
-    tmax = ct.tmax;
-  } else {          // termination.py:192-235 in closed form
-    int n1 = __ffs(~step) - 1;
-    tmax = __popc(step >> 1);
-    tmin = tmax - n1 + 1;
-  }
+  const TreeIdx ti = tree_step_indices(step, ct.tmin, ct.tmax);  // termination.py:109-113, 192-235 in closed form
+  const int tmin = ti.tmin, tmax = ti.tmax;
   const bool even = (step & 1) == 0;
   double *ckp = a.ckp + ((size_t)tmax * a.C + c) * a.D;
   double *cks = a.cks + ((size_t)tmax * a.C + c) * a.D;
@@ -638,34 +566,15 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
   kd = wave_sum(kd);
   ct.tmin = tmin;
   ct.tmax = tmax;
-  // proposals.py:19-62
-  const double E = ct.U_cur + 0.5 * kd;
-  double delta = ct.H0 - E;
-  if (isnan(delta)) delta = -INFINITY;
-  const bool div = fabs(delta) > a.thr;
-  const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
+  // proposals.py:19-62, then progressive_uniform_sampling proposals.py:72-102 (+ :141-144) -- nuts_tree.cuh
+  const TreePoint np = tree_new_point(ct.H0, ct.U_cur, kd, a.thr);
+  const bool div = np.div;
   bool term = false;
-  if (step == 0) {
-    ct.sub_E = E;
-    ct.sub_w = np_w;
-    ct.sub_slpa = np_slpa;
-    ct.length = 1;
-    copy_cur_to_slot<MET_DENSE>(a, row, lane, ct.prop_slot ^ 1);
+  if (tree_sample_step<true>(ct, step, np, lane, [&](double pr) { return rng_bernoulli(rng.g[2], pr); })) {
+    copy_cur_to_slot<MET_DENSE>(a, row, lane, ct.prop_slot ^ 1);  // sub-trajectory proposal <- the new point
     put2(ct.U_slot, ct.prop_slot ^ 1, ct.U_cur);
-  } else {
-    // progressive_uniform_sampling proposals.py:72-102 (+ proposals.py:141-144), three lanes at once
-    const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
-    int acc = rng_bernoulli(rng.g[2], sc.pa);
-    ct.sub_w = sc.sub_w;
-    ct.sub_slpa = sc.sub_slpa;
-    if (acc) {
-      ct.sub_E = E;
-      if (!ct.phantom) {
-        copy_cur_to_slot<MET_DENSE>(a, row, lane, ct.prop_slot ^ 1);
-        put2(ct.U_slot, ct.prop_slot ^ 1, ct.U_cur);
-      }
-    }
-    ct.length += 1;
+  }
+  if (step >= 1) {
     // is_iterative_turning termination.py:133-187
     if (tmax >= tmin) {
       int idx = tmax;
@@ -703,18 +612,16 @@ __device__ inline void nuts_book(const EngineArgs &a, long long c, int lane, Cha
       term = crit;
     }
   }
-  if (step == 0 && div && !ct.phantom) {
-    // trajectory.py:336: integrate() returns the first-step tuple, yet the scan still
-    // executes (and draws from site #3): finalize now, keep stepping as a phantom.
-    nuts_finalize_expansion<MET_DENSE>(a, c, lane, ct, true, false, rng);
-    ct.done = 0;
-    ct.phantom = 1;
-    ct.step = 1;
-  } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
-    if (ct.phantom) ct.done = 1;
-    else nuts_finalize_expansion<MET_DENSE>(a, c, lane, ct, div, term, rng);
-  } else {
-    ct.step = step + 1;
+  const TreeControl tc = tree_step_control(ct, step, div, term);
+  if (tc.finalize) {
+    nuts_finalize_expansion<MET_DENSE>(a, c, lane, ct, tc.fin_div, tc.fin_term, rng);
+    if (step == 0) {
+      // trajectory.py:336: integrate() returns the first-step tuple, yet the scan still
+      // executes (and draws from site #3): finalized now, the chain keeps stepping as a phantom.
+      ct.done = 0;
+      ct.phantom = 1;
+      ct.step = 1;
+    }
   }
 }
 

@@ -255,15 +255,8 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
     // ---- dynamic_integration body (trajectory.py:195-305) -----------------------------------
     const int step = ct.step;
     if (!ct.phantom) ct.nleap += 1;
-    int tmin, tmax;
-    if (step == 0) {
-      tmin = ct.tmin;  // termination.py:109-113: stale indices of the previous sub-trajectory
-      tmax = ct.tmax;
-    } else {
-      const int n1 = __ffs(~step) - 1;
-      tmax = __popc(step >> 1);
-      tmin = tmax - n1 + 1;
-    }
+    const TreeIdx ti = tree_step_indices(step, ct.tmin, ct.tmax);  // termination.py:109-113 (stale at step 0), 192-235
+    const int tmin = ti.tmin, tmax = ti.tmax;
     if (el) pb = (step == 0) ? p : pb + p;
     if ((step & 1) == 0) {  // termination.py:115-131
       const double pe = __shfl(p, e), pbe = __shfl(pb, e);
@@ -274,29 +267,12 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
     }
     ct.tmin = tmin;
     ct.tmax = tmax;
-    const double E = ct.U_cur + 0.5 * kd;  // proposals.py:19-62
-    double delta = ct.H0 - E;
-    if (isnan(delta)) delta = -INFINITY;
-    const bool div = fabs(delta) > a.thr;
-    const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
-    bool term = false, take = false;
-    if (step == 0) {
-      ct.sub_E = E;
-      ct.sub_w = np_w;
-      ct.sub_slpa = np_slpa;
-      ct.length = 1;
-      take = true;
-    } else {
-      // progressive_uniform_sampling proposals.py:72-102 (+ :141-144), three lanes at once
-      const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
-      const int acc = rng_bernoulli(rng.g[2], sc.pa);
-      ct.sub_w = sc.sub_w;
-      ct.sub_slpa = sc.sub_slpa;
-      if (acc) {
-        ct.sub_E = E;
-        take = !ct.phantom;
-      }
-      ct.length += 1;
+    // proposals.py:19-62, progressive_uniform_sampling proposals.py:72-102 (+ :141-144) -- nuts_tree.cuh
+    const TreePoint np = tree_new_point(ct.H0, ct.U_cur, kd, a.thr);
+    const bool div = np.div;
+    bool term = false;
+    const bool take = tree_sample_step<true>(ct, step, np, lane, [&](double pr) { return rng_bernoulli(rng.g[2], pr); });
+    if (step >= 1) {
       if (tmax >= tmin) {  // termination.py:133-187
         int idx = tmax;
         bool crit = false;
@@ -336,21 +312,9 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
     }
 
     // ---- sub-trajectory / expansion control (trajectory.py:336, 537-608) --------------------
-    bool finalize = false, fin_div = false, fin_term = false;
-    if (step == 0 && div && !ct.phantom) {
-      finalize = true;
-      fin_div = true;
-    } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
-      if (ct.phantom) ct.done = 1;
-      else {
-        finalize = true;
-        fin_div = div;
-        fin_term = term;
-      }
-    } else {
-      ct.step = step + 1;
-    }
-    if (finalize) {
+    const TreeControl tc = tree_step_control(ct, step, div, term);
+    const bool fin_div = tc.fin_div, fin_term = tc.fin_term;
+    if (tc.finalize) {
       const int dir = ct.dir, oth = 1 - dir;
       double dl = 0.0, dr = 0.0;
       {
@@ -378,25 +342,9 @@ __global__ __launch_bounds__(LR_BLOCK) void k_nuts_linreg(EngineArgs a, NutsSamp
       const double d_l = sum2(dl), d_r = sum2(dr);
       const bool turning = (d_l <= 0) | (d_r <= 0);
       put2(ct.U_end, dir, ct.U_cur);
-      const ExpansionScalars xs =
-          nuts_expansion_scalars(ct.sub_w, ct.prop_w, ct.sub_slpa, ct.prop_slpa, fin_div || fin_term, lane);
-      ct.acc_prob = xs.e_slpa / (double)ct.length;
-      double pbias = xs.e_ratio;
-      if (pbias > 1.0) pbias = 1.0;
-      if (pbias < 0.0) pbias = 0.0;
-      const int acc_b = rng_bernoulli(rng.g[3], pbias);
-      ct.prop_slpa = xs.la_slpa;
-      if (!(fin_div || fin_term)) {
-        ct.prop_w = xs.la_w;
-        if (acc_b) {
-          ct.prop_slot ^= 1;
-          ct.prop_E = ct.sub_E;
-        }
-      }
-      ct.ndoubl = ct.j + 1;
-      ct.out_div = fin_div;
-      ct.out_turn = turning;
-      const bool end_transition = fin_div || turning || fin_term || (ct.j + 1 == a.max_exp);
+      if (tree_merge_expansion<true>(ct, fin_div, fin_term, lane, [&](double pr) { return rng_bernoulli(rng.g[3], pr); }))
+        ct.prop_slot ^= 1;
+      const bool end_transition = tree_expansion_outcome(ct, fin_div, fin_term, turning, a.max_exp);
       if (end_transition) {
         if (step == 0 && fin_div) {  // trajectory.py:336: the scan still runs (phantom)
           ct.phantom = 1;

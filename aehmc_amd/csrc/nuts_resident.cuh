@@ -316,15 +316,8 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK)
     // ---- dynamic_integration body (trajectory.py:195-305) ------------------------------
     const int step = ct.step;
     if (!ct.phantom) ct.nleap += 1;
-    int tmin, tmax;
-    if (step == 0) {
-      tmin = ct.tmin;  // termination.py:109-113: stale indices of the previous sub-trajectory
-      tmax = ct.tmax;
-    } else {
-      int n1 = __ffs(~step) - 1;
-      tmax = __popc(step >> 1);
-      tmin = tmax - n1 + 1;
-    }
+    const TreeIdx ti = tree_step_indices(step, ct.tmin, ct.tmax);  // termination.py:109-113 (stale at step 0), 192-235
+    const int tmin = ti.tmin, tmax = ti.tmax;
     const bool even = (step & 1) == 0;
     {
       double *ckp = CKL ? res_lds + ((size_t)(wave * a.max_exp + tmax) * 2) * 64 : a.ckp + ((size_t)tmax * a.C + c) * a.D;
@@ -344,37 +337,13 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK)
     }
     ct.tmin = tmin;
     ct.tmax = tmax;
-    const double E = ct.U_cur + 0.5 * kd;  // proposals.py:19-62
-    double delta = ct.H0 - E;
-    if (isnan(delta)) delta = -INFINITY;
-    const bool div = fabs(delta) > a.thr;
-    const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
-    bool term = false, take = false;
-    if (step == 0) {
-      ct.sub_E = E;
-      ct.sub_w = np_w;
-      ct.sub_slpa = np_slpa;
-      ct.length = 1;
-      take = true;
-    } else {
-      int acc;
-      if (TM::WAVE) {  // the wave owns one chain: three lanes evaluate the three transcendental chains at once
-        const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);
-        acc = rng_bernoulli(rng.g[2], sc.pa);
-        ct.sub_w = sc.sub_w;
-        ct.sub_slpa = sc.sub_slpa;
-      } else {
-        double pa = 1.0 / (1.0 + exp(-(np_w - ct.sub_w)));  // proposals.py:96-99
-        if (isnan(pa)) pa = 0.0;
-        acc = rng_bernoulli(rng.g[2], pa);
-        ct.sub_w = np_logaddexp(ct.sub_w, np_w);
-        ct.sub_slpa = np_logaddexp(ct.sub_slpa, np_slpa);
-      }
-      if (acc) {
-        ct.sub_E = E;
-        take = !ct.phantom;
-      }
-      ct.length += 1;
+    // proposals.py:19-62, 72-102, 141-144 (nuts_tree.cuh; a wavefront that owns one chain evaluates the three
+    // transcendental chains of a step in three lanes at once, sub-wavefront teams in scalar form)
+    const TreePoint np = tree_new_point(ct.H0, ct.U_cur, kd, a.thr);
+    const bool div = np.div;
+    bool term = false;
+    const bool take = tree_sample_step<TM::WAVE>(ct, step, np, lane, [&](double pr) { return rng_bernoulli(rng.g[2], pr); });
+    if (step >= 1) {
       if (tmax >= tmin) {  // termination.py:133-187
         int idx = tmax;
         bool crit = false;
@@ -432,21 +401,9 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK)
     }
 
     // ---- sub-trajectory / expansion control (trajectory.py:336, 537-608) ----------------
-    bool finalize = false, fin_div = false, fin_term = false;
-    if (step == 0 && div && !ct.phantom) {
-      finalize = true;
-      fin_div = true;
-    } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
-      if (ct.phantom) ct.done = 1;
-      else {
-        finalize = true;
-        fin_div = div;
-        fin_term = term;
-      }
-    } else {
-      ct.step = step + 1;
-    }
-    if (finalize) {
+    const TreeControl tc = tree_step_control(ct, step, div, term);
+    const bool fin_div = tc.fin_div, fin_term = tc.fin_term;
+    if (tc.finalize) {
       const int dir = ct.dir, oth = 1 - dir;
       double d_l = 0.0, d_r = 0.0;
 #pragma unroll
@@ -484,25 +441,9 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK)
       team_sum2<T>(d_l, d_r, single);
       const bool turning = (d_l <= 0) | (d_r <= 0);
       put2(ct.U_end, dir, ct.U_cur);
-      ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;
-      double pbias = exp(ct.sub_w - ct.prop_w);
-      if (pbias > 1.0) pbias = 1.0;
-      if (pbias < 0.0) pbias = 0.0;
-      int acc_b = rng_bernoulli(rng.g[3], pbias);
-      if (fin_div || fin_term) {
-        ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);
-      } else {
-        ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);
-        ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
-        if (acc_b) {
-          ct.prop_slot ^= 1;
-          ct.prop_E = ct.sub_E;
-        }
-      }
-      ct.ndoubl = ct.j + 1;
-      ct.out_div = fin_div;
-      ct.out_turn = turning;
-      const bool end_transition = fin_div || turning || fin_term || (ct.j + 1 == a.max_exp);
+      if (tree_merge_expansion<TM::WAVE>(ct, fin_div, fin_term, lane, [&](double pr) { return rng_bernoulli(rng.g[3], pr); }))
+        ct.prop_slot ^= 1;
+      const bool end_transition = tree_expansion_outcome(ct, fin_div, fin_term, turning, a.max_exp);
       if (end_transition) {
         const int s = ct.prop_slot;  // outputs (the phantom scan below cannot change them)
 #pragma unroll

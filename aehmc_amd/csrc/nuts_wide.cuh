@@ -233,15 +233,8 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     const double b = 0.5 * step_size, aa = 1 * step_size;
     const int step = ct.step;
     if (!ct.phantom) ct.nleap += 1;
-    int tmin, tmax;
-    if (step == 0) {
-      tmin = ct.tmin;  // termination.py:109-113: stale indices of the previous sub-trajectory
-      tmax = ct.tmax;
-    } else {
-      const int n1 = __ffs(~step) - 1;
-      tmax = __popc(step >> 1);
-      tmin = tmax - n1 + 1;
-    }
+    const TreeIdx ti = tree_step_indices(step, ct.tmin, ct.tmax);  // termination.py:109-113 (stale at step 0), 192-235
+    const int tmin = ti.tmin, tmax = ti.tmax;
     const bool even = (step & 1) == 0;
     const bool check = step >= 1 && tmax >= tmin;
     // level tmax of the check is the pair the previous step stored: p and the momentum sum as
@@ -370,24 +363,12 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
     ct.tmax = tmax;
 
     // ---- dynamic_integration body (trajectory.py:195-305), per-chain scalars ------------------
-    const double E = ct.U_cur + 0.5 * kd;  // proposals.py:19-62
-    double delta = ct.H0 - E;
-    if (isnan(delta)) delta = -INFINITY;
-    const bool div = fabs(delta) > a.thr;
-    const double np_w = delta, np_slpa = delta > 0 ? 0.0 : delta;
-    bool term = false, take = false;
-    if (step == 0) {
-      ct.sub_w = np_w;
-      ct.sub_slpa = np_slpa;
-      ct.length = 1;
-      take = true;
-    } else {
-      const StepScalars sc = nuts_step_scalars(ct.sub_w, np_w, ct.sub_slpa, np_slpa, lane);  // proposals.py:96-99, 141-144
-      const int acc = rng_bernoulli(rng.g[2], sc.pa);
-      ct.sub_w = sc.sub_w;
-      ct.sub_slpa = sc.sub_slpa;
-      if (acc) take = !ct.phantom;
-      ct.length += 1;
+    // proposals.py:19-62, 72-102, 141-144 (nuts_tree.cuh)
+    const TreePoint np = tree_new_point(ct.H0, ct.U_cur, kd, a.thr);
+    const bool div = np.div;
+    bool term = false;
+    const bool take = tree_sample_step<true>(ct, step, np, lane, [&](double pr) { return rng_bernoulli(rng.g[2], pr); });
+    if (step >= 1) {
       AEHMC_TICK(3);  // per-chain scalars
       if (check) {  // termination.py:133-187
         int idx = tmax;
@@ -448,21 +429,9 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
 
     AEHMC_TICK(5);  // proposal copy
     // ---- sub-trajectory / expansion control (trajectory.py:336, 537-608) ----------------------
-    bool finalize = false, fin_div = false, fin_term = false;
-    if (step == 0 && div && !ct.phantom) {
-      finalize = true;
-      fin_div = true;
-    } else if (step >= 1 && (div || term || step == (1 << ct.j))) {
-      if (ct.phantom) ct.done = 1;
-      else {
-        finalize = true;
-        fin_div = div;
-        fin_term = term;
-      }
-    } else {
-      ct.step = step + 1;
-    }
-    if (finalize) {
+    const TreeControl tc = tree_step_control(ct, step, div, term);
+    const bool fin_div = tc.fin_div, fin_term = tc.fin_term;
+    if (tc.finalize) {
       AEHMC_FRESH_TT();
       const int dir = ct.dir, oth = 1 - dir;
       const bool oth_init = oth ? end_init1 : end_init0;
@@ -496,22 +465,9 @@ __global__ __launch_bounds__(T) void k_nuts_wide(EngineArgs a) {
       sum4(d_l, d_r, e0, e1);
       const bool turning = (d_l <= 0) | (d_r <= 0);
       put2(ct.U_end, dir, ct.U_cur);
-      ct.acc_prob = exp(ct.sub_slpa) / (double)ct.length;
-      double pbias = exp(ct.sub_w - ct.prop_w);
-      if (pbias > 1.0) pbias = 1.0;
-      if (pbias < 0.0) pbias = 0.0;
-      const int acc_b = rng_bernoulli(rng.g[3], pbias);
-      if (fin_div || fin_term) {
-        ct.prop_slpa = np_logaddexp(ct.sub_slpa, ct.prop_slpa);
-      } else {
-        ct.prop_w = np_logaddexp(ct.prop_w, ct.sub_w);
-        ct.prop_slpa = np_logaddexp(ct.prop_slpa, ct.sub_slpa);
-        if (acc_b) prop_buf = sub_buf;
-      }
-      ct.ndoubl = ct.j + 1;
-      ct.out_div = fin_div;
-      ct.out_turn = turning;
-      const bool end_transition = fin_div || turning || fin_term || (ct.j + 1 == a.max_exp);
+      if (tree_merge_expansion<true>(ct, fin_div, fin_term, lane, [&](double pr) { return rng_bernoulli(rng.g[3], pr); }))
+        prop_buf = sub_buf;
+      const bool end_transition = tree_expansion_outcome(ct, fin_div, fin_term, turning, a.max_exp);
       if (end_transition) {
         // outputs (the phantom scan below cannot change them); a proposal that is still the initial
         // state leaves q, dU/dq and U as they are
