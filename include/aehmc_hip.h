@@ -130,8 +130,13 @@ int aehmc_set_target(aehmc_ctx *ctx, const aehmc_target *target);
  * function indexes).  The library compiles its kernel templates against it with hipRTC (libhiprtc, gfx950;
  * `include_dir` = the directory that holds the library's csrc/ headers) on first use and caches the code objects by
  * source: the lock-step engine (any metric, any D), the register-resident NUTS kernel (D <= 512, diagonal / scalar
- * metric) and the fused HMC kernel (D <= 1024, diagonal / scalar metric).  Compilation errors come back through
- * aehmc_last_error with the compiler's log. */
+ * metric) and the fused HMC kernel (D <= 1024, diagonal / scalar metric) and, since round 5, the workgroup-per-chain
+ * NUTS / HMC kernels (diagonal / scalar metric, D <= 10176 / 10240) and the block-resident NUTS / HMC kernels (shared
+ * dense metric, 64 < D <= 512).  The density alone is enough: with `#include "dual.cuh"` the source may define
+ *     template <class T> __device__ T aehmc_logp
+ *         (T q, long long i, const double *const *prm)
+ * and a three-line aehmc_custom_elem that instantiates it with aehmc::Dual (what aehmc_amd/targets.py appends).
+ * Compilation errors come back through aehmc_last_error with the compiler's log, and the previous binding stays. */
 int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
                             int32_t n_params, const char *include_dir);
 

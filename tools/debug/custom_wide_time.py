@@ -23,12 +23,20 @@ template <class T> __device__ T aehmc_logp(T q, long long i, const double *const
   return hn * log1p(z * z * inv_nu);
 }
 """
+# a density of the built-in Gaussian's own cost (one division by sigma in value and derivative each): what the custom PATH costs
+SRC_GAUSS = """
+template <class T> __device__ T aehmc_logp(T q, long long i, const double *const *prm) {
+  const T z = q / prm[0][i];
+  return -0.5 * (z * z) - prm[1][i];
+}
+"""
 r = np.random.default_rng(0)
 nu, s = 3.0 + 5 * r.random(D), 0.5 + r.random(D)
 q0 = torch.as_tensor(r.standard_normal((C, D)), device="cuda")
 imm = torch.ones(D, dtype=torch.float64, device="cuda")
 for name, tgt in (("custom Student-t (density only)", targets.Custom(SRC, params=[nu, s])),
                   ("custom Student-t, reciprocals as parameters", targets.Custom(SRC_MUL, params=[-0.5 * (nu + 1.0), 1.0 / s, 1.0 / nu])),
+                  ("custom Gaussian (density only)", targets.Custom(SRC_GAUSS, params=[s, np.log(s) + 0.9189385332046727])),
                   ("built-in diagonal Gaussian", targets.DiagGaussian(np.zeros(D), s))):
     kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt)
     state = nuts.new_state(q0, tgt)
