@@ -352,6 +352,46 @@ def pc_dense_secondary(eng, device, D=200, C=4096, T=10):
         return [{"config": f"pc-dense-nuts-d{D}", "error": repr(e)[:300]}]
 
 
+def custom_secondary(eng, device, D=5000, C=4096, T=4):
+    """A user-defined target given by its log-DENSITY only (Student-t; differentiated by the engine, csrc/dual.cuh) on the
+    workgroup-per-chain NUTS kernel compiled at run time, beside the built-in diagonal Gaussian at the same shape
+    (VERDICT r4 item 7).  The pass of that kernel is bound by VALU issue, so the ratio is the density's arithmetic."""
+    from aehmc_amd import RandomStream, nuts, targets
+    src = """
+template <class T> __device__ T aehmc_logp(T q, long long i, const double *const *prm) {
+  const double hn = prm[0][i], inv_s = prm[1][i], inv_nu = prm[2][i];
+  const T z = q * inv_s;
+  return hn * log1p(z * z * inv_nu);
+}
+"""
+    try:
+        r = np.random.default_rng(0)
+        nu, sg = 3.0 + 5 * r.random(D), 0.5 + r.random(D)
+        q0 = torch.as_tensor(r.standard_normal((C, D)), device=device)
+        imm = torch.ones(D, dtype=torch.float64, device=device)
+        eps, out = 0.4 * D ** -0.25, {}
+        for name, tgt in (("custom", targets.Custom(src, params=[-0.5 * (nu + 1.0), 1.0 / sg, 1.0 / nu])),
+                          ("builtin", targets.DiagGaussian(np.zeros(D), sg))):
+            kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+            state = nuts.new_state(q0, tgt)
+            for _ in range(2):
+                state = kernel(state, eps, imm)[0].state._replace(momentum=None)
+            torch.cuda.synchronize(device)
+            t0, nl = time.perf_counter(), 0
+            for _ in range(T):
+                info = kernel(state, eps, imm)[0]
+                state = info.state._replace(momentum=None)
+                nl += int(info.n_leapfrog.sum().item())
+            torch.cuda.synchronize(device)
+            out[name] = nl / (time.perf_counter() - t0)
+        return [{"config": f"custom-student-t-nuts-d{D}",
+                 "workload": f"{D}-dim Student-t defined by its log-density (engine-differentiated), diagonal mass, NUTS depth 10, {C} chains",
+                 "value": out["custom"], "unit": "leapfrog-steps/s", "builtin_diag_gaussian": out["builtin"],
+                 "builtin_over_custom": out["builtin"] / out["custom"], "kernel": "k_nuts_wide<512,16,LDS,custom> (hipRTC)"}]
+    except Exception as e:  # a failing side measurement must not cost the main line
+        return [{"config": f"custom-student-t-nuts-d{D}", "error": repr(e)[:300]}]
+
+
 def launch_ranks(n, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one process per
     GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches
@@ -630,6 +670,7 @@ def main():
         secondary = bench_secondary(eng, device, max(args.steps, 3), 2)
         secondary += dense_mid_secondary(eng, device)
         secondary += pc_dense_secondary(eng, device)
+        secondary += custom_secondary(eng, device)
         torch.cuda.empty_cache()
         secondary += other_configs()
 
