@@ -59,9 +59,14 @@ def _content_key(arr: np.ndarray):
 
 
 def _param_key(v):
-    """Cache key of one target / metric parameter: torch tensors by identity + version counter, anything
-    else (numpy arrays, lists, scalars) by content."""
+    """Cache key of one target / metric parameter: DEVICE tensors by identity + version counter, anything
+    else (CPU tensors, numpy arrays, lists, scalars) by content.  (A CPU tensor can be edited through a numpy view of
+    its storage without its version counter moving -- `t.numpy()[0] = 1.0` -- so identity + version is not a safe key
+    for it; it is uploaded anyway, hashing it is the cheaper part.)"""
     if isinstance(v, torch.Tensor):
+        if v.device.type == "cpu":
+            arr = v.detach().to(torch.float64).numpy()
+            return ("c", arr.shape, _content_key(arr))
         return ("t", id(v), v._version, tuple(v.shape))
     arr = np.asarray(v, dtype=np.float64)
     return ("n", arr.shape, _content_key(arr))

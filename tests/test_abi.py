@@ -170,6 +170,20 @@ def test_large_host_arrays_are_keyed_by_full_content():
             engine.SAMPLED_HASH_ABOVE = None
 
 
+def test_cpu_tensors_are_keyed_by_content():
+    """A CPU torch tensor edited through a numpy view of its storage keeps its version counter:
+    identity + version would serve the stale upload.  CPU tensors are keyed by content like numpy arrays."""
+    import torch
+    from aehmc_amd import engine
+    t = torch.zeros(64, dtype=torch.float64)
+    k0, v0 = engine._param_key(t), t._version
+    t.numpy()[3] = 2.5
+    assert t._version == v0            # the edit is invisible to the version counter ...
+    assert engine._param_key(t) != k0  # ... and visible to the key
+    assert engine._param_key(t) == engine._param_key(t.clone())  # equal content, equal key
+    assert engine._param_key(torch.zeros(4, dtype=torch.float32))[0] == "c"
+
+
 def test_random_stream_from_state_for_a_later_kernel_and_dtype_checks():
     """Resuming a kernel that was NOT the first one built from its stream: `n_spawned` puts the spawn sequence where the
     unbroken session had it, so kernels built after the resumed one get the call sites they would have got; states of
