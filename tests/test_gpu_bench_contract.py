@@ -217,3 +217,28 @@ def test_integration_md_binding_snippet_runs():
                    "print('SNIPPET-OK', float(acc.mean()))\n")
     out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0 and "SNIPPET-OK" in out.stdout, out.stderr[-3000:]
+
+
+def test_integration_md_custom_density_snippet_runs(tmp_path):
+    """The second snippet of INTEGRATION.md -- a user-defined log-density bound through the C-ABI, differentiated by the
+    engine -- executed behind the first one, then one NUTS transition on the new target."""
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, re.S)
+    assert len(blocks) >= 2 and "aehmc_set_custom_target" in blocks[1]
+    code = blocks[0].replace('"libaehmc_hip.so"', repr(os.path.join(ROOT, "aehmc_amd", "libaehmc_hip.so")))
+    code += blocks[1].replace("/path/to/aehmc_amd/csrc", os.path.join(ROOT, "aehmc_amd", "csrc")).replace("/var/cache/aehmc_rtc", str(tmp_path))
+    code += ("\nassert lib.aehmc_new_state(ctx, ct.c_int64(C), ct.c_void_p(q.data_ptr()), ct.c_void_p(U.data_ptr()), ct.c_void_p(g.data_ptr()), stream) == 0\n"
+             "torch.cuda.synchronize()\n"
+             "ref = (0.5 * 6.0 * torch.log1p(q * q / 5.0)).sum(1)\n"
+             "assert torch.allclose(U, ref, rtol=1e-12), (U[:3], ref[:3])\n"
+             "assert torch.allclose(g, 6.0 * q / (5.0 + q * q), rtol=1e-12, atol=1e-14)      # the engine's derivative of the density\n"
+             "rc = lib.aehmc_nuts_step(ctx, ct.c_int64(C), ct.c_void_p(rng.data_ptr()), ct.c_double(0.1), ct.c_int64(10), ct.c_double(1000.0),\n"
+             "                         ct.c_void_p(q.data_ptr()), ct.c_void_p(U.data_ptr()), ct.c_void_p(g.data_ptr()), ct.byref(diag), stream)\n"
+             "assert rc == 0, lib.aehmc_last_error(ctx)\n"
+             "torch.cuda.synchronize()\n"
+             "assert torch.isfinite(q).all() and (out['n_leapfrog'] > 0).all()\n"
+             "import os\nassert any(f.endswith('.aehmcco') for f in os.listdir(%r))\n"
+             "print('SNIPPET2-OK')\n" % str(tmp_path))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "SNIPPET2-OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
