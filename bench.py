@@ -81,11 +81,22 @@ def emit(obj, verbose=False):
     obj = compact(obj, verbose)
     line = json.dumps(obj, separators=(",", ":"))
     if not verbose and len(line) > LINE_LIMIT and obj.get("secondary"):
-        for drop in ("workload", "traffic_source", "counters", "hbm", "valu", "fp64_flops", "launches", "avg_launch_ms"):
+        keep = ("mfma_busy_fraction", "wait_any_fraction_of_wave_cycles", "wait_any_frac_of_wave_cycles",
+                "valu_busy_fraction_of_kernel_time_at_2.4GHz", "l2_hit_rate", "clock_GHz_grbm")
+        # `traffic_source` is always profiles/<round>/<config>_pmc_summary.json; long counter dicts shrink to the figures
+        # the roofline argument uses; only then the prose (`workload`: the `config` names say which) and the rest
+        for drop in ("traffic_source", "<long counters>", "streaming_bytes_per_transition", "algorithmic_l2_bytes_per_launch",
+                     "algorithmic_flops_per_launch", "whole_call_leapfrogs_per_s", "workload", "counters", "hbm", "valu", "fp64_flops", "launches", "avg_launch_ms"):
             for e in obj["secondary"]:
+                roof = e.get("roofline") if isinstance(e.get("roofline"), dict) else {}
+                if drop == "<long counters>":
+                    for holder in (e, roof):
+                        c = holder.get("counters")
+                        if isinstance(c, dict) and len(c) > len(keep):
+                            holder["counters"] = {k: v for k, v in c.items() if k in keep}
+                    continue
                 e.pop(drop, None)
-                if isinstance(e.get("roofline"), dict):
-                    e["roofline"].pop(drop, None)
+                roof.pop(drop, None)
             line = json.dumps(obj, separators=(",", ":"))
             if len(line) <= LINE_LIMIT:
                 break
