@@ -315,6 +315,14 @@ __device__ inline void wave_normals(Pcg64 &rng, long long n, Store store, const 
       rng.state = shfl_u128(sk, 63);
       continue;
     }
+    if (want < 64 && (fail & ((1ULL << want) - 1)) == 0) {
+      // the request ends inside this round and none of the lanes it takes was rejected (round 5; 2/3 of the last rounds of
+      // a D = 100 draw): lane l delivers normal pos + l, the stream stands behind lane want - 1 -- what the general
+      // code below arrives at through its mask walk and shifted stores
+      if (lane < want) store(pos + lane, d.x);
+      rng.state = shfl_u128(sk, (int)want - 1);
+      return;
+    }
     // Rejections are resolved in lane order; `dropped` collects the lanes that deliver nothing
     // (consumed by a rejection's redraws, or cut off behind a restart), and every surviving
     // lane stores once at the end, shifted down by the dropped lanes below it.
