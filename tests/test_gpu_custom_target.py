@@ -69,9 +69,10 @@ def oracle_nuts(tgt, seeds, q0, eps, imm, max_exp, n):
 @pytest.mark.parametrize("D,metric,resident", [(10, "diag", 2), (10, "diag", 0), (70, "diag", 2), (300, "diag", 2),
                                                (40, "dense", 2), (90, "dense", 2), (200, "dense", 2), (300, "dense", 2),
                                                (600, "diag", 2), (600, "diag", 0),
-                                               (1500, "diag", 2), (5000, "diag", 2)])
+                                               (1500, "diag", 2), (5000, "diag", 2), (10176, "diag", 2)])
 def test_custom_target_nuts_matches_numpy(eng, D, metric, resident):
-    """register-resident kernel (D <= 512, diagonal / scalar metric), workgroup-per-chain kernel (512 < D <= 10176:
+    """register-resident kernel (D <= 512, diagonal / scalar metric), workgroup-per-chain kernel (512 < D <= 10176 -- the
+    largest chain whose q and dU/dq fit the CU's 160 KB of LDS, tested at exactly that size:
     k_nuts_wide, q and dU/dq in LDS above D = 4096; round 5), block-resident kernels (shared dense metric, 64 < D <= 512:
     k_nuts_block_reg / k_nuts_block_dense; round 5), lock-step engine (resident_nuts = 0, small dense problems): all
     compiled at run time against the user's function"""
@@ -110,7 +111,7 @@ def test_custom_target_nuts_matches_numpy(eng, D, metric, resident):
 
 
 @pytest.mark.parametrize("D,fused,metric", [(10, 1, "diag"), (10, 0, "diag"), (200, 1, "diag"), (1500, 1, "diag"),
-                                            (3000, 1, "diag"), (5000, 1, "diag"), (9000, 1, "diag"),
+                                            (3000, 1, "diag"), (5000, 1, "diag"), (9000, 1, "diag"), (10240, 1, "diag"),
                                             (100, 1, "dense"), (200, 1, "dense"), (300, 1, "dense"), (200, 0, "dense")])
 def test_custom_target_hmc_matches_numpy(eng, D, fused, metric):
     """fused register-resident HMC (D <= 1024), the workgroup-per-chain kernel (1024 < D <= 10240: k_hmc_wide at 256 /

@@ -1,0 +1,73 @@
+"""CPU-side guard for the run-time compiled programs (aehmc_set_custom_target / aehmc_set_custom_joint_target): the kernel
+templates of every family a user-defined target can run on are instantiated against a user density by the offline
+compiler (`hipcc -fsyntax-only`, device pass, a few seconds) -- so a header edit that breaks the AEHMC_T_CUSTOM /
+AEHMC_JOINT_TARGET code paths is caught without a GPU.  (hipRTC itself, the lowered names and the launches are covered by
+tests/test_gpu_custom_target.py and tests/test_gpu_autodiff.py.)"""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "aehmc_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+ELEMENTWISE = r'''
+#define AEHMC_CUSTOM_TARGET 1
+#include "dual.cuh"
+template <class T> __device__ T aehmc_logp(T q, long long i, const double *const *prm) {   // what targets.Custom receives
+  const double nu = prm[0][i];
+  return -0.5 * (nu + 1.0) * log1p(q * q / nu);
+}
+__device__ void aehmc_custom_elem(double q, long long i, const double *const *prm, double &u, double &g) {  // targets._ELEM_FROM_LOGP
+  const aehmc::Dual r = aehmc_logp(aehmc::Dual(q, 1.0), i, prm);
+  u = -r.v;
+  g = -r.d;
+}
+#include "engine.cuh"
+#include "nuts_resident.cuh"
+#include "nuts_wide.cuh"
+#include "hmc_fused.cuh"
+#include "nuts_block_reg.cuh"
+// (k_new_state_elem, k_step<...> etc. are not templates on the target: the syntax pass checks their bodies as they are)
+template __global__ void aehmc::k_nuts_wide<256, 4, false, 5>(aehmc::EngineArgs);
+template __global__ void aehmc::k_nuts_wide<512, 20, true, 5>(aehmc::EngineArgs);
+template __global__ void aehmc::k_hmc_wide<256, 8, 5, false>(aehmc::HmcFusedArgs, const double *, int);
+template __global__ void aehmc::k_hmc_wide<1024, 10, 5, true>(aehmc::HmcFusedArgs, const double *, int);
+template __global__ void aehmc::k_hmc_fused<2, 5, false>(aehmc::HmcFusedArgs);
+template __global__ void aehmc::k_hmc_fused<2, 5, true>(aehmc::HmcFusedArgs);
+template __global__ void aehmc::k_nuts_block_reg<2, false>(aehmc::EngineArgs, aehmc::NutsSampleArgs);
+template __global__ void aehmc::k_nuts_block_reg<4, false>(aehmc::EngineArgs, aehmc::NutsSampleArgs);
+template __global__ void aehmc::k_nuts_block_dense<false>(aehmc::EngineArgs, aehmc::NutsSampleArgs);
+template __global__ void aehmc::k_hmc_block_reg<2, false>(aehmc::EngineArgs, const double *, long long, long long, double *, double *, int *);
+template __global__ void aehmc::k_hmc_block_dense<false>(aehmc::EngineArgs, const double *, long long, long long, double *, double *, int *);
+'''
+
+JOINT = r'''
+#define AEHMC_JOINT_TARGET 1
+#include "dual.cuh"
+template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm) {     // what targets.CustomJoint receives
+  auto v = q[0];
+  auto lp = -v * v / 18.0;
+  for (int i = 1; i < q.size(); i++) lp += -0.5 * q[i] * q[i] * exp(-v) - 0.5 * v;
+  return lp;
+}
+#include "engine.cuh"
+#include "nuts_resident.cuh"
+// (k_new_state_joint is not a template: the syntax pass checks its body as it is)
+template __global__ void aehmc::k_nuts_resident<64, 1, true, 8, false>(aehmc::EngineArgs, aehmc::NutsSampleArgs);
+template __global__ void aehmc::k_nuts_resident<64, 1, false, 9, false>(aehmc::EngineArgs, aehmc::NutsSampleArgs);
+template __global__ void aehmc::k_hmc_fused_dense<false, false, false>(aehmc::EngineArgs, const double *, double *, long long, long long, double *, double *, int *);
+template __global__ void aehmc::k_hmc_fused_dense<true, false, true>(aehmc::EngineArgs, const double *, double *, long long, long long, double *, double *, int *);
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("name,source", [("elementwise", ELEMENTWISE), ("joint", JOINT)], ids=["elementwise", "joint"])
+def test_kernel_templates_instantiate_against_a_user_density(tmp_path, name, source):
+    path = tmp_path / f"{name}.hip"
+    path.write_text(source)
+    out = subprocess.run([HIPCC, "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I", CSRC, "--cuda-device-only",
+                          "-fsyntax-only", "-Wno-unused-value", str(path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-4000:]
