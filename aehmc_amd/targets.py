@@ -124,8 +124,9 @@ class Custom(Target):
       error, not a wrong posterior.
 
     The engine compiles its kernel templates against the source with hipRTC on first use (a few seconds; cached per
-    source): the lock-step engine for any metric and dimension, the register-resident NUTS kernel (D <= 512) and the
-    fused HMC kernel (D <= 1024) for diagonal / scalar metrics."""
+    source): the lock-step engine for any metric and dimension; for diagonal / scalar metrics the register-resident NUTS
+    kernel (D <= 512), the fused HMC kernel (D <= 1024) and the workgroup-per-chain NUTS / HMC kernels (D <= 10176 /
+    10240); for a shared dense metric the block-resident NUTS / HMC kernels (64 < D <= 512)."""
 
     kind = T_CUSTOM
 
