@@ -136,6 +136,25 @@ struct JointArg<Dual> {
   __device__ inline __attribute__((always_inline)) Dual operator[](int i) const { return Dual(joint_lane_read(ql, i), i == lane ? 1.0 : 0.0); }
   __device__ inline __attribute__((always_inline)) int size() const { return D; }
 };
+// The same view over a row of coordinates in memory (LDS) for joint densities of MORE than 64 coordinates (round 5;
+// engine.cuh: k_target_joint_rows): the wavefront evaluates the density ceil(D / 64) times, lane l seeding coordinate
+// `seed` = l + 64 k in pass k.  q[i] with a wave-uniform i is a broadcast read.
+template <class T>
+struct JointRow;
+template <>
+struct JointRow<double> {
+  const double *q;
+  int seed, D;
+  __device__ inline __attribute__((always_inline)) double operator[](int i) const { return q[i]; }
+  __device__ inline __attribute__((always_inline)) int size() const { return D; }
+};
+template <>
+struct JointRow<Dual> {
+  const double *q;
+  int seed, D;
+  __device__ inline __attribute__((always_inline)) Dual operator[](int i) const { return Dual(q[i], i == seed ? 1.0 : 0.0); }
+  __device__ inline __attribute__((always_inline)) int size() const { return D; }
+};
 #endif
 
 }  // namespace aehmc

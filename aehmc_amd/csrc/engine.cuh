@@ -747,6 +747,7 @@ AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_nuts_fused(EngineArgs a)
 // too), one rounding per product and per sum.  Literal dense mode (metrics.py:71: imm p_half and imm p' are formed,
 // 3 products per leapfrog).
 constexpr int FUSED_DENSE_MAX_D = 64;
+constexpr int JOINT_ROWS_MAX_D = 2048;  // joint (non-separable) user targets on the lock-step path: four wavefronts' rows in 64 KB of LDS (k_target_joint_rows)
 constexpr int FUSED_DENSE_BLOCK = 512;  // eight chains per workgroup share the matrices
 // y[i] = sum_k M[i][k] x[k] for i < D; MT = M transposed in LDS (MT[k * D + i] = M[i][k]); x, y rows in global memory,
 // element i read and written by lane i only
@@ -1123,6 +1124,42 @@ __global__ __launch_bounds__(256) void k_new_state_joint(EngineArgs a) {  // hmc
   const double U = target_joint(a, lane, D, on ? a.q[c * a.D + lane] : 0.0, g);
   if (on) a.g[c * a.D + lane] = g;
   if (lane == 0) a.U[c] = U;
+}
+// A joint target of any size on the lock-step path (round 5): U and dU/dq of every (live) chain from its position row,
+// between the stage kernels -- the place the dense-precision, regression and row-reduction targets are evaluated at
+// (engine.hip: launch_leapfrog's target_ext).  One wavefront per chain; the row waits in LDS and the density is evaluated
+// ceil(D / 64) times, lane l carrying the derivative with respect to coordinate l + 64 k in pass k (dual.cuh: JointRow):
+// O(D^2 / 64) density terms per gradient and wavefront, every lane ends each pass with the same value bits.
+// U -> ctl[c].U_cur (leapfrog; finished chains are skipped) or U[c] (new_state).
+__global__ __launch_bounds__(256) void k_target_joint_rows(EngineArgs a, const double *q, double *g, double *U, int to_ctl,
+                                                           const int *row_idx, const int *n_rows) {
+  extern __shared__ __attribute__((aligned(16))) double joint_rows[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+  long long c = w;
+  if (row_idx) {
+    if (w >= *n_rows) return;
+    c = row_idx[w];
+  } else if (w >= a.C) {
+    return;
+  }
+  if (to_ctl && a.ctl[c].done) return;
+  const int D = (int)a.D;
+  const size_t row = (size_t)c * a.D;
+  double *const qr = joint_rows + (size_t)wave * D;
+  for (int i = lane; i < D; i += 64) qr[i] = q[row + i];
+  __threadfence_block();  // (the row is read back through other lanes' addresses)
+  double Uv = 0.0;
+  for (int k = 0; k * 64 < D; k++) {
+    const JointRow<Dual> arg{qr, lane + 64 * k, D};
+    const Dual r = aehmc_logp(arg, a.cparams);
+    if (lane + 64 * k < D) g[row + lane + 64 * k] = -r.d;
+    Uv = -r.v;
+  }
+  if (lane == 0) {
+    if (to_ctl) a.ctl[c].U_cur = Uv;
+    else U[c] = Uv;
+  }
 }
 #endif
 AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_residual(EngineArgs a, const double *q, double *r) {

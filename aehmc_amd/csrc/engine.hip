@@ -495,13 +495,14 @@ extern "C" int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, i
   return 0;
 }
 
-static const std::vector<std::string> RTC_JBASE = {"aehmc::k_new_state_joint"};
+static const std::vector<std::string> RTC_JBASE = {"aehmc::k_new_state_joint", "aehmc::k_target_joint_rows"};
 extern "C" int aehmc_set_custom_joint_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
                                              int32_t n_params, const char *include_dir) {
   if (!ctx || !source || !include_dir) return -2;
   HIPCHK(hipSetDevice(ctx->device));
-  if (D <= 0 || D > FUSED_DENSE_MAX_D)
-    FAIL("joint target: D must be in [1, " + std::to_string(FUSED_DENSE_MAX_D) + "] (one coordinate per lane of the chain's wavefront)");
+  // (D <= 64: one coordinate per lane, the single-launch kernels; above: the lock-step path, the position row in LDS)
+  if (D <= 0 || D > JOINT_ROWS_MAX_D)
+    FAIL("joint target: D must be in [1, " + std::to_string(JOINT_ROWS_MAX_D) + "]");
   if (int rc = custom_bind(ctx, source, include_dir, params, n_params, "jbase", RTC_JBASE)) return rc;
   aehmc_target t{};
   t.kind = AEHMC_T_JOINT;
@@ -1084,6 +1085,13 @@ static int launch_glm(aehmc_ctx *ctx, const EngineArgs &a, const double *q, doub
     HIPCHK(hipGetLastError());                                                        \
   } while (0)
 
+// joint user-defined target on the lock-step path: U and dU/dq of the (live) chains from their position rows
+static int launch_joint_rows(aehmc_ctx *ctx, const EngineArgs &a, const double *q, double *g, double *U, int to_ctl,
+                             hipStream_t st, const int *ri, const int *nr) {
+  return rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[1], chain_grid(a.C), dim3(256), (size_t)4 * a.D * sizeof(double), st, a, q, g, U,
+                    to_ctl, ri, nr);
+}
+
 // kernels that evaluate a coordinate-wise target: the library's own instantiation, or -- user-defined target -- the
 // run-time compiled one of the same name
 #define LAUNCH_T(name, kern, C, st, a)                                                                  \
@@ -1103,14 +1111,16 @@ static int launch_leapfrog(aehmc_ctx *ctx, const EngineArgs &a, bool book, bool 
   const bool md = a.met_ndim == 2;
   const bool tdense = a.tkind == AEHMC_T_DENSE_MVN;
   const int64_t C = a.C, D = a.D;
-  const bool tlin = a.tkind == AEHMC_T_LINREG, tglm = a.tkind == AEHMC_T_GLM;
-  // targets evaluated between the stages: dense MVN (GEMM), linear regression (row sums), user-defined row reduction
+  const bool tlin = a.tkind == AEHMC_T_LINREG, tglm = a.tkind == AEHMC_T_GLM, tjoint = a.tkind == AEHMC_T_JOINT;
+  // targets evaluated between the stages: dense MVN (GEMM), linear regression (row sums), user-defined row reduction,
+  // user-defined joint density
   auto target_ext = [&]() -> int {
     if (tdense) return gemm(ctx, C, D, D, a.rbuf, D, ctx->tgt.prec, D, a.cur_g, D, st, ri, nr);
     if (tglm) return launch_glm(ctx, a, a.cur_q, a.cur_g, nullptr, 1, st, ri, nr);
+    if (tjoint) return launch_joint_rows(ctx, a, a.cur_q, a.cur_g, nullptr, 1, st, ri, nr);
     return launch_linreg(ctx, a, a.cur_q, a.cur_g, nullptr, 1, st);
   };
-  const bool text = tdense || tlin || tglm;
+  const bool text = tdense || tlin || tglm || tjoint;
   if (!md && !text) {
     if (book) LAUNCH_T("aehmc::k_step<true, true, true, false, true>", (k_step<true, true, true, false, true>), C, st, a);
     else LAUNCH_T("aehmc::k_step<true, true, true, false, false>", (k_step<true, true, true, false, false>), C, st, a);
@@ -1193,6 +1203,7 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
     a.C = C; a.D = ctx->tgt.D; a.tkind = ctx->tgt.kind;
     a.cparams = ctx->d_cparams;
     a.q = const_cast<double *>(q); a.U = U; a.g = g;
+    if (a.D > FUSED_DENSE_MAX_D) return launch_joint_rows(ctx, a, q, g, U, 0, st, nullptr, nullptr);
     return rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[0], chain_grid(C), dim3(256), 0, st, a);
   }
   if (int rc = fill_args(ctx, C, 1, a, false)) return rc;
@@ -1252,7 +1263,7 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
-  if (want_resident && tkind == AEHMC_T_JOINT) return NUTS_PATH_FUSED_DENSE;  // (run-time compiled, D <= 64)
+  if (want_resident && tkind == AEHMC_T_JOINT && D <= FUSED_DENSE_MAX_D) return NUTS_PATH_FUSED_DENSE;  // (run-time compiled)
   if (want_resident && nuts_resident_dense_supported(tkind, nd, D))
     return NUTS_PATH_FUSED_DENSE;  // (per-chain dense metrics included: each wavefront reads its own matrices)
   // mid-size dense problems (shared dense metric, 64 < D <= 512, linear dense mode): a workgroup per 16 chains runs
@@ -1405,7 +1416,6 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     HIPCHK(tu::nuts_pc_dense(a, m, st));
     return prof_end(ctx, st, p);
   }
-  if (a.tkind == AEHMC_T_JOINT) FAIL("joint targets run on the single-launch kernels only (option resident_nuts must not be 0)");
   if (ctx->opt_fused_nuts && a.met_ndim < 2 && target_is_elem_host(a.tkind)) {
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
@@ -1418,7 +1428,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
   if (int rc = launch_begin(ctx, a, true, st)) return rc;
   long long maxsteps = 0;
   for (int j = 0; j < max_num_expansions; j++) maxsteps += (1LL << j) + 1;  // 2**j + 1 per expansion
-  const bool compact = ctx->opt_compact && (a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN || a.tkind == AEHMC_T_GLM);
+  const bool compact = ctx->opt_compact && (a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN || a.tkind == AEHMC_T_GLM || a.tkind == AEHMC_T_JOINT);
   const int *ri = compact ? a.row_idx : nullptr, *nr = compact ? a.n_rows : nullptr;
   if (compact) {
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, (const ChainCtl *)a.ctl, (long long)C,
@@ -1703,7 +1713,6 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): the transition in one
   // launch with the products inside the wavefront (k_hmc_fused_dense), as for NUTS
   const bool tjoint = a.tkind == AEHMC_T_JOINT;
-  if (tjoint && !ctx->opt_fused_hmc) FAIL("joint targets run on the single-launch kernels only (option fused_hmc must not be 0)");
   const bool fused_dense = ctx->opt_fused_hmc && D <= FUSED_DENSE_MAX_D &&
                            (tjoint || ((a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN) &&
                                        (target_is_elem_host(a.tkind) || a.tkind == AEHMC_T_DENSE_MVN)));

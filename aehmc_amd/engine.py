@@ -196,7 +196,7 @@ class Engine:
                 self._check(self.lib.aehmc_set_custom_glm_target(self.ctx, target.source.encode(), D, X.shape[0],
                                                                  X.data_ptr(), y.data_ptr(), ptrs, len(arrs), inc.encode()),
                             "aehmc_set_custom_glm_target")
-            elif target.kind == 7:  # targets.T_JOINT: a joint density, differentiated by the engine (D <= 64)
+            elif target.kind == 7:  # targets.T_JOINT: a joint density, differentiated by the engine (D <= 2048; single-launch kernels up to 64)
                 keep = (target, p)
                 self._check(self.lib.aehmc_set_custom_joint_target(self.ctx, target.source.encode(), D, ptrs, len(arrs),
                                                                    inc.encode()), "aehmc_set_custom_joint_target")

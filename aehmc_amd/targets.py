@@ -145,7 +145,7 @@ class Custom(Target):
 
 
 class CustomJoint(Target):
-    """A user-defined JOINT (non-separable) ``logprob_fn`` of up to 64 coordinates -- hierarchical models, funnels:
+    """A user-defined JOINT (non-separable) ``logprob_fn`` of up to 2048 coordinates -- hierarchical models, funnels:
     what the reference samples through aeppl's ``joint_logprob`` (tests/test_hmc.py:170-264).  ``source`` is HIP source
     defining the log-DENSITY only,
 
@@ -162,16 +162,18 @@ class CustomJoint(Target):
                             return lp;
                           }''', dim=10)
 
-    Runs NUTS and HMC in single launches (any number of transitions) with a scalar, diagonal or dense metric, shared or
-    per chain, and under ``window_adaptation``."""
+    Up to 64 coordinates NUTS and HMC run in single launches (any number of transitions) with a scalar, diagonal or
+    dense metric, shared or per chain, and under ``window_adaptation``.  Above 64 (round 5) the target runs on the
+    lock-step path: the chain's row waits in LDS and the wavefront evaluates the density ceil(dim / 64) times per
+    gradient, lane l seeding coordinate l + 64 k in pass k -- O(dim^2 / 64) density terms per leapfrog and chain."""
 
     kind = T_JOINT
 
     def __init__(self, source: str, dim: int, params=()):
         if "aehmc_logp" not in source:
             raise ValueError("CustomJoint: the source must define aehmc_logp(const V &q, const double *const *prm)")
-        if not 1 <= int(dim) <= 64:
-            raise ValueError("CustomJoint: 1 <= dim <= 64 (one coordinate per lane of the chain's wavefront)")
+        if not 1 <= int(dim) <= 2048:
+            raise ValueError("CustomJoint: 1 <= dim <= 2048")
         self.user_source = str(source)
         self.source = _DUAL + self.user_source
         self.param_list, self.dim = list(params), int(dim)

@@ -53,7 +53,7 @@ enum aehmc_target_kind {
   AEHMC_T_LINREG = 4,       /* examples/LinearRegression.ipynb:126-166, q = [w, log n] */
   AEHMC_T_CUSTOM = 5,       /* user-defined coordinate-wise target, compiled at run time: aehmc_set_custom_target */
   AEHMC_T_GLM = 6,          /* user-defined row-reduction target over a data matrix: aehmc_set_custom_glm_target */
-  AEHMC_T_JOINT = 7         /* user-defined JOINT (non-separable) log-density, D <= 64, differentiated by the engine:
+  AEHMC_T_JOINT = 7         /* user-defined JOINT (non-separable) log-density, D <= 2048, differentiated by the engine:
                                aehmc_set_custom_joint_target */
 };
 
@@ -160,12 +160,14 @@ int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, i
  * is HIP source that includes "dual.cuh" and defines
  *     template <class V> __device__ auto aehmc_logp
  *         (const V &q, const double *const *prm)
- * with q[i] the coordinates (i wave-uniform) and q.size() = D <= 64 -- hierarchical models, funnels, anything that is
+ * with q[i] the coordinates (i wave-uniform) and q.size() = D <= 2048 -- hierarchical models, funnels, anything that is
  * not a sum over coordinates or data rows.  Forward mode: lane i of the chain's wavefront evaluates the density with
- * the derivative seeded at coordinate i (csrc/dual.cuh), so one evaluation per leapfrog yields U = -logp and the whole
- * gradient.  Runs on the single-launch kernels of small problems (k_nuts_resident / k_hmc_fused_dense compiled against
- * it: scalar, diagonal or dense metric, shared or per chain, any number of transitions per launch) and in new_state;
- * the lock-step engine (options resident_nuts / fused_hmc = 0) does not take joint targets. */
+ * the derivative seeded at coordinate i (csrc/dual.cuh), so for D <= 64 ONE evaluation per leapfrog yields U = -logp and
+ * the whole gradient: the single-launch kernels of small problems (k_nuts_resident / k_hmc_fused_dense compiled against
+ * it: scalar, diagonal or dense metric, shared or per chain, any number of transitions per launch) and new_state.
+ * Above 64 coordinates, and with options resident_nuts / fused_hmc = 0, the density is evaluated on the lock-step path
+ * between the stage kernels (k_target_joint_rows: the chain's row in LDS, ceil(D / 64) evaluations per gradient, lane l
+ * seeding coordinate l + 64 k in pass k): any metric, O(D^2 / 64) density terms per leapfrog and chain. */
 int aehmc_set_custom_joint_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
                                   int32_t n_params, const char *include_dir);
 

@@ -276,17 +276,89 @@ def test_a_wrong_hand_written_gradient_is_rejected(eng):
 def test_joint_density_errors(eng):
     from aehmc_amd import nuts, targets
     from aehmc_amd.engine import EngineError
-    with pytest.raises(ValueError, match="dim <= 64"):
-        targets.CustomJoint(FUNNEL, dim=65)
+    with pytest.raises(ValueError, match="dim <= 2048"):
+        targets.CustomJoint(FUNNEL, dim=2049)
     with pytest.raises(EngineError, match="compilation failed"):
         nuts.new_state(dev(np.zeros((2, 4))), targets.CustomJoint(FUNNEL.replace("exp(-v)", "exq(-v)"), dim=4))
     # the engine is still bound to nothing broken: a good target right behind the failed one works
     st = nuts.new_state(dev(np.zeros((2, 4))), targets.CustomJoint(FUNNEL, dim=4))
     assert torch.isfinite(st.potential_energy).all()
-    eng.set_option("resident_nuts", 0)
-    from aehmc_amd import RandomStream
-    with pytest.raises(EngineError, match="single-launch kernels"):
-        nuts.new_kernel(RandomStream(seeds=[0, 1]), targets.CustomJoint(FUNNEL, dim=4))(st, 0.1, np.ones(4))
+
+
+@pytest.mark.parametrize("D", [65, 100, 130, 2048])
+def test_joint_density_above_64_coordinates_value_and_gradient(eng, D):
+    """new_state of a joint density with more coordinates than a wavefront has lanes: the row in LDS, ceil(D / 64) forward
+    passes (k_target_joint_rows), ragged last pass; against the analytic gradient"""
+    from aehmc_amd import nuts, targets
+    r = np.random.default_rng(D)
+    q0 = 0.3 * r.normal(size=(9, D))
+    q0[:, 0] = 0.5 * r.normal(size=9)
+    state = nuts.new_state(dev(q0), targets.CustomJoint(FUNNEL, dim=D))
+    otgt = Funnel(D)
+    for c in range(q0.shape[0]):
+        U, g = otgt(q0[c])
+        np.testing.assert_allclose(state.potential_energy[c].item(), U, rtol=1e-12)
+        np.testing.assert_allclose(state.potential_energy_grad[c].cpu().numpy(), g, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("D,metric,sampler", [(100, "diag", "nuts"), (100, "dense", "nuts"), (200, "diag", "nuts"),
+                                              (100, "diag", "hmc"), (130, "dense", "hmc")])
+def test_joint_density_above_64_coordinates_samplers_match_numpy(eng, D, metric, sampler):
+    """NUTS / HMC with a joint density of 64 < D <= 2048 coordinates (lock-step path, the density evaluated between the
+    stage kernels): every transition against the numpy restatement with the analytic gradient"""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    r = np.random.default_rng(D + len(metric))
+    C, n, max_exp, L = 4, 3, 5, 6
+    eps = 0.05
+    q0 = 0.3 * r.normal(size=(C, D))
+    imm = make_metric(metric, D, r)
+    seeds = [300 + c for c in range(C)]
+    tgt, otgt = targets.CustomJoint(FUNNEL, dim=D), Funnel(D)
+    mod, omod = (nuts, no.nuts_kernel) if sampler == "nuts" else (hmc, no.hmc_kernel)
+    kw = {"max_num_expansions": max_exp} if sampler == "nuts" else {}
+    kern = mod.new_kernel(RandomStream(seeds=seeds), tgt, **kw)
+    state = mod.new_state(dev(q0), tgt)
+    okern = [omod(no.RandomStream(sd), otgt, **kw) for sd in seeds]
+    ostate = [no.new_state(q0[c].copy(), otgt) for c in range(C)]
+    extra = () if sampler == "nuts" else (L,)
+    for _ in range(n):
+        info, _ = kern(state, eps, dev(imm) if metric == "dense" else imm, *extra)
+        state = info.state._replace(momentum=None)
+        for c in range(C):
+            o = okern[c](ostate[c], eps, imm, *extra)
+            ostate[c] = o.state._replace(momentum=None)
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL)
+            np.testing.assert_allclose(info.state.potential_energy_grad[c].cpu().numpy(), o.state.potential_energy_grad,
+                                       rtol=RTOL, atol=1e-10)
+            np.testing.assert_allclose(info.acceptance_probability[c].item(), o.acceptance_probability, rtol=1e-8)
+            assert bool(info.is_diverging[c]) == bool(o.is_diverging)
+            if sampler == "nuts":
+                assert info.n_leapfrog[c].item() == o.n_leapfrog and info.num_doublings[c].item() == o.num_doublings
+                assert bool(info.is_turning[c]) == bool(o.is_turning)
+
+
+def test_joint_density_on_the_lockstep_path_equals_the_single_launch_kernels(eng):
+    """D <= 64 with resident_nuts / fused_hmc = 0: the same density on the lock-step path (it raised until round 5) --
+    same trees, same accept decisions, values to rounding"""
+    from aehmc_amd import RandomStream, hmc, nuts
+    make, _, D = models()["schools"]
+    r = np.random.default_rng(5)
+    C = 6
+    q0, imm = 0.5 * r.normal(size=(C, D)), 0.5 + r.random(D)
+    outs = {}
+    for fast in (1, 0):
+        eng.set_option("resident_nuts", 2 if fast else 0)
+        eng.set_option("fused_hmc", fast)
+        tgt = make()
+        kn = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=6)
+        sn, infn = kn.sample(nuts.new_state(dev(q0), tgt), 0.1, imm, 4)[:2]
+        kh = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        sh, infh = kh.sample(hmc.new_state(dev(q0), tgt), 0.1, imm, 7, 4)[:2]
+        outs[fast] = (sn, infn.n_leapfrog, sh, infh.acceptance_probability)
+    assert torch.equal(outs[1][1], outs[0][1])
+    for k in (0, 2, 3):
+        np.testing.assert_allclose(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy(), rtol=1e-9, atol=1e-12)
 
 
 CORRELATED_NORMAL = """
