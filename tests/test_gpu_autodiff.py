@@ -399,6 +399,43 @@ def test_joint_density_statistics_and_warmup(eng):
     assert torch.isfinite(torch.as_tensor(e)).all() and torch.isfinite(state.position).all()
 
 
+AR1_CHAIN = """
+// a stationary AR(1) chain x_0 ~ N(0, 1), x_i | x_{i-1} ~ N(rho x_{i-1}, 1 - rho^2): every marginal is N(0, 1), neighbours
+// correlate with rho -- non-separable, any number of coordinates
+template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm) {
+  const double rho = 0.6, s2 = 1.0 - rho * rho;
+  auto lp = -0.5 * q[0] * q[0];
+  for (int i = 1; i < q.size(); i++) {
+    auto d = q[i] - rho * q[i - 1];
+    lp += -0.5 * d * d / s2;
+  }
+  return lp;
+}
+"""
+
+
+def test_joint_density_above_64_coordinates_statistics_and_warmup(eng):
+    """An 80-coordinate non-separable density on the lock-step path under window_adaptation.run (per-chain step sizes and
+    diagonal metrics) and NUTS sampling: unit marginal variances, lag-1 correlation rho, zero means within Monte-Carlo
+    error -- as /root/reference/tests/test_hmc.py:267-346 checks its targets."""
+    from aehmc_amd import RandomStream, nuts, targets, window_adaptation
+    D, C, n = 80, 256, 120
+    tgt = targets.CustomJoint(AR1_CHAIN, dim=D)
+    r = np.random.default_rng(1)
+    kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=6)
+    state = nuts.new_state(dev(r.normal(size=(C, D))), tgt)
+    state, (eps, imm), _ = window_adaptation.run(kernel, state, num_steps=200)
+    samples = kernel.sample(state, eps, imm, n)[0].cpu().numpy()  # [n, C, D]
+    x = samples.reshape(-1, D)
+    chain_means = samples.mean(axis=0)                              # [C, D]
+    se = chain_means.std(axis=0) / np.sqrt(C)
+    assert np.all(np.abs(chain_means.mean(axis=0)) < 5 * se + 1e-3)
+    var = x.var(axis=0)
+    assert np.all(np.abs(var - 1.0) < 0.12), (var.min(), var.max())
+    lag1 = np.mean([np.corrcoef(x[:, i], x[:, i + 1])[0, 1] for i in range(0, D - 1, 7)])
+    assert abs(lag1 - 0.6) < 0.03, lag1
+
+
 def test_a_failed_compile_leaves_the_previous_target_bound(eng):
     """Binding a user-defined target is a transaction: a source that does not compile must not replace the
     code objects / parameter table of the target that is bound -- the next step of THAT target has to run on its own
