@@ -1131,6 +1131,21 @@ __global__ __launch_bounds__(256) void k_new_state_joint(EngineArgs a) {  // hmc
 // ceil(D / 64) times, lane l carrying the derivative with respect to coordinate l + 64 k in pass k (dual.cuh: JointRow):
 // O(D^2 / 64) density terms per gradient and wavefront, every lane ends each pass with the same value bits.
 // U -> ctl[c].U_cur (leapfrog; finished chains are skipped) or U[c] (new_state).
+// (device part: `qr` = this wavefront's D doubles of LDS; returns U on every lane)
+__device__ inline double joint_rows_eval(const EngineArgs &a, const double *q, double *g, double *qr, int lane) {
+  const int D = (int)a.D;
+  for (int i = lane; i < D; i += 64) qr[i] = q[i];
+  __threadfence_block();  // (the row is read back through other lanes' addresses)
+  double Uv = 0.0;
+  for (int k = 0; k * 64 < D; k++) {
+    const JointRow<Dual> arg{qr, lane + 64 * k, D};
+    const Dual r = aehmc_logp(arg, a.cparams);
+    if (lane + 64 * k < D) g[lane + 64 * k] = -r.d;
+    Uv = -r.v;
+  }
+  __threadfence_block();  // (the stage that follows reads g through other lanes' addresses)
+  return Uv;
+}
 __global__ __launch_bounds__(256) void k_target_joint_rows(EngineArgs a, const double *q, double *g, double *U, int to_ctl,
                                                            const int *row_idx, const int *n_rows) {
   extern __shared__ __attribute__((aligned(16))) double joint_rows[];
@@ -1144,21 +1159,86 @@ __global__ __launch_bounds__(256) void k_target_joint_rows(EngineArgs a, const d
     return;
   }
   if (to_ctl && a.ctl[c].done) return;
-  const int D = (int)a.D;
   const size_t row = (size_t)c * a.D;
-  double *const qr = joint_rows + (size_t)wave * D;
-  for (int i = lane; i < D; i += 64) qr[i] = q[row + i];
-  __threadfence_block();  // (the row is read back through other lanes' addresses)
-  double Uv = 0.0;
-  for (int k = 0; k * 64 < D; k++) {
-    const JointRow<Dual> arg{qr, lane + 64 * k, D};
-    const Dual r = aehmc_logp(arg, a.cparams);
-    if (lane + 64 * k < D) g[row + lane + 64 * k] = -r.d;
-    Uv = -r.v;
-  }
+  const double Uv = joint_rows_eval(a, q + row, g + row, joint_rows + (size_t)wave * a.D, lane);
   if (lane == 0) {
     if (to_ctl) a.ctl[c].U_cur = Uv;
     else U[c] = Uv;
+  }
+}
+// The lock-step loop of a joint target with a scalar / diagonal metric for ONE chain per wavefront, in one launch
+// (round 5; what k_nuts_fused is for coordinate-wise targets and k_nuts_pc_dense for per-chain dense metrics): the same
+// device functions in the same order -- first stages | density | last stage + bookkeeping -- hence the same bits as
+// the lock-step path, without its three launches and its host poll per leapfrog.  m.T transitions per launch.
+__global__ __launch_bounds__(256) void k_nuts_joint_rows(EngineArgs a, NutsSampleArgs m) {
+  extern __shared__ __attribute__((aligned(16))) double joint_rows[];
+  AEHMC_CHAIN_OF_WAVE();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double *const qr = joint_rows + (size_t)wave * a.D;
+  const size_t row = (size_t)c * a.D;
+  ChainRng rng = rng_load(a, c);
+  ChainCtl ct = {};
+  double U_state = a.U[c];
+  long long nleap_sum = 0;
+  for (long long t_idx = 0; t_idx < m.T; t_idx++) {
+    draw_momentum<false>(a, c, lane, rng.g[0]);
+    nuts_init_chain<false>(a, c, lane, ct, rng, &U_state);
+    while (!ct.done) {
+      double U_new = 0.0;
+      leap_stages<true, true, false, false>(a, c, lane, ct.dir, U_new);  // p_half, q'
+      ct.U_cur = joint_rows_eval(a, a.cur_q + row, a.cur_g + row, qr, lane);
+      leap_stages<false, false, true, false>(a, c, lane, ct.dir, U_new);  // p' = p_half - b dU/dq'
+      nuts_book<false>(a, c, lane, ct, rng);
+    }
+    U_state = pick2(ct.U_slot, ct.prop_slot);
+    nleap_sum += ct.nleap;
+    __threadfence_block();
+    if (m.samples) {
+      double *dst = m.samples + ((size_t)t_idx * a.C + c) * a.D;
+      for (long long i = lane; i < a.D; i += 64) dst[i] = a.q[row + i];
+    }
+    if (lane == 0) {
+      if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
+      if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
+    }
+  }
+  rng_store(a, c, lane, rng, 0, 3);
+  if (lane == 0 && m.nleap_total) m.nleap_total[c] = nleap_sum;
+}
+// HMC: nt transitions x L leapfrogs in one launch (hmc_run's lock-step loop for one chain per wavefront)
+__global__ __launch_bounds__(256) void k_hmc_joint_rows(EngineArgs a, long long L, long long nt, double *samples,
+                                                        double *acc_hist, int *div_hist) {
+  extern __shared__ __attribute__((aligned(16))) double joint_rows[];
+  AEHMC_CHAIN_OF_WAVE();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double *const qr = joint_rows + (size_t)wave * a.D;
+  const size_t row = (size_t)c * a.D;
+  Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4), g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
+  double U_state = a.U[c];
+  for (long long tt = 0; tt < nt; tt++) {
+    draw_momentum<false>(a, c, lane, g1);
+    ChainCtl ct = hmc_init_chain<false>(a, c, lane, &U_state);
+    for (long long l = 0; l < L; l++) {  // trajectory.py:86-95
+      double U_new = 0.0;
+      leap_stages<true, true, false, false>(a, c, lane, 1, U_new);
+      ct.U_cur = joint_rows_eval(a, a.cur_q + row, a.cur_g + row, qr, lane);
+      leap_stages<false, false, true, false>(a, c, lane, 1, U_new);
+    }
+    __threadfence_block();
+    const HmcEnd e = hmc_end_chain_rng<false>(a, c, lane, ct, L, g2);
+    if (e.acc) U_state = ct.U_cur;
+    if (samples) {
+      double *dst = samples + ((size_t)tt * a.C + c) * a.D;
+      for (long long i = lane; i < a.D; i += 64) dst[i] = a.q[row + i];
+    }
+    if (lane == 0) {
+      if (acc_hist) acc_hist[(size_t)tt * a.C + c] = e.pa;
+      if (div_hist) div_hist[(size_t)tt * a.C + c] = e.is_div;
+    }
+  }
+  if (lane == 0) {
+    pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
+    pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
   }
 }
 #endif

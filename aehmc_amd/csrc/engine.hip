@@ -495,7 +495,8 @@ extern "C" int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, i
   return 0;
 }
 
-static const std::vector<std::string> RTC_JBASE = {"aehmc::k_new_state_joint", "aehmc::k_target_joint_rows"};
+static const std::vector<std::string> RTC_JBASE = {"aehmc::k_new_state_joint", "aehmc::k_target_joint_rows", "aehmc::k_nuts_joint_rows",
+                                                   "aehmc::k_hmc_joint_rows"};
 extern "C" int aehmc_set_custom_joint_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
                                              int32_t n_params, const char *include_dir) {
   if (!ctx || !source || !include_dir) return -2;
@@ -1223,7 +1224,7 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
 // which kernel family a NUTS call takes (one place: aehmc_nuts_warmup asks before it commits to a
 // single-launch warm-up)
 enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE, NUTS_PATH_FUSED_DENSE,
-       NUTS_PATH_BLOCK_DENSE, NUTS_PATH_PC_DENSE };
+       NUTS_PATH_BLOCK_DENSE, NUTS_PATH_PC_DENSE, NUTS_PATH_JOINT_ROWS };
 // workspace of the small-dense kernels with per-chain metrics (hipFree waits for earlier launches that use it)
 static int fused_dense_workspace(aehmc_ctx *ctx, size_t need, double **out) {
   if (ctx->fd_ws_bytes < need) {
@@ -1264,6 +1265,12 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
   if (want_resident && tkind == AEHMC_T_JOINT && D <= FUSED_DENSE_MAX_D) return NUTS_PATH_FUSED_DENSE;  // (run-time compiled)
+  // joint target of more than 64 coordinates, scalar / diagonal metric: the lock-step loop of a chain in one wavefront,
+  // one launch per call (k_nuts_joint_rows); with a dense metric the lock-step path itself (GEMMs over all chains)
+  // -- up to D = 192: beyond, the density's O(D^2 / 64) terms are the whole cost and a wavefront that carries its chain
+  // through a deep tree holds its SIMD slot while finished chains idle, where the lock-step path compacts the live
+  // chains (funnel, 4096 chains: D = 100 3.1 -> 4.9e7 leapfrog/s in one launch, D = 256 1.41 -> 1.35e7: profiles/r5/INDEX.md)
+  if (want_resident && tkind == AEHMC_T_JOINT && nd < 2 && D <= 192) return NUTS_PATH_JOINT_ROWS;
   if (want_resident && nuts_resident_dense_supported(tkind, nd, D))
     return NUTS_PATH_FUSED_DENSE;  // (per-chain dense metrics included: each wavefront reads its own matrices)
   // mid-size dense problems (shared dense metric, 64 < D <= 512, linear dense mode): a workgroup per 16 chains runs
@@ -1402,6 +1409,19 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     } else if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(tu::nuts_block_roll(a, m, bp, st));
     else if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(tu::nuts_block_reg(a, m, bp, st));
     else HIPCHK(tu::nuts_block_dense(a, m, bp, st));
+    return prof_end(ctx, st, p);
+  }
+  if (path == NUTS_PATH_JOINT_ROWS) {  // joint target, D > 64, scalar / diagonal metric: every transition of the call in one launch
+    NutsSampleArgs m{};
+    m.T = 1;
+    if (multi && multi_done && !multi->adapt) {
+      m = *multi;
+      *multi_done = true;
+    }
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (int rc = rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[2], chain_grid(C), dim3(256), (size_t)4 * a.D * sizeof(double), st, a, m))
+      return rc;
     return prof_end(ctx, st, p);
   }
   if (path == NUTS_PATH_PC_DENSE) {  // per-chain dense metrics, 64 < D <= 512: every transition of the call in one launch
@@ -1750,6 +1770,18 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     HIPCHK(hipGetLastError());
     if (int rc = prof_end(ctx, st, p)) return rc;
     if (T > 1 && out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
+    return 0;
+  }
+  // joint target of more than 64 coordinates, scalar / diagonal metric: all T transitions in one launch, the lock-step
+  // loop of a chain in one wavefront (k_hmc_joint_rows)
+  if (ctx->opt_fused_hmc && tjoint && a.met_ndim < 2) {
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (int rc = rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[3], chain_grid(C), dim3(256), (size_t)4 * D * sizeof(double), st, a,
+                            (long long)L, (long long)T, samples, acc_hist, (int *)div_hist))
+      return rc;
+    if (int rc = prof_end(ctx, st, p)) return rc;
+    if (out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
     return 0;
   }
   // one dense metric per chain, 64 < D <= 512, coordinate-wise target, linear dense mode: all T transitions in one

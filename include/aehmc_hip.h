@@ -167,7 +167,9 @@ int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, i
  * it: scalar, diagonal or dense metric, shared or per chain, any number of transitions per launch) and new_state.
  * Above 64 coordinates, and with options resident_nuts / fused_hmc = 0, the density is evaluated on the lock-step path
  * between the stage kernels (k_target_joint_rows: the chain's row in LDS, ceil(D / 64) evaluations per gradient, lane l
- * seeding coordinate l + 64 k in pass k): any metric, O(D^2 / 64) density terms per leapfrog and chain. */
+ * seeding coordinate l + 64 k in pass k): any metric, O(D^2 / 64) density terms per leapfrog and chain; with a scalar or
+ * diagonal metric the same loop runs for one chain per wavefront in one launch per call (k_nuts_joint_rows up to
+ * D = 192, k_hmc_joint_rows at any D; bitwise the lock-step path). */
 int aehmc_set_custom_joint_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
                                   int32_t n_params, const char *include_dir);
 

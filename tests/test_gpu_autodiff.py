@@ -338,6 +338,31 @@ def test_joint_density_above_64_coordinates_samplers_match_numpy(eng, D, metric,
                 assert bool(info.is_turning[c]) == bool(o.is_turning)
 
 
+@pytest.mark.parametrize("D", [100, 192, 200])
+def test_joint_density_above_64_one_launch_equals_lockstep_bitwise(eng, D):
+    """64 < D, scalar / diagonal metric: k_nuts_joint_rows / k_hmc_joint_rows run the lock-step engine's own device
+    functions for one chain per wavefront, all transitions of a sample() call in one launch -- bit for bit the lock-step
+    path (resident_nuts / fused_hmc = 0: three launches per leapfrog), generator states included.  (NUTS takes the
+    one-launch kernel up to D = 192, HMC at any size: D = 200 compares the lock-step NUTS with itself.)"""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    r = np.random.default_rng(D)
+    C = 7
+    q0, imm = 0.3 * r.normal(size=(C, D)), 0.5 + r.random(D)
+    outs = {}
+    for fast in (1, 0):
+        eng.set_option("resident_nuts", 2 if fast else 0)
+        eng.set_option("fused_hmc", fast)
+        tgt = targets.CustomJoint(AR1_CHAIN, dim=D)
+        kn = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=5)
+        sn, infn = kn.sample(nuts.new_state(dev(q0), tgt), 0.2, imm, 3)[:2]
+        kh = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        sh, infh, acch = kh.sample(hmc.new_state(dev(q0), tgt), 0.2, imm, 5, 3)[:3]
+        outs[fast] = (sn, infn.n_leapfrog, infn.state.potential_energy, sh, acch, kn._nuts["holder"]["rng"].clone(),
+                      kh._hmc["holder"]["rng"].clone())
+    for x, y in zip(outs[1], outs[0]):
+        assert torch.equal(x, y)
+
+
 def test_joint_density_on_the_lockstep_path_equals_the_single_launch_kernels(eng):
     """D <= 64 with resident_nuts / fused_hmc = 0: the same density on the lock-step path (it raised until round 5) --
     same trees, same accept decisions, values to rounding"""
