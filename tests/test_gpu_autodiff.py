@@ -363,6 +363,35 @@ def test_joint_density_above_64_one_launch_equals_lockstep_bitwise(eng, D):
         assert torch.equal(x, y)
 
 
+def test_joint_density_above_64_per_chain_parameters(eng):
+    """per-chain step sizes and per-chain diagonal metrics (what window adaptation hands back) on the one-launch joint
+    kernels == the lock-step path, bit for bit; a per-chain DENSE metric (lock-step only) runs and stays finite"""
+    from aehmc_amd import PerChain, RandomStream, hmc, nuts, targets
+    r = np.random.default_rng(8)
+    D, C = 90, 6
+    q0 = 0.3 * r.normal(size=(C, D))
+    eps = PerChain(dev(0.1 + 0.1 * r.random(C)))
+    imm = PerChain(dev(0.5 + r.random((C, D))))
+    outs = {}
+    for fast in (1, 0):
+        eng.set_option("resident_nuts", 2 if fast else 0)
+        eng.set_option("fused_hmc", fast)
+        tgt = targets.CustomJoint(AR1_CHAIN, dim=D)
+        kn = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=5)
+        sn, infn = kn.sample(nuts.new_state(dev(q0), tgt), eps, imm, 3)[:2]
+        kh = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        sh = kh.sample(hmc.new_state(dev(q0), tgt), eps, imm, 4, 3)[0]
+        outs[fast] = (sn, infn.n_leapfrog, sh)
+    for x, y in zip(outs[1], outs[0]):
+        assert torch.equal(x, y)
+    A = r.normal(size=(C, D, D))
+    dense = PerChain(dev(np.einsum("cij,ckj->cik", A, A) / D + np.eye(D)))
+    tgt = targets.CustomJoint(AR1_CHAIN, dim=D)
+    kn = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=4)
+    info, _ = kn(nuts.new_state(dev(q0), tgt), 0.1, dense)
+    assert torch.isfinite(info.state.position).all() and (info.n_leapfrog > 0).all()
+
+
 def test_joint_density_on_the_lockstep_path_equals_the_single_launch_kernels(eng):
     """D <= 64 with resident_nuts / fused_hmc = 0: the same density on the lock-step path (it raised until round 5) --
     same trees, same accept decisions, values to rounding"""
