@@ -318,14 +318,14 @@ static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vec
     if (ctx->custom_src.empty()) FAIL("internal: no user-defined target source");
     std::string src = RTC_PROLOGUE;
     if (joint) src += "#define AEHMC_JOINT_TARGET 1\n";  // (engine.cuh: leap_small_dense calls aehmc_logp through dual.cuh)
-    else if (which != "glm") src += "#define AEHMC_CUSTOM_TARGET 1\n";  // (engine.cuh: target_elem calls aehmc_custom_elem)
+    else if (which != "glm" && which != "glmk") src += "#define AEHMC_CUSTOM_TARGET 1\n";  // (engine.cuh: target_elem calls aehmc_custom_elem)
     src += "#line 1 \"custom_target\"\n" + ctx->custom_src + "\n";
     src += "#include \"engine.cuh\"\n";
     if (which == "nuts" || which == "jnuts") src += "#include \"nuts_resident.cuh\"\n";
     if (which == "wide") src += "#include \"nuts_wide.cuh\"\n";
     if (which == "block") src += "#include \"nuts_block_reg.cuh\"\n";
     if (which == "hmc") src += "#include \"hmc_fused.cuh\"\n";
-    if (which == "glm") src += "#include \"glm_rows.cuh\"\n";
+    if (which == "glm" || which == "glmk") src += "#include \"glm_rows.cuh\"\n";  // ("glmk": one instantiation of the one-launch kernels)
     const std::string inc = "-I" + ctx->custom_inc;
     const char *opts[] = {"--offload-arch=" AEHMC_GPU_ARCH, "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str(),
                           "-mllvm", "-disable-machine-licm"};  // (the flags of csrc/Makefile)
@@ -1224,7 +1224,17 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
 // which kernel family a NUTS call takes (one place: aehmc_nuts_warmup asks before it commits to a
 // single-launch warm-up)
 enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE, NUTS_PATH_FUSED_DENSE,
-       NUTS_PATH_BLOCK_DENSE, NUTS_PATH_PC_DENSE, NUTS_PATH_JOINT_ROWS };
+       NUTS_PATH_BLOCK_DENSE, NUTS_PATH_PC_DENSE, NUTS_PATH_JOINT_ROWS, NUTS_PATH_GLM_ROWS };
+// user-defined row-reduction target with few coordinates: the one-launch kernels of glm_rows.cuh keep D partial sums per lane
+constexpr int GLM_ROWS_MAX_D = 32;
+// Where they pay (tools/debug/glm_time.py, logistic regression; profiles/r5/INDEX.md): the sweep is bound by the user's row
+// function on the vector ALUs at 2 - 3 wavefronts per SIMD, the lock-step path runs it at full occupancy, only for live
+// chains, and puts the products with X on the matrix cores -- but pays five launches per leapfrog.  One launch wins with
+// few coordinates (<= 16: 144 - 152 registers) or few chains (<= 1024: the lock-step path's launches dominate).
+static bool glm_rows_wanted(int64_t D, int64_t C) { return D <= GLM_ROWS_MAX_D && (D <= 16 || C <= 1024); }
+static std::string glm_rows_name(const char *kernel, int64_t D) {
+  return std::string("aehmc::") + kernel + "<" + (D <= 8 ? "8" : D <= 16 ? "16" : "32") + ">";
+}
 // workspace of the small-dense kernels with per-chain metrics (hipFree waits for earlier launches that use it)
 static int fused_dense_workspace(aehmc_ctx *ctx, size_t need, double **out) {
   if (ctx->fd_ws_bytes < need) {
@@ -1265,6 +1275,7 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
   if (want_resident && tkind == AEHMC_T_JOINT && D <= FUSED_DENSE_MAX_D) return NUTS_PATH_FUSED_DENSE;  // (run-time compiled)
+  if (want_resident && tkind == AEHMC_T_GLM && nd < 2 && glm_rows_wanted(D, C)) return NUTS_PATH_GLM_ROWS;  // (run-time compiled)
   // joint target of more than 64 coordinates, scalar / diagonal metric: the lock-step loop of a chain in one wavefront,
   // one launch per call (k_nuts_joint_rows); with a dense metric the lock-step path itself (GEMMs over all chains)
   // -- up to D = 192: beyond, the density's O(D^2 / 64) terms are the whole cost and a wavefront that carries its chain
@@ -1409,6 +1420,21 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     } else if (ctx->opt_block_dense != 2 && block_roll_wanted(a.D, m.T, ctx->opt_block_roll)) HIPCHK(tu::nuts_block_roll(a, m, bp, st));
     else if (ctx->opt_block_dense != 2 && block_reg_supported(a.D)) HIPCHK(tu::nuts_block_reg(a, m, bp, st));
     else HIPCHK(tu::nuts_block_dense(a, m, bp, st));
+    return prof_end(ctx, st, p);
+  }
+  if (path == NUTS_PATH_GLM_ROWS) {  // row-reduction target, D <= 32, scalar / diagonal metric: every transition of the call in one launch
+    NutsSampleArgs m{};
+    m.T = 1;
+    if (multi && multi_done && !multi->adapt) {
+      m = *multi;
+      *multi_done = true;
+    }
+    const std::string name = glm_rows_name("k_nuts_glm_rows", a.D);
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (int rc = rtc_launch(ctx, "glmk", {name}, name, chain_grid(C), dim3(256), 0, st, a, m, (const double *)ctx->glm_XT,
+                            ctx->glm_y, (long long)ctx->glm_N))
+      return rc;
     return prof_end(ctx, st, p);
   }
   if (path == NUTS_PATH_JOINT_ROWS) {  // joint target, D > 64, scalar / diagonal metric: every transition of the call in one launch
@@ -1770,6 +1796,18 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     HIPCHK(hipGetLastError());
     if (int rc = prof_end(ctx, st, p)) return rc;
     if (T > 1 && out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
+    return 0;
+  }
+  // row-reduction target with D <= 32, scalar / diagonal metric: all T transitions in one launch (glm_rows.cuh)
+  if (ctx->opt_fused_hmc && a.tkind == AEHMC_T_GLM && a.met_ndim < 2 && glm_rows_wanted(D, C)) {
+    const std::string name = glm_rows_name("k_hmc_glm_rows", D);
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (int rc = rtc_launch(ctx, "glmk", {name}, name, chain_grid(C), dim3(256), 0, st, a, (long long)L, (long long)T, samples, acc_hist,
+                            (int *)div_hist, (const double *)ctx->glm_XT, ctx->glm_y, (long long)ctx->glm_N))
+      return rc;
+    if (int rc = prof_end(ctx, st, p)) return rc;
+    if (out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
     return 0;
   }
   // joint target of more than 64 coordinates, scalar / diagonal metric: all T transitions in one launch, the lock-step

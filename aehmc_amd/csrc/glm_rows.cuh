@@ -56,4 +56,140 @@ __global__ __launch_bounds__(256) void k_glm_finish(EngineArgs a, const double *
   }
 }
 
+// ---- small-D row-reduction targets in ONE launch per call (round 5) ---------------------------------------------------
+// The lock-step path above pays two chain-batched GEMMs and three more launches per leapfrog -- right for large D x N,
+// ~80 us per leapfrog whatever the size.  With D <= DA (8 / 16 / 32) coordinates the wavefront that owns a chain can
+// sweep the data itself: lane l takes rows l, l + 64, ... (X^T [D][N]: coalesced), forms z_n = sum_d x_nd q_d with the
+// position in LDS, calls the user's row function and keeps D partial sums of x_nd dloss_n in registers; D wave sums and
+// the prior finish U and dU/dq.  Around it the lock-step engine's own stage / bookkeeping device functions, one chain
+// per wavefront (as k_nuts_fused / k_nuts_pc_dense / k_nuts_joint_rows).  The sums run in another order than the GEMMs':
+// results agree with the lock-step path to rounding (1e-13), with the numpy restatement at the usual 1e-9.
+template <int DA>
+__device__ inline double glm_rows_eval(const EngineArgs &a, const double *XT, const double *y, long long N, const double *q,
+                                       double *g, double *qs, int lane) {
+  const int D = (int)a.D;
+  for (int d = lane; d < D; d += 64) qs[d] = q[d];
+  __threadfence_block();  // (read back as broadcasts)
+  double acc[DA], ls = 0.0;
+#pragma unroll
+  for (int d = 0; d < DA; d++) acc[d] = 0.0;
+  // UN row groups per trip, all their loads requested before the first use
+  // (measured: 2 and 4 groups per trip change nothing -- the sweep is bound by the user's row function, ~200 vector
+  //  instructions per 64 rows for a logistic loss in forward mode, not by the round trips -- and cost registers)
+  constexpr int UN = 1;
+  for (long long n0 = lane; n0 < N; n0 += 64 * UN) {
+    double x[UN][DA], yv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long long n = n0 + 64 * u, nc = n < N ? n : N - 1;  // (past the end: a valid row, its terms dropped below)
+#pragma unroll
+      for (int d = 0; d < DA; d++) x[u][d] = d < D ? XT[(size_t)d * N + nc] : 0.0;
+      yv[u] = y[nc];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long long n = n0 + 64 * u;
+      double z = 0.0;
+#pragma unroll
+      for (int d = 0; d < DA; d++)
+        if (d < D) z += x[u][d] * qs[d];
+      double l, dl;
+      aehmc_glm_row(z, yv[u], n < N ? n : N - 1, a.cparams, l, dl);
+      if (n >= N) l = dl = 0.0;
+      ls += l;
+#pragma unroll
+      for (int d = 0; d < DA; d++) acc[d] += x[u][d] * dl;
+    }
+  }
+  ls = wave_sum(ls);
+  double gl = 0.0;  // lane d ends with dU/dq_d
+#pragma unroll
+  for (int d = 0; d < DA; d++) {
+    if (d < D) {
+      const double s = wave_sum(acc[d]);
+      if (lane == d) gl = s;
+    }
+  }
+  double us = 0.0;
+  if (lane < D) {
+    double u, pg;
+    aehmc_glm_prior(qs[lane], lane, a.cparams, u, pg);
+    g[lane] = gl + pg;
+    us = u;
+  }
+  us = wave_sum(us);
+  __threadfence_block();  // (the stage that follows reads g through other lanes' addresses)
+  return ls + us;
+}
+template <int DA>
+__global__ __launch_bounds__(256) void k_nuts_glm_rows(EngineArgs a, NutsSampleArgs m, const double *XT, const double *y, long long N) {
+  __shared__ double glm_q[4][DA];
+  AEHMC_CHAIN_OF_WAVE();
+  double *const qs = glm_q[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  const size_t row = (size_t)c * a.D;
+  ChainRng rng = rng_load(a, c);
+  ChainCtl ct = {};
+  double U_state = a.U[c];
+  long long nleap_sum = 0;
+  for (long long t_idx = 0; t_idx < m.T; t_idx++) {
+    draw_momentum<false>(a, c, lane, rng.g[0]);
+    nuts_init_chain<false>(a, c, lane, ct, rng, &U_state);
+    while (!ct.done) {
+      double U_new = 0.0;
+      leap_stages<true, true, false, false>(a, c, lane, ct.dir, U_new);  // p_half, q'
+      ct.U_cur = glm_rows_eval<DA>(a, XT, y, N, a.cur_q + row, a.cur_g + row, qs, lane);
+      leap_stages<false, false, true, false>(a, c, lane, ct.dir, U_new);  // p' = p_half - b dU/dq'
+      nuts_book<false>(a, c, lane, ct, rng);
+    }
+    U_state = pick2(ct.U_slot, ct.prop_slot);
+    nleap_sum += ct.nleap;
+    __threadfence_block();
+    if (m.samples) {
+      double *dst = m.samples + ((size_t)t_idx * a.C + c) * a.D;
+      for (long long i = lane; i < a.D; i += 64) dst[i] = a.q[row + i];
+    }
+    if (lane == 0) {
+      if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
+      if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
+    }
+  }
+  rng_store(a, c, lane, rng, 0, 3);
+  if (lane == 0 && m.nleap_total) m.nleap_total[c] = nleap_sum;
+}
+template <int DA>
+__global__ __launch_bounds__(256) void k_hmc_glm_rows(EngineArgs a, long long L, long long nt, double *samples, double *acc_hist,
+                                                      int *div_hist, const double *XT, const double *y, long long N) {
+  __shared__ double glm_q[4][DA];
+  AEHMC_CHAIN_OF_WAVE();
+  double *const qs = glm_q[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  const size_t row = (size_t)c * a.D;
+  Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4), g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
+  double U_state = a.U[c];
+  for (long long tt = 0; tt < nt; tt++) {
+    draw_momentum<false>(a, c, lane, g1);
+    ChainCtl ct = hmc_init_chain<false>(a, c, lane, &U_state);
+    for (long long l = 0; l < L; l++) {  // trajectory.py:86-95
+      double U_new = 0.0;
+      leap_stages<true, true, false, false>(a, c, lane, 1, U_new);
+      ct.U_cur = glm_rows_eval<DA>(a, XT, y, N, a.cur_q + row, a.cur_g + row, qs, lane);
+      leap_stages<false, false, true, false>(a, c, lane, 1, U_new);
+    }
+    __threadfence_block();
+    const HmcEnd e = hmc_end_chain_rng<false>(a, c, lane, ct, L, g2);
+    if (e.acc) U_state = ct.U_cur;
+    if (samples) {
+      double *dst = samples + ((size_t)tt * a.C + c) * a.D;
+      for (long long i = lane; i < a.D; i += 64) dst[i] = a.q[row + i];
+    }
+    if (lane == 0) {
+      if (acc_hist) acc_hist[(size_t)tt * a.C + c] = e.pa;
+      if (div_hist) div_hist[(size_t)tt * a.C + c] = e.is_div;
+    }
+  }
+  if (lane == 0) {
+    pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
+    pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
+  }
+}
+
 }  // namespace aehmc

@@ -151,6 +151,8 @@ int aehmc_set_custom_target(aehmc_ctx *ctx, const char *source, int64_t D, const
  * with X run as chain-batched fp64 MFMA GEMMs (Z = Q X^T, then G = dLoss X), the user's functions in run-time
  * compiled kernels between and behind them; lock-step engine (any metric).  The library keeps a transposed copy of X
  * and a [C, N] work array. */
+/* (round 5: with D <= 32 and a scalar / diagonal metric NUTS and HMC run whole calls in ONE launch -- the wavefront that owns
+ * a chain sweeps the rows itself, k_nuts_glm_rows / k_hmc_glm_rows -- when D <= 16 or the call has <= 1024 chains) */
 int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, int64_t N, const double *X,
                                 const double *y, const double *const *params, int32_t n_params,
                                 const char *include_dir);

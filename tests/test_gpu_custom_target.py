@@ -308,11 +308,17 @@ def logistic_data(N, D, seed):
     return X, y, w
 
 
-@pytest.mark.parametrize("N,D,metric", [(300, 6, "diag"), (1000, 3, "scalar1"), (257, 20, "dense"), (64, 70, "dense")])
-def test_custom_glm_target_matches_numpy(eng, N, D, metric):
-    """logistic regression through NUTS and HMC on the lock-step engine (the two products with X on the fp64 MFMA GEMM,
-    the user's loss / prior in run-time compiled kernels) against the numpy restatement, chain by chain"""
+@pytest.mark.parametrize("N,D,metric,resident", [(300, 6, "diag", 2), (300, 6, "diag", 0), (1000, 3, "scalar1", 2), (257, 20, "dense", 2),
+                                                 (64, 70, "dense", 2), (2000, 8, "diag", 2), (700, 13, "diag", 2), (130, 32, "diag", 2),
+                                                 (500, 33, "diag", 2)])
+def test_custom_glm_target_matches_numpy(eng, N, D, metric, resident):
+    """logistic regression through NUTS and HMC against the numpy restatement, chain by chain: on the lock-step engine
+    (the two products with X on the fp64 MFMA GEMM, the user's loss / prior in run-time compiled kernels: dense metrics,
+    D > 32, resident_nuts = 0) and, round 5, in ONE launch per call for D <= 32 with a scalar / diagonal metric (k_nuts_glm_rows
+    / k_hmc_glm_rows<8|16|32>: the wavefront that owns a chain sweeps the data rows itself)"""
     from aehmc_amd import RandomStream, hmc, nuts, targets
+    eng.set_option("resident_nuts", resident)
+    eng.set_option("fused_hmc", 1 if resident else 0)
     X, y, _ = logistic_data(N, D, N + D)
     r = np.random.default_rng(D)
     tau, C = 2.0, 4
@@ -351,6 +357,30 @@ def test_custom_glm_target_matches_numpy(eng, N, D, metric):
         o = no.hmc_kernel(no.RandomStream(seeds[c]), otgt)(no.new_state(q0[c].copy(), otgt), 0.3, imm, 6)
         np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-11)
         np.testing.assert_allclose(info.acceptance_probability[c].item(), o.acceptance_probability, rtol=1e-8)
+
+
+def test_custom_glm_one_launch_equals_lockstep(eng):
+    """sample(T) of a row-reduction target on the one-launch kernels against the lock-step engine (GEMMs): same trees, same
+    accept decisions, same generator states; values to rounding (the row sums run in another order than the GEMM's)"""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    N, D, C = 900, 10, 9
+    X, y, _ = logistic_data(N, D, 77)
+    r = np.random.default_rng(4)
+    q0, imm = 0.3 * r.normal(size=(C, D)), 0.02 + 0.05 * r.random(D)
+    tgt = targets.CustomGLM(LOGISTIC, X, y, params=[[2.0]])
+    outs = {}
+    for fast in (1, 0):
+        eng.set_option("resident_nuts", 2 if fast else 0)
+        eng.set_option("fused_hmc", fast)
+        kn = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=6)
+        sn, infn = kn.sample(nuts.new_state(dev(q0), tgt), 0.4, imm, 4)[:2]
+        kh = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+        sh, _, acch = kh.sample(hmc.new_state(dev(q0), tgt), 0.3, imm, 6, 4)[:3]
+        outs[fast] = (sn, sh, acch, infn.n_leapfrog, kn._nuts["holder"]["rng"].clone(), kh._hmc["holder"]["rng"].clone())
+    for k in (3, 4, 5):
+        assert torch.equal(outs[1][k], outs[0][k])
+    for k in (0, 1, 2):
+        np.testing.assert_allclose(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy(), rtol=1e-9, atol=1e-12)
 
 
 def test_custom_glm_posterior(eng):

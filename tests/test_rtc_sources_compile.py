@@ -63,8 +63,32 @@ template __global__ void aehmc::k_hmc_fused_dense<true, false, true>(aehmc::Engi
 '''
 
 
+GLM = r'''
+#include "dual.cuh"
+template <class T> __device__ T aehmc_glm_loglik(T z, double y, long long n, const double *const *prm) {   // what targets.CustomGLM receives
+  return y * z - softplus(z);
+}
+template <class T> __device__ T aehmc_glm_logprior(T q, long long i, const double *const *prm) { return -0.5 * q * q / 4.0; }
+__device__ void aehmc_glm_row(double z, double y, long long n, const double *const *prm, double &loss, double &dloss) {  // targets._GLM_FROM_LOGP
+  const aehmc::Dual r = aehmc_glm_loglik(aehmc::Dual(z, 1.0), y, n, prm);
+  loss = -r.v;
+  dloss = -r.d;
+}
+__device__ void aehmc_glm_prior(double q, long long i, const double *const *prm, double &u, double &g) {
+  const aehmc::Dual r = aehmc_glm_logprior(aehmc::Dual(q, 1.0), i, prm);
+  u = -r.v;
+  g = -r.d;
+}
+#include "glm_rows.cuh"
+template __global__ void aehmc::k_nuts_glm_rows<8>(aehmc::EngineArgs, aehmc::NutsSampleArgs, const double *, const double *, long long);
+template __global__ void aehmc::k_nuts_glm_rows<32>(aehmc::EngineArgs, aehmc::NutsSampleArgs, const double *, const double *, long long);
+template __global__ void aehmc::k_hmc_glm_rows<16>(aehmc::EngineArgs, long long, long long, double *, double *, int *, const double *, const double *, long long);
+'''
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("name,source", [("elementwise", ELEMENTWISE), ("joint", JOINT)], ids=["elementwise", "joint"])
+@pytest.mark.parametrize("name,source", [("elementwise", ELEMENTWISE), ("joint", JOINT), ("glm", GLM)],
+                         ids=["elementwise", "joint", "glm"])
 def test_kernel_templates_instantiate_against_a_user_density(tmp_path, name, source):
     path = tmp_path / f"{name}.hip"
     path.write_text(source)
