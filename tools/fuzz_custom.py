@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep for USER-DEFINED targets (run-time compiled kernels): random sampler, target form
-(coordinate-wise Student-t given by its density / joint AR(1) density), D, metric, chain count and engine options against
+(coordinate-wise Student-t given by its density / joint AR(1) density / logistic regression given by its densities), D, metric, chain count and engine options against
 the numpy restatement (oracle/np_oracle.py) with the analytic gradient -- positions, energies and gradients at 1e-9,
 leapfrog counts / doublings / flags exact.  Every kernel family a user target can reach is drawn: register-resident,
 workgroup-per-chain, block-resident, lock-step, the joint one-launch kernels below and above 64 coordinates.
@@ -50,6 +50,24 @@ class StudentT:
         return float(u), (self.nu + 1.0) * z / (self.nu + z * z) / self.s
 
 
+GLM = """
+template <class T> __device__ T aehmc_glm_loglik(T z, double y, long long n, const double *const *prm) { return y * z - softplus(z); }
+template <class T> __device__ T aehmc_glm_logprior(T q, long long i, const double *const *prm) { return -0.5 * q * q / (prm[0][0] * prm[0][0]); }
+"""
+
+
+class Logistic:
+    def __init__(self, X, y, tau):
+        self.X, self.y, self.tau = X, y, tau
+
+    def __call__(self, q):
+        q = np.asarray(q, dtype=np.float64)
+        z = self.X @ q
+        loss = np.where(z > 0, z + np.log1p(np.exp(-np.abs(z))), np.log1p(np.exp(-np.abs(z)))) - self.y * z
+        d = 1.0 / (1.0 + np.exp(-z)) - self.y
+        return float(loss.sum() + (0.5 * q * q / self.tau ** 2).sum()), self.X.T @ d + q / self.tau ** 2
+
+
 class Ar1:
     def __call__(self, q):
         q = np.asarray(q, dtype=np.float64)
@@ -68,18 +86,27 @@ class Ar1:
 def one(case):
     r = np.random.default_rng(case)
     sampler = r.choice(["nuts", "hmc"])
-    form = r.choice(["elem", "joint"], p=[0.6, 0.4])
+    form = r.choice(["elem", "joint", "glm"], p=[0.45, 0.3, 0.25])
     mk = r.choice(["diag", "dense"], p=[0.7, 0.3])
     if form == "elem":
         D = int(r.choice([3, 40, 70, 130, 200, 300, 600, 1100, 2500] if mk == "diag" else [5, 40, 70, 130, 200, 300]))
+    elif form == "glm":
+        D = int(r.choice([1, 2, 7, 8, 9, 16, 17, 31, 32, 33, 45]))
     else:
         D = int(r.choice([2, 9, 33, 64, 65, 100, 150, 192, 193, 260]))
     C = int(r.choice([1, 3, 5, 17]))
+    if form == "glm" and r.random() < 0.15:
+        C = 1030  # (above the chain count up to which D > 16 takes the one-launch kernels)
     opts = {"resident_nuts": int(r.choice([0, 2], p=[0.25, 0.75])), "fused_hmc": int(r.choice([0, 1], p=[0.25, 0.75])),
             "block_dense": int(r.choice([0, 1, 2], p=[0.2, 0.6, 0.2]))}
     if form == "elem":
         nu, s = 3.0 + 5 * r.random(D), 0.5 + r.random(D)
         tgt, otgt = targets.Custom(STUDENT_T, params=[nu, s]), StudentT(nu, s)
+    elif form == "glm":
+        N = int(r.choice([1, 5, 63, 64, 65, 200, 1000, 2500]))
+        X = r.normal(size=(N, D)) / np.sqrt(D)
+        y = (r.random(N) < 0.5).astype(np.float64)
+        tgt, otgt = targets.CustomGLM(GLM, X, y, params=[[2.0]]), Logistic(X, y, 2.0)
     else:
         tgt, otgt = targets.CustomJoint(AR1, dim=D), Ar1()
     if mk == "diag":
@@ -99,18 +126,18 @@ def one(case):
     try:
         if sampler == "nuts":
             kern = nuts.new_kernel(RandomStream(seeds=seeds), tgt, max_num_expansions=max_exp)
-            okern = [no.nuts_kernel(no.RandomStream(sd), otgt, max_num_expansions=max_exp) for sd in seeds]
+            okern = {c: no.nuts_kernel(no.RandomStream(seeds[c]), otgt, max_num_expansions=max_exp) for c in (range(C) if C < 100 else (0, 1, C // 2, C - 1))}
             extra = ()
         else:
             kern = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
-            okern = [no.hmc_kernel(no.RandomStream(sd), otgt) for sd in seeds]
+            okern = {c: no.hmc_kernel(no.RandomStream(seeds[c]), otgt) for c in (range(C) if C < 100 else (0, 1, C // 2, C - 1))}
             extra = (L,)
         state = nuts.new_state(torch.as_tensor(q0, device="cuda"), tgt)
-        ostate = [no.new_state(q0[c].copy(), otgt) for c in range(C)]
+        ostate = {c: no.new_state(q0[c].copy(), otgt) for c in (range(C) if C < 100 else (0, 1, C // 2, C - 1))}
         for _ in range(n):
             info, _ = kern(state, eps, immg, *extra)
             state = info.state._replace(momentum=None)
-            for c in range(C):
+            for c in (range(C) if C < 100 else (0, 1, C // 2, C - 1)):  # (the oracle is a Python loop: a few chains of a big call)
                 o = okern[c](ostate[c], eps, imm, *extra)
                 ostate[c] = o.state._replace(momentum=None)
                 ctx = dict(case=case, sampler=sampler, form=form, metric=mk, D=D, C=C, c=c, **opts)
