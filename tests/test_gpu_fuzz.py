@@ -18,3 +18,15 @@ def test_random_configurations_match_oracle():
     assert out.returncode == 0, tail
     line = [l for l in out.stdout.splitlines() if l.startswith("fuzz:")][-1]
     assert int(line.split()[1]) >= 100 and " 0 mismatches" in line, line
+
+
+@pytest.mark.timeout(600)
+def test_random_user_defined_targets_match_numpy():
+    """tools/fuzz_custom.py: user-defined targets (density-only Student-t, a joint AR(1) density, logistic regression) over
+    the run-time compiled kernel families, against the numpy restatement with the analytic gradient"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_custom.py"), "20", "11"],
+                         capture_output=True, text=True, timeout=550, cwd=ROOT)
+    tail = out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.returncode == 0, tail
+    line = [l for l in out.stdout.splitlines() if l.startswith("fuzz_custom:")][-1]
+    assert int(line.split()[1]) >= 50 and " 0 mismatches" in line, line
