@@ -45,6 +45,7 @@ SYMBOLS = {
     "aehmc_set_custom_target": (_I, [_P, ct.c_char_p, _I64, ct.POINTER(_P), ct.c_int32, ct.c_char_p]),
     "aehmc_set_custom_joint_target": (_I, [_P, ct.c_char_p, _I64, ct.POINTER(_P), ct.c_int32, ct.c_char_p]),
     "aehmc_set_rtc_cache": (_I, [_P, ct.c_char_p]),
+    "aehmc_rtc_stats": (_I, [_P, ct.POINTER(ct.c_int64), ct.POINTER(ct.c_int64)]),
     "aehmc_set_custom_glm_target": (_I, [_P, ct.c_char_p, _I64, _I64, _P, _P, ct.POINTER(_P), ct.c_int32, ct.c_char_p]),
     "aehmc_set_metric": (_I, [_P, ct.POINTER(CMetric)]),
     "aehmc_set_step_sizes": (_I, [_P, _P, _I64]),

@@ -98,6 +98,7 @@ struct aehmc_ctx {
   // keyed by program + source, kept for the life of the ctx) and the device array of its parameter arrays
   std::string custom_src, custom_inc;
   std::string rtc_cache_dir;  // compiled code objects of user-defined targets, kept across processes (aehmc_set_rtc_cache)
+  int64_t rtc_compiled = 0, rtc_loaded = 0;  // programs compiled by hipRTC / taken from rtc_cache_dir (aehmc_rtc_stats)
   const double **d_cparams = nullptr;
   int n_cparams = 0;
   // user-defined row-reduction target: data matrix X [N,D], its transpose (owned), responses, [C,N] / [C] work arrays (owned)
@@ -306,6 +307,12 @@ extern "C" int aehmc_set_rtc_cache(aehmc_ctx *ctx, const char *dir) {
   ctx->rtc_cache_dir = dir ? dir : "";
   return 0;
 }
+extern "C" int aehmc_rtc_stats(const aehmc_ctx *ctx, int64_t *compiled, int64_t *loaded_from_cache) {
+  if (!ctx) return -2;
+  if (compiled) *compiled = ctx->rtc_compiled;
+  if (loaded_from_cache) *loaded_from_cache = ctx->rtc_loaded;
+  return 0;
+}
 
 static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vector<std::string> &names,
                         const std::string &want, hipFunction_t *out) {
@@ -372,6 +379,9 @@ static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vec
       }
       hiprtcDestroyProgram(&prog);
       if (!cache_path.empty()) rtc_cache_store(cache_path, lowered, code);
+      ctx->rtc_compiled++;
+    } else {
+      ctx->rtc_loaded++;
     }
     aehmc_ctx::RtcProgram rp;
     if (hipModuleLoadData(&rp.mod, code.data()) != hipSuccess) {

@@ -351,6 +351,13 @@ class Engine:
         self._check(self.lib.aehmc_set_workspace(self.ctx, self._ws.data_ptr(), self._ws.numel()),
                     "aehmc_set_workspace")
 
+    def rtc_stats(self):
+        """(programs compiled by hipRTC, programs loaded from the on-disk cache) of this engine's ctx."""
+        import ctypes as ct
+        a, b = ct.c_int64(0), ct.c_int64(0)
+        self._check(self.lib.aehmc_rtc_stats(self.ctx, ct.byref(a), ct.byref(b)), "aehmc_rtc_stats")
+        return a.value, b.value
+
     def set_option(self, name: str, value: int):
         self._check(self.lib.aehmc_set_option(self.ctx, name.encode(), int(value)), "aehmc_set_option")
 

@@ -180,6 +180,9 @@ int aehmc_set_custom_joint_target(aehmc_ctx *ctx, const char *source, int64_t D,
  * directory that is specific to the library's own sources -- the headers a program includes (aehmc_amd/engine.py uses
  * ~/.cache/aehmc_amd/rtc-<source hash>).  NULL or "" switches the cache off (default). */
 int aehmc_set_rtc_cache(aehmc_ctx *ctx, const char *dir);
+/* How many run-time programs this ctx compiled with hipRTC and how many it took from the directory above (either
+ * pointer may be NULL): what a caller checks to know that a second process did not recompile -- a count, not a time. */
+int aehmc_rtc_stats(const aehmc_ctx *ctx, int64_t *compiled, int64_t *loaded_from_cache);
 int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
 
 /* engine options (name, default):

@@ -517,22 +517,22 @@ def test_a_failed_compile_leaves_the_previous_target_bound(eng):
 def test_compiled_targets_are_kept_on_disk_across_processes(tmp_path):
     """The code objects of a user-defined target are cached on disk (keyed by everything the compiler saw, in a directory
     named by the library's source hash): a second PROCESS binds the same target without recompiling and computes the
-    same bits."""
+    same bits.  "Without recompiling" is the library's own count of hipRTC compilations (aehmc_rtc_stats), not a time."""
     import os, subprocess, sys, json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prog = r"""
-import json, sys, time, numpy as np, torch
+import json, sys, numpy as np, torch
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 from aehmc_amd import RandomStream, nuts, targets
+from aehmc_amd.engine import get_engine
 from test_gpu_autodiff import FUNNEL
 torch.zeros(1, device="cuda")
 tgt = targets.CustomJoint(FUNNEL, dim=10)
 q0 = torch.as_tensor(0.3 * np.random.default_rng(0).normal(size=(8, 10)), device="cuda")
-t0 = time.perf_counter()
 state = nuts.new_state(q0, tgt)
 info, _ = nuts.new_kernel(RandomStream(seeds=list(range(8))), tgt, max_num_expansions=5)(state, 0.1, np.ones(10))
 torch.cuda.synchronize()
-print(json.dumps({"seconds": time.perf_counter() - t0, "q": info.state.position.cpu().numpy().tolist()}))
+print(json.dumps({"rtc": list(get_engine().rtc_stats()), "q": info.state.position.cpu().numpy().tolist()}))
 """ % (root, os.path.join(root, "tests"))
     env = dict(os.environ, AEHMC_AMD_RTC_CACHE=str(tmp_path))
     runs = []
@@ -543,4 +543,4 @@ print(json.dumps({"seconds": time.perf_counter() - t0, "q": info.state.position.
     files = [f for d, _, fs in os.walk(tmp_path) for f in fs]
     assert len(files) == 2 and all(f.endswith(".aehmcco") for f in files), files  # new_state's program and the NUTS kernel
     assert runs[0]["q"] == runs[1]["q"]
-    assert runs[1]["seconds"] < 0.5 * runs[0]["seconds"] and runs[1]["seconds"] < 2.0, [r["seconds"] for r in runs]
+    assert runs[0]["rtc"] == [2, 0] and runs[1]["rtc"] == [0, 2], [r["rtc"] for r in runs]  # [compiled, loaded from disk]

@@ -4,7 +4,7 @@
 the numpy restatement (oracle/np_oracle.py) with the analytic gradient -- positions, energies and gradients at 1e-9,
 leapfrog counts / doublings / flags exact.  Every kernel family a user target can reach is drawn: register-resident,
 workgroup-per-chain, block-resident, lock-step, the joint one-launch kernels below and above 64 coordinates.
-usage: fuzz_custom.py [seconds] [seed]"""
+usage: fuzz_custom.py [seconds] [seed]   (FUZZ_COUNT=N or FUZZ_CASES=a,b,... : fixed case lists)"""
 import os, sys, time, traceback
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -157,13 +157,24 @@ def one(case):
 
 
 t0, n, bad = time.time(), 0, []
-case = seed0 * 1_000_000
-only = [int(x) for x in os.environ.get("FUZZ_CASES", "").split(",") if x]
-for case in only:
-    one(case)
-if only:
-    sys.exit(0)
-while time.time() - t0 < budget:
+
+
+def cases():
+    """FUZZ_CASES=id,id,... : exactly those; FUZZ_COUNT=N : the N ids from seed * 10**6 on (both deterministic -- what the test
+    suite runs); otherwise ids from seed * 10**6 on for `seconds` of wall clock (the long sweeps recorded under profiles/)."""
+    only = [int(x) for x in os.environ.get("FUZZ_CASES", "").split(",") if x]
+    if only:
+        yield from only
+    elif os.environ.get("FUZZ_COUNT"):
+        yield from range(seed0 * 1_000_000, seed0 * 1_000_000 + int(os.environ["FUZZ_COUNT"]))
+    else:
+        case = seed0 * 1_000_000
+        while time.time() - t0 < budget:
+            yield case
+            case += 1
+
+
+for case in cases():
     try:
         one(case)
         n += 1
@@ -171,5 +182,5 @@ while time.time() - t0 < budget:
         bad.append(case)
         print("MISMATCH case", case, repr(e)[:700], flush=True)
         traceback.print_exc(limit=1)
-    case += 1
 print(f"fuzz_custom: {n} configurations in {time.time() - t0:.0f} s, {len(bad)} mismatches: {bad}")
+sys.exit(1 if bad else 0)

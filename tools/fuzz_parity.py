@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: random (sampler, target, metric, D, C, step size, tree depth, engine options)
 against the C oracle -- every discrete output and the generator state exact, values to 1e-9.  A net
-for variants that no hand-written test reaches.  usage: fuzz_parity.py [seconds] [seed]"""
+for variants that no hand-written test reaches.  usage: fuzz_parity.py [seconds] [seed]   (FUZZ_COUNT=N or FUZZ_CASES=a,b,... : fixed case lists)"""
 import os, sys, time, traceback
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -148,15 +148,30 @@ def one(case):
 
 
 t0, n, bad = time.time(), 0, []
-case = seed0 * 1_000_000
-while time.time() - t0 < budget:
+
+
+def cases():
+    """FUZZ_CASES=id,id,... : exactly those; FUZZ_COUNT=N : the N ids from seed * 10**6 on (both deterministic -- what the test
+    suite runs); otherwise ids from seed * 10**6 on for `seconds` of wall clock (the long sweeps recorded under profiles/)."""
+    only = [int(x) for x in os.environ.get("FUZZ_CASES", "").split(",") if x]
+    if only:
+        yield from only
+    elif os.environ.get("FUZZ_COUNT"):
+        yield from range(seed0 * 1_000_000, seed0 * 1_000_000 + int(os.environ["FUZZ_COUNT"]))
+    else:
+        case = seed0 * 1_000_000
+        while time.time() - t0 < budget:
+            yield case
+            case += 1
+
+
+for case in cases():
     try:
         d = one(case)
         n += d is not None
     except Exception as e:
         bad.append((case, repr(e)[:400]))
-        print("MISMATCH case", case, repr(e)[:600], flush=True)
+        print("MISMATCH case", case, repr(e)[:700], flush=True)
         traceback.print_exc(limit=1)
-    case += 1
 print(f"fuzz: {n} configurations in {time.time() - t0:.0f} s, {len(bad)} mismatches: {[b[0] for b in bad]}")
 sys.exit(1 if bad else 0)
