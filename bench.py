@@ -85,10 +85,15 @@ def emit(obj, verbose=False):
                 "valu_busy_fraction_of_kernel_time_at_2.4GHz", "l2_hit_rate", "clock_GHz_grbm")
         # `traffic_source` is always profiles/<round>/<config>_pmc_summary.json; long counter dicts shrink to the figures
         # the roofline argument uses; only then the prose (`workload`: the `config` names say which) and the rest
-        for drop in ("traffic_source", "<long counters>", "streaming_bytes_per_transition", "algorithmic_l2_bytes_per_launch",
+        for drop in ("<short counters_dropped>", "traffic_source", "<long counters>", "streaming_bytes_per_transition", "algorithmic_l2_bytes_per_launch",
                      "algorithmic_flops_per_launch", "whole_call_leapfrogs_per_s", "workload", "counters", "hbm", "valu", "fp64_flops", "launches", "avg_launch_ms"):
             for e in obj["secondary"]:
                 roof = e.get("roofline") if isinstance(e.get("roofline"), dict) else {}
+                if drop == "<short counters_dropped>":  # (the top-level roofline keeps the full sentence)
+                    for holder in (e, roof):
+                        if holder.get("counters_dropped"):
+                            holder["counters_dropped"] = "summary of another build"
+                    continue
                 if drop == "<long counters>":
                     for holder in (e, roof):
                         c = holder.get("counters")
@@ -115,7 +120,7 @@ def pmc_summary(name):
     profiles/rN/<name>, and only if it was measured on the very binary this run loads -- every summary stores the
     sha256 of the libaehmc_hip.so it profiled (`lib_sha256`); one without it, or with another hash, is NOT used:
     peak / frac / traffic derived from it are dropped from the line and `counters_dropped` says why."""
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         path = os.path.join(PROFILES_DIR, rnd, name)
         if os.path.exists(path):
             summ = json.load(open(path))

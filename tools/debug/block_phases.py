@@ -48,13 +48,15 @@ vec = ((C * D * 8) + 255) & ~255
 off = (26 + 3 * E) * vec
 flow = False  # (k_nuts_block_flow: tools/debug/experiments/block_flow)
 nrec = (C + 15) // 16 * 4 if flow else C  # k_nuts_block_flow: one record per wavefront (4 per workgroup)
-tim = ws[off: off + nrec * 8 * 8].view(torch.float64).reshape(nrec, 8).cpu().numpy()
+NS = 16 if (D <= 256 and os.environ.get('BLOCK_DENSE', '1') == '1') else 8
+tim = ws[off: off + nrec * NS * 8].view(torch.float64).reshape(nrec, NS).cpu().numpy()
 blocks = nl[: C // 16 * 16].reshape(-1, 16).max(axis=1)
 names = ["rows->LDS", "barrier A", "MFMA", "barrier B", "book", "leap12", "vote", "begin"]
 if flow:
     names = ["book: pass", "book: sums, scalars, draw, take", "MFMA", "barriers", "book: U-turn levels, expansion, end / next", "stage12", "vote", "begin"]
 elif D <= 256 and os.environ.get("BLOCK_DENSE", "1") == "1":  # the register kernel's phases
-    names = ["book: pass", "book: scal", "MFMA", "barriers", "book: rest", "stage12", "vote", "begin/end/draw"]
+    names = ["book: pass", "book: step scalars + draw", "MFMA", "barriers", "book: control + expansion end", "stage12", "vote", "begin/end/draw",
+             "book: reductions, energy", "book: proposal copy", "book: U-turn levels", "", "", "", "", ""]
 tot = tim.sum(axis=1)
 print(f"D={D} C={C} T={T}: {dt*1e3:.3f} ms per transition; leapfrogs/chain/transition mean {nl.mean():.1f}; "
       f"ticks per wave and transition {tot.mean() / T:.0f}")

@@ -91,9 +91,28 @@ AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_blk_pack(const double *s
 // blk_gemm_ablate.hip, D = 512): MFMAs alone 64.6 cycles each per SIMD, + A fragments from LDS 66, + this tile padded
 // to 18 doubles per row (conflict-free reads, two-way conflicts on the writes) 98, swizzled 77; the global loads
 // and the wavefront fences add nothing.
+// The first BLK_PREFETCH K-tiles of a wavefront's column block of B, requested AHEAD of the product (round 6): B does not
+// depend on anything the chains compute, so the block-resident kernels issue these loads before the workgroup barrier
+// that precedes the product -- the L2 round trip (~1 000 cycles at the head of every product, with the MFMA pipe idle)
+// passes while the wavefront waits at the barrier.
+struct BlkPre {
+  d2_t gb[BLK_PREFETCH][2];
+};
+__device__ __forceinline__ void blk_tile_prefetch(const double *__restrict__ Bp, int Dp, int n0, int lane, BlkPre &pre) {
+  const int r = lane >> 2, kq = lane & 3;
+  const double *pb = Bp + (long long)(n0 + r) * Dp + 2 * kq;
+  const int nk = Dp / 16;
+#pragma unroll
+  for (int s = 0; s < BLK_PREFETCH; s++) {
+    const int kt = s < nk ? s : nk - 1;
+    pre.gb[s][0] = *reinterpret_cast<const d2_t *>(pb + kt * 16);
+    pre.gb[s][1] = *reinterpret_cast<const d2_t *>(pb + kt * 16 + 8);
+  }
+}
+template <bool PRE = false>
 __device__ __forceinline__ void blk_wave_tile(const double *abuf, int S, const double *__restrict__ Bp, int Dp,
                                               long long N, int n0, double *out, long long ldo, unsigned rowmask,
-                                              int lane, double *tb) {
+                                              int lane, double *tb, const BlkPre *pre = nullptr) {
   const int fr = lane & 15, fk = lane >> 4;
   const int r = lane >> 2, kq = lane & 3;
   const double *pb = Bp + (long long)(n0 + r) * Dp + 2 * kq;
@@ -102,9 +121,14 @@ __device__ __forceinline__ void blk_wave_tile(const double *abuf, int S, const d
   d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int s = 0; s < BLK_PREFETCH; s++) {
-    const int kt = s < nk ? s : nk - 1;
-    gb[s][0] = *reinterpret_cast<const d2_t *>(pb + kt * 16);
-    gb[s][1] = *reinterpret_cast<const d2_t *>(pb + kt * 16 + 8);
+    if (PRE) {
+      gb[s][0] = pre->gb[s][0];
+      gb[s][1] = pre->gb[s][1];
+    } else {
+      const int kt = s < nk ? s : nk - 1;
+      gb[s][0] = *reinterpret_cast<const d2_t *>(pb + kt * 16);
+      gb[s][1] = *reinterpret_cast<const d2_t *>(pb + kt * 16 + 8);
+    }
   }
   const double *pa = abuf + fr * S + fk;
   const int xw = (((r >> 1) & 1) << 3) | ((r >> 2) << 1);    // swizzle of this lane's staging row ...
@@ -149,7 +173,7 @@ __device__ __forceinline__ void blk_wave_tile(const double *abuf, int S, const d
 }
 
 // Developer instrumentation (make timing): shader-clock cycles per phase, accumulated by every wavefront and written
-// to a.linreg_part[c * 16 + phase] (k_nuts_block_dense: c * 8) (unused workspace on this path); compiled out of the product library.
+// to a.linreg_part[c * 16 + phase] (unused workspace on this path); compiled out of the product library.
 struct BlkTimer {
 #ifdef AEHMC_WIDE_TIMING
   long long acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

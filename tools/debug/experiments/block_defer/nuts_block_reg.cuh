@@ -25,7 +25,9 @@
 namespace aehmc {
 
 constexpr int BLK_REG_MAX_D = 256;
-constexpr int BLK_PARK = 20;  // doubles per wavefront: the chain's four generators (see k_nuts_block_reg) + the rolling kernel's between-transition scalars
+constexpr int BLK_PARK = 40;  // doubles per wavefront: the chain's four generators (see k_nuts_block_reg), the rolling kernel's between-transition
+                              // scalars [16..19], the point whose sampling is pending [20..23], the proposal slots' potential energies [24..26],
+                              // the tree state of the deferred code [28..35], the trajectory ends' potential energies [36..37]
 #ifndef __HIPCC_RTC__  // (host side)
 inline bool block_reg_supported(long long D) { return D >= BLK_MIN_D && D <= BLK_REG_MAX_D; }
 // two row buffers [16][S] (operand / result, swapping roles from product to product) + one staging tile per wavefront
@@ -74,11 +76,23 @@ __device__ __forceinline__ int blk_opaque(int x) {
   return x;
 }
 
-// dst[16][S] = src[16][S] * Bp^T, both in LDS, for the rows of `rowmask`; the caller places the barriers
+// dst[16][S] = src[16][S] * Bp^T, both in LDS, for the rows of `rowmask`; the caller places the barriers.  Column
+// block nt is computed by wavefront nt, or by wavefront 15 - nt (REV): the two products of a leapfrog are given to
+// opposite ends of the workgroup, so that up to D = 128 no wavefront has a block in both -- each has a whole product
+// phase for its chain's deferred tree code (nuts_block_tree.inc).
+template <bool REV = false>
 __device__ __forceinline__ void blk_gemm_lds(const double *src, double *dst, int S, const double *Bp, long long D,
                                              int wave, int lane, double *tb, unsigned rowmask = 0xffffu) {
-  const int NT = (int)((D + 15) / 16);
-  for (int nt = wave; nt < NT; nt += BLK_CHAINS) blk_wave_tile(src, S, Bp, NT * 16, D, nt * 16, dst, S, rowmask, lane, tb);
+  const int NT = (int)((D + 15) / 16);  // (<= 16: D <= BLK_REG_MAX_D)
+  const int nt = REV ? BLK_CHAINS - 1 - wave : wave;
+  if (nt < NT) blk_wave_tile(src, S, Bp, NT * 16, D, nt * 16, dst, S, rowmask, lane, tb);
+}
+__device__ __forceinline__ bool blk_has_tile(long long D, int wave, bool rev) {
+  return (rev ? BLK_CHAINS - 1 - wave : wave) < (int)((D + 15) / 16);
+}
+template <class T>
+__device__ __forceinline__ T pick4(T a0, T a1, T a2, T a3, int i) {
+  return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
 }
 
 template <int R, bool TDENSE>
@@ -137,19 +151,23 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
   }
   BlkTimer tm;
   __shared__ int blk_alive[BLK_CHAINS];  // the round's vote (the barriers order LDS traffic only: blk_barrier_lds)
+  // proposal slots (nuts_block_tree.inc): 0, 1 = the lock-step engine's two, 2 = its moving-end vectors cur_q / cur_p / cur_g
+  // (free here: the moving end lives in registers), 3 = psub / rbuf / zbuf (free here too); which slot plays which role: `roles`
+  int roles = 0, pend = 0;
 
 #define BT_LC lane
 #define BTA(ptr, r) ((ptr) + row)[lc + 64 * (r)]
-#define BT_SLOT_Q(s) pick2(a.slot_q, s)
-#define BT_SLOT_P(s) pick2(a.slot_p, s)
-#define BT_SLOT_G(s) pick2(a.slot_g, s)
+#define BT_SLOT_Q(s) pick4(a.slot_q[0], a.slot_q[1], a.cur_q, a.psub, s)
+#define BT_SLOT_P(s) pick4(a.slot_p[0], a.slot_p[1], a.cur_p, a.rbuf, s)
+#define BT_SLOT_G(s) pick4(a.slot_g[0], a.slot_g[1], a.cur_g, a.zbuf, s)
+#define BT_HAS_W 0
 #define BT_END_Q(e) pick2(a.end_q, e)
 #define BT_END_P(e) pick2(a.end_p, e)
 #define BT_END_G(e) pick2(a.end_g, e)
 #define BT_END_V(e) pick2(a.end_v, e)
 #define BT_END_W(e) pick2(a.end_w, e)
 #define BT_PSUM a.psum
-#define BT_TAKE_W(slot, r) (void)0
+#define BT_TAKE_W(slot, r, w) (void)0
 #define BT_OUT_Q a.q
 #define BT_OUT_G a.g
 #define BT_OUT_U a.U
@@ -172,6 +190,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
 #undef BT_END_W
 #undef BT_PSUM
 #undef BT_TAKE_W
+#undef BT_HAS_W
 #undef BT_OUT_Q
 #undef BT_OUT_G
 #undef BT_OUT_U
@@ -235,24 +254,23 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
       kd = wave_sum(kd);
       const double U = U_state;
       ct.H0 = U + 0.5 * kd;
-      ct.prop_E = ct.H0;
-      ct.prop_w = 0.0;
-      ct.prop_slpa = -INFINITY;
-      ct.sub_E = ct.sub_w = ct.sub_slpa = 0.0;
-      ct.U_cur = ct.U_end[0] = ct.U_end[1] = ct.U_slot[0] = ct.U_slot[1] = U;
-      ct.acc_prob = 0.0;
+      ct.U_cur = U;
+      init_parked(U, ct.H0);
       ct.nleap = 0;
       ct.j = 0;
-      ct.length = 0;
       ct.tmin = ct.tmax = 0;
       ct.done = ct.phantom = 0;
-      ct.prop_slot = 0;
       ct.ndoubl = ct.out_div = ct.out_turn = 0;
       ct.dir = blk_bernoulli(park, 1, 0.5, lane);  // trajectory.py:516
       ct.step = 0;
     }
     tm.tick(7);
-    // ---- one leapfrog of every live chain per trip: first stages | P r | imm g' | last stage + bookkeeping ----
+    // ---- one leapfrog of every live chain per trip: first stages | P r | imm g' | last stage + the bookkeeping the
+    //      next leapfrog depends on; the rest of the bookkeeping (nuts_block_tree.inc: deferred) under the products of
+    //      the next trip -- in the phase of the product the wavefront has no column block of, else before its block of
+    //      the first or of the second product by turns (so that a SIMD's wavefronts are not all in their blocks at once) ----
+    // (one call site of deferred(): the product phases are a two-trip loop)
+    const int when = !TDENSE || !blk_has_tile(D, wave, false) ? 0 : (!blk_has_tile(D, wave, true) ? 1 : (wave >> 2) & 1);
     for (;;) {
       if (valid && !ct.done) stage12();
       tm.tick(5);
@@ -265,29 +283,26 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
       live = __builtin_amdgcn_readfirstlane(live);
       tm.tick(6);  // vote (waits for the slowest chain's bookkeeping)
       if (!live) break;
-      if (TDENSE) {
-        blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb);  // dU/dq' = P r
+#pragma nounroll
+      for (int ph = 0; ph < (TDENSE ? 2 : 1); ph++) {
+        if (ph == when && pend) deferred();
+        if (!TDENSE) blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);              // w' = imm dU/dq'
+        else if (ph == 0) blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb);         // dU/dq' = P r
+        else blk_gemm_lds<true>(ybuf, xbuf, S, a.imm, D, wave, lane, tb);                 // w' = imm dU/dq'
         tm.tick(2);
         blk_barrier_lds();
         tm.tick(3);
-        blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);   // w' = imm dU/dq'
-        tm.tick(2);
-        blk_barrier_lds();
-        tm.tick(3);
-      } else {
-        blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);   // w' = imm dU/dq'
-        tm.tick(2);
-        blk_barrier_lds();
-        tm.tick(3);
+        if (TDENSE && ph == 0 && alive) stash_g();  // (dU/dq' into the candidate slot: acknowledged under the second product)
       }
       if (alive) {
         book();
         tm.tick(4);
       }
     }
+    if (pend) deferred();  // (the chains whose trees ended in the last trip)
     // ---- per-transition records (the outputs themselves were written when the transition ended) ----
     if (valid) {
-      U_state = pick2(ct.U_slot, ct.prop_slot);
+      U_state = slot_U[ct.prop_slot];
       nleap_sum += ct.nleap;
       if (m.samples) {
         double *dst = m.samples + ((size_t)t_idx * a.C + c) * D;
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
           if (ok[r]) dst[EI(r)] = AT(a.q, r);
       }
       if (lane == 0) {
-        if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
+        if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = dstate[6];
         if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
       }
     }

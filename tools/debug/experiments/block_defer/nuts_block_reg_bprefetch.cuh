@@ -80,6 +80,17 @@ __device__ __forceinline__ void blk_gemm_lds(const double *src, double *dst, int
   const int NT = (int)((D + 15) / 16);
   for (int nt = wave; nt < NT; nt += BLK_CHAINS) blk_wave_tile(src, S, Bp, NT * 16, D, nt * 16, dst, S, rowmask, lane, tb);
 }
+// the same with the head of the wavefront's column block of B requested by blk_gemm_lds_prefetch (before the barrier
+// in front of the product): D <= BLK_REG_MAX_D, so a wavefront has at most one block
+__device__ __forceinline__ void blk_gemm_lds_prefetch(const double *Bp, long long D, int wave, int lane, BlkPre &pre) {
+  const int NT = (int)((D + 15) / 16);
+  if (wave < NT) blk_tile_prefetch(Bp, NT * 16, wave * 16, lane, pre);
+}
+__device__ __forceinline__ void blk_gemm_lds_pre(const double *src, double *dst, int S, const double *Bp, long long D,
+                                                 int wave, int lane, double *tb, const BlkPre &pre, unsigned rowmask = 0xffffu) {
+  const int NT = (int)((D + 15) / 16);
+  if (wave < NT) blk_wave_tile<true>(src, S, Bp, NT * 16, D, wave * 16, dst, S, rowmask, lane, tb, &pre);
+}
 
 template <int R, bool TDENSE>
 __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, NutsSampleArgs m) {
@@ -253,11 +264,14 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
     }
     tm.tick(7);
     // ---- one leapfrog of every live chain per trip: first stages | P r | imm g' | last stage + bookkeeping ----
+    // (the head of each product's matrix block is requested before the barrier in front of the product: BlkPre)
     for (;;) {
       if (valid && !ct.done) stage12();
       tm.tick(5);
       const bool alive = valid && !ct.done;
       if (lane == 0) blk_alive[wave] = alive ? 1 : 0;
+      BlkPre pre;
+      blk_gemm_lds_prefetch(TDENSE ? m.prec : a.imm, D, wave, lane, pre);
       blk_barrier_lds();
       int live = 0;
 #pragma unroll
@@ -266,16 +280,17 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_reg(EngineArgs a, Nu
       tm.tick(6);  // vote (waits for the slowest chain's bookkeeping)
       if (!live) break;
       if (TDENSE) {
-        blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb);  // dU/dq' = P r
+        blk_gemm_lds_pre(xbuf, ybuf, S, m.prec, D, wave, lane, tb, pre);  // dU/dq' = P r
+        blk_gemm_lds_prefetch(a.imm, D, wave, lane, pre);
         tm.tick(2);
         blk_barrier_lds();
         tm.tick(3);
-        blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb);   // w' = imm dU/dq'
+        blk_gemm_lds_pre(ybuf, xbuf, S, a.imm, D, wave, lane, tb, pre);   // w' = imm dU/dq'
         tm.tick(2);
         blk_barrier_lds();
         tm.tick(3);
       } else {
-        blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb);   // w' = imm dU/dq'
+        blk_gemm_lds_pre(xbuf, ybuf, S, a.imm, D, wave, lane, tb, pre);   // w' = imm dU/dq'
         tm.tick(2);
         blk_barrier_lds();
         tm.tick(3);

@@ -78,8 +78,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
   // addressed from ONE base and stride: two scalar register pairs instead of twenty-five -- with every pointer of
   // EngineArgs live in the round loop the scalar file overflowed into VGPR lanes, and the v_readlane traffic of getting
   // them back (1215 sites against 293) made the per-leapfrog code 25 % slower (profiles/r4/INDEX.md).
-  // launch_nuts_block_reg checks the layout it relies on.  w = imm dU/dq of the two proposal slots (beside slot_q /
-  // slot_p / slot_g) lives in the moving-end rows cur_w / cur_v, which this kernel does not use otherwise.
+  // launch_nuts_block_roll checks the layout it relies on.  w = imm dU/dq of the four proposal slots (beside slot_q /
+  // slot_p / slot_g) lives in the rows cur_w / cur_v / vhalf (which this kernel does not use otherwise) and blk_w.
   // Pointers that only the once-per-transition code uses (the state and diagnostics arrays, the per-transition records)
   // are read from a table in LDS where they are used -- as kernel arguments referenced inside the round loop each would
   // hold a scalar register pair (or a VGPR lane and a v_readlane) for the whole loop.
@@ -98,13 +98,15 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
 #define W_END_Q(e) WSV(3 + 3 * (e))
 #define W_END_P(e) WSV(4 + 3 * (e))
 #define W_END_G(e) WSV(5 + 3 * (e))
-#define W_SLOT_Q(s) WSV(9 + 3 * (s))
-#define W_SLOT_P(s) WSV(10 + 3 * (s))
-#define W_SLOT_G(s) WSV(11 + 3 * (s))
+// four proposal slots (nuts_block_tree.inc): 0, 1 = the lock-step engine's two, 2 = its moving-end vectors cur_q / cur_p /
+// cur_g (vectors 0, 1, 2: free here, the moving end lives in registers), 3 = psub / rbuf / zbuf (free here too)
+#define W_SLOT_Q(s) WSV((s) < 2 ? 9 + 3 * (s) : ((s) == 2 ? 0 : 16))
+#define W_SLOT_P(s) WSV((s) < 2 ? 10 + 3 * (s) : ((s) == 2 ? 1 : 18 + 2 * a.max_exp))
+#define W_SLOT_G(s) WSV((s) < 2 ? 11 + 3 * (s) : ((s) == 2 ? 2 : 19 + 2 * a.max_exp))
 #define W_PSUM WSV(15)
 #define W_END_V(e) WSV(wmd + 1 + (e))
 #define W_END_W(e) WSV(wmd + 4 + a.max_exp + (e))
-#define W_SLOT_W(s) WSV((s) ? wmd : wmd + 3 + a.max_exp)
+#define W_SLOT_W(s) WSV((s) == 0 ? wmd + 3 + a.max_exp : ((s) == 1 ? wmd : ((s) == 2 ? 17 + 2 * a.max_exp : wmd + 6 + a.max_exp)))  /* cur_w, cur_v, vhalf, blk_w */
 #pragma unroll
   for (int r = 0; r < R; r++) {
     ok[r] = valid && EI(r) < D;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
     }
   }
   BlkTimer tm;
+  int roles = 0, pend = 0;  // (nuts_block_tree.inc: which proposal slot plays which role; what deferred() has to do)
 
 #define BT_LC (blk_opaque(lane) & 63)
 #define BTA(ptr, r) ATL(ptr, r)
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
 #define BT_END_V(e) W_END_V(e)
 #define BT_END_W(e) W_END_W(e)
 #define BT_PSUM W_PSUM
-#define BT_TAKE_W(slot, r) ATL(W_SLOT_W(slot), r) = wrow[EI(r)]  /* w = imm dU/dq travels with the proposal: the next transition starts from it */
+#define BT_TAKE_W(slot, r, w) ATL(W_SLOT_W(slot), r) = (w)  /* w = imm dU/dq travels with the proposal: the next transition starts from it */
+#define BT_HAS_W 1
 #define BT_OUT_Q COLD(double, 0)
 #define BT_OUT_G COLD(double, 1)
 #define BT_OUT_U COLD(double, 2)
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
 #undef BT_END_W
 #undef BT_PSUM
 #undef BT_TAKE_W
+#undef BT_HAS_W
 #undef BT_OUT_Q
 #undef BT_OUT_G
 #undef BT_OUT_U
@@ -185,7 +190,8 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
   // transitions costs ~T x (mean + a begin round) rounds instead of T x the deepest tree of 16 (profiles/r4/INDEX.md:
   // the estimate from recorded tree lengths and the measurement).  Only the FIRST transition of a launch has to form w
   // (one more product, all chains together).  Per-chain arithmetic is untouched: same bits whatever the schedule.
-  constexpr int PH_RUN = 0, PH_WAIT = 1, PH_DONE = 2, PH_DRAW = 3;
+  // (PH_END: the tree has ended; its deferred tree code and the transition's records run under the next round's products)
+  constexpr int PH_RUN = 0, PH_WAIT = 1, PH_DONE = 2, PH_DRAW = 3, PH_END = 4;
   __shared__ int blk_status[BLK_CHAINS];
   const int roll = m.roll > 0 ? m.roll : (TDENSE ? 3 : 4);
   int phase = valid ? PH_WAIT : PH_DONE;
@@ -219,18 +225,12 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
     kd = wave_sum(kd);
     const double U = *U_home;
     ct.H0 = U + 0.5 * kd;
-    ct.prop_E = ct.H0;
-    ct.prop_w = 0.0;
-    ct.prop_slpa = -INFINITY;
-    ct.sub_E = ct.sub_w = ct.sub_slpa = 0.0;
-    ct.U_cur = ct.U_end[0] = ct.U_end[1] = ct.U_slot[0] = ct.U_slot[1] = U;
-    ct.acc_prob = 0.0;
+    ct.U_cur = U;
+    init_parked(U, ct.H0);
     ct.nleap = 0;
     ct.j = 0;
-    ct.length = 0;
     ct.tmin = ct.tmax = 0;
     ct.done = ct.phantom = 0;
-    ct.prop_slot = 0;
     ct.ndoubl = ct.out_div = ct.out_turn = 0;
     ct.dir = blk_bernoulli(park, 1, 0.5, lane);  // trajectory.py:516
     ct.step = 0;
@@ -240,10 +240,10 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
     const int lc = blk_opaque(lane) & 63;  // (addresses formed here, not hoisted out of the round loop: see ATL)
     const long long t_cur = *t_home;
     if (lane == 0) {
-      *U_home = pick2(ct.U_slot, ct.prop_slot);
+      *U_home = slot_U[ct.prop_slot];
       *nleap_home += ct.nleap;
       *t_home = t_cur + 1;
-      if (COLD(double, 10)) COLD(double, 10)[(size_t)t_cur * a.C + c] = ct.acc_prob;
+      if (COLD(double, 10)) COLD(double, 10)[(size_t)t_cur * a.C + c] = dstate[6];
       if (COLD(int, 11)) COLD(int, 11)[(size_t)t_cur * a.C + c] = ct.out_div;
     }
     if (COLD(double, 9)) {
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
       const int sk = blk_status[k];
       runmask |= (sk == PH_RUN ? 1u : 0u) << k;
       waitmask |= (sk == PH_WAIT ? 1u : 0u) << k;
-      drawmask |= (sk == PH_DRAW ? 1u : 0u) << k;
+      drawmask |= ((sk == PH_DRAW || sk == PH_END) ? 1u : 0u) << k;
     }
     runmask = __builtin_amdgcn_readfirstlane(runmask);
     waitmask = __builtin_amdgcn_readfirstlane(waitmask);
@@ -284,28 +284,48 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
     // rows that begin a transition in this round (nothing running: all that wait, once the last normals are drawn)
     const unsigned bmask = (nwait >= need || (nrun == 0 && drawmask == 0)) ? waitmask : 0u;
     const bool beginning = (bmask >> wave) & 1u;
+    // the tree code that book() deferred (nuts_block_tree.inc) and, behind a tree's end, the transition's records: under
+    // the products -- in the phase of the product the wavefront has no column block of, else before its block of the
+    // first or of the second product by turns (one call site: the product phases are a loop)
+    auto window = [&]() __attribute__((always_inline)) {
+      if (pend) deferred();
+      if (phase == PH_END) {
+        end_transition();
+        tm.tick(7);
+      }
+    };
+    const bool has_work = pend != 0 || phase == PH_END;
     if (!(runmask | bmask)) {
       // (the workgroup's last trees have just ended: their chains draw below, the round has no products)
+      if (has_work) window();
       blk_barrier_lds();  // (blk_status is rewritten at the head of the next round)
     } else if (TDENSE) {
-      if (bmask) blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb, bmask);  // p = L^-T z (metrics.py:66-67)
-      if (runmask) blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb, runmask);   // dU/dq' = P r
-      tm.tick(2);
-      blk_barrier_lds();
-      tm.tick(3);
-      if (__builtin_expect(beginning, 0)) {
+      const int when = !blk_has_tile(D, wave, false) ? 0 : (!blk_has_tile(D, wave, true) ? 1 : (wave >> 2) & 1);
+#pragma nounroll
+      for (int ph = 0; ph < 2; ph++) {
+        if (ph == when && has_work) window();
+        if (ph == 0) {
+          if (bmask) blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb, bmask);  // p = L^-T z (metrics.py:66-67)
+          if (runmask) blk_gemm_lds(xbuf, ybuf, S, m.prec, D, wave, lane, tb, runmask);   // dU/dq' = P r
+        } else {
+          blk_gemm_lds<true>(ybuf, xbuf, S, a.imm, D, wave, lane, tb, runmask | bmask);    // w' = imm dU/dq' | v = imm p
+        }
+        tm.tick(2);
+        blk_barrier_lds();
+        tm.tick(3);
+        if (ph == 0 && phase == PH_RUN) stash_g();  // (dU/dq' into the candidate slot: acknowledged under the second product)
+        if (__builtin_expect(beginning, 0)) {
+          if (ph == 0) {
 #pragma unroll
-        for (int r = 0; r < R; r++) p[r] = ok[r] ? yrow[EI(r)] : 0.0;
-      }
-      blk_gemm_lds(ybuf, xbuf, S, a.imm, D, wave, lane, tb, runmask | bmask);          // w' = imm dU/dq' | v = imm p
-      tm.tick(2);
-      blk_barrier_lds();
-      tm.tick(3);
-      if (__builtin_expect(beginning, 0)) {
+            for (int r = 0; r < R; r++) p[r] = ok[r] ? yrow[EI(r)] : 0.0;
+          } else {
 #pragma unroll
-        for (int r = 0; r < R; r++) v[r] = ok[r] ? xrow[EI(r)] : 0.0;
+            for (int r = 0; r < R; r++) v[r] = ok[r] ? xrow[EI(r)] : 0.0;
+          }
+        }
       }
     } else {
+      if (has_work) window();
       if (bmask) blk_gemm_lds(xbuf, ybuf, S, a.sqrt_mass, D, wave, lane, tb, bmask);  // p = L^-T z
       if (runmask) blk_gemm_lds(xbuf, ybuf, S, a.imm, D, wave, lane, tb, runmask);    // w' = imm dU/dq'
       tm.tick(2);
@@ -321,6 +341,7 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
     }
     if (phase == PH_RUN) {  // (one call site: the bookkeeping is inlined once)
       book();
+      if (ct.done) phase = PH_END;
       tm.tick(4);
     }
     if (!TDENSE && __builtin_expect(bmask != 0, 0)) {  // (the running chains' bookkeeping above filled the wait)
@@ -356,9 +377,6 @@ __global__ __launch_bounds__(BLK_THREADS) void k_nuts_block_roll(EngineArgs a, N
     if (__builtin_expect(phase == PH_DRAW, 0)) {
       draw_z();
       phase = PH_WAIT;
-      tm.tick(7);
-    } else if (__builtin_expect(phase == PH_RUN && ct.done, 0)) {
-      end_transition();
       tm.tick(7);
     } else if (__builtin_expect(beginning, 0)) {
       init_tree();
@@ -401,7 +419,9 @@ inline bool blk_roll_layout_ok(const EngineArgs &a) {
   const ptrdiff_t s = a.cur_p - a.cur_q;
   const ptrdiff_t E = a.max_exp, md = 20 + 2 * E;
   auto at = [&](const double *p, ptrdiff_t k) { return p == a.cur_q + k * s; };
-  bool ok = s > 0 && at(a.psum, 15) && at(a.ckp, 17) && at(a.cur_v, md) && at(a.ckv, md + 3) && at(a.cur_w, md + 3 + E);
+  bool ok = s > 0 && at(a.cur_g, 2) && at(a.psum, 15) && at(a.psub, 16) && at(a.ckp, 17) && at(a.vhalf, 17 + 2 * E) &&
+            at(a.rbuf, 18 + 2 * E) && at(a.zbuf, 19 + 2 * E) && at(a.cur_v, md) && at(a.ckv, md + 3) &&
+            at(a.cur_w, md + 3 + E) && at(a.blk_w, md + 6 + E);
   for (int e = 0; e < 2; e++)
     ok = ok && at(a.end_q[e], 3 + 3 * e) && at(a.end_p[e], 4 + 3 * e) && at(a.end_g[e], 5 + 3 * e) &&
          at(a.slot_q[e], 9 + 3 * e) && at(a.slot_p[e], 10 + 3 * e) && at(a.slot_g[e], 11 + 3 * e) &&
