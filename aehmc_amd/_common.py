@@ -32,6 +32,10 @@ class Layout:
             self.D = shape[0] if len(shape) == 1 else 1
         self.scalar_chain_shape = shape[:1] if batched else ()
 
+    @property
+    def scalar(self):  # a chain's position is a scalar (the reference's size-() random variable)
+        return len(self.user_shape) == len(self.scalar_chain_shape)
+
     def rows(self, x, device):
         return _dev_f64(x, device).reshape(self.C, self.D).clone()
 
@@ -61,6 +65,8 @@ def new_state(q, logprob_fn, num_chains=None) -> IntegratorState:
     C = shape[0] if batched else 1
     layout = Layout(shape, batched, C)
     rows = layout.rows(q, eng.device)
+    from .targets import as_target
+    logprob_fn = as_target(logprob_fn, layout.D, layout.scalar)  # (a Python function of the position: traced once)
     eng.set_target(logprob_fn, layout.D)
     if eng.metric_ndim is None or eng.metric_D != layout.D:
         # new_state needs no metric; bind a unit one so that the ctx is complete

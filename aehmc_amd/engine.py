@@ -169,7 +169,11 @@ class Engine:
         return ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ------------------------------------------------------------------ binding
-    def set_target(self, target: Target, D: int, force: bool = False):
+    def set_target(self, target, D: int, force: bool = False, scalar=None):
+        # a Python function of the position (the reference's logprob_fn): traced once into a Custom / CustomJoint target
+        if not isinstance(target, Target):
+            from . import targets as _targets
+            target = _targets.as_target(target, D, scalar)
         # keyed by the CONTENT of the parameters (numpy arrays edited in place between calls must be seen,
         # as for the metric below), not by the identity of the Target object
         params = target.params()

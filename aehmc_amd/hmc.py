@@ -17,7 +17,7 @@ new_state = _new_state
 def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000) -> Callable:
     """Build a HMC kernel (reference: aehmc/hmc.py:43-126).
 
-    Same arguments as the reference; ``logprob_fn`` is a ``targets.Target``.  The two RNG
+    Same arguments as the reference; ``logprob_fn`` is a ``targets.Target`` or, as in the reference, a Python function of the position (traced once: ``targets.from_callable``).  The two RNG
     call sites of the reference graph (momentum hmc.py:122, accept hmc.py:194) are taken
     from ``srng`` here, in that order."""
     rng_host = srng.sites(2)
@@ -34,7 +34,7 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
         if "rng" not in holder or holder["rng"].device != eng.device:  # (uploaded at construction when a GPU is there)
             holder["rng"] = holder["rng"].to(eng.device) if "rng" in holder else rng_to_device(rng_host, eng.device)
         q, U, g = state_rows(state, layout, eng.device)
-        eng.set_target(logprob_fn, layout.D)
+        eng.set_target(logprob_fn, layout.D, scalar=layout.scalar)
         eng.set_metric(inverse_mass_matrix, layout.D)
         out = eng.hmc_step(holder["rng"], eng.set_step_sizes(step_size), int(num_integration_steps),
                            float(divergence_threshold), q, U, g)
@@ -52,7 +52,7 @@ def new_kernel(srng: RandomStream, logprob_fn, divergence_threshold: int = 1000)
         if "rng" not in holder or holder["rng"].device != eng.device:  # (uploaded at construction when a GPU is there)
             holder["rng"] = holder["rng"].to(eng.device) if "rng" in holder else rng_to_device(rng_host, eng.device)
         q, U, g = state_rows(state, layout, eng.device)
-        eng.set_target(logprob_fn, layout.D)
+        eng.set_target(logprob_fn, layout.D, scalar=layout.scalar)
         eng.set_metric(inverse_mass_matrix, layout.D)
         out = eng.hmc_sample(holder["rng"], eng.set_step_sizes(step_size), int(num_integration_steps),
                              float(divergence_threshold), int(num_samples), q, U, g, keep_samples)

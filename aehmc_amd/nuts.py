@@ -34,7 +34,7 @@ def new_kernel(srng: RandomStream, logprob_fn, max_num_expansions: int = 10,
         if "rng" not in holder or holder["rng"].device != eng.device:  # (uploaded at construction when a GPU is there)
             holder["rng"] = holder["rng"].to(eng.device) if "rng" in holder else rng_to_device(rng_host, eng.device)
         q, U, g = state_rows(state, layout, eng.device)
-        eng.set_target(logprob_fn, layout.D)
+        eng.set_target(logprob_fn, layout.D, scalar=layout.scalar)
         eng.set_metric(inverse_mass_matrix, layout.D)
         out = eng.nuts_step(holder["rng"], eng.set_step_sizes(step_size), int(max_num_expansions),
                             float(divergence_threshold), q, U, g)
@@ -52,7 +52,7 @@ def new_kernel(srng: RandomStream, logprob_fn, max_num_expansions: int = 10,
         if "rng" not in holder or holder["rng"].device != eng.device:  # (uploaded at construction when a GPU is there)
             holder["rng"] = holder["rng"].to(eng.device) if "rng" in holder else rng_to_device(rng_host, eng.device)
         q, U, g = state_rows(state, layout, eng.device)
-        eng.set_target(logprob_fn, layout.D)
+        eng.set_target(logprob_fn, layout.D, scalar=layout.scalar)
         eng.set_metric(inverse_mass_matrix, layout.D)
         out = eng.nuts_sample(holder["rng"], eng.set_step_sizes(step_size), int(max_num_expansions),
                               float(divergence_threshold), int(num_samples), q, U, g, keep_samples)

@@ -1,9 +1,11 @@
-"""Stand-ins for the reference's symbolic ``logprob_fn``.
+"""The reference's ``logprob_fn``.
 
 The reference takes any Python callable building an Aesara graph and differentiates it
-(aehmc/hmc.py:33-34, integrators.py:64-65).  Arbitrary callables cannot be compiled to
-HIP, so the engine takes Target objects naming a device function (``kind``) plus its
-parameter buffers.  ``potential = -logprob``.
+(aehmc/hmc.py:33-34, integrators.py:64-65).  Here a ``logprob_fn`` is either a Target object
+naming a device function (``kind``) plus its parameter buffers, or -- as in the reference --
+a Python function of the position: ``from_callable`` traces it once (aehmc_amd/tracing.py)
+and emits the HIP source of a ``Custom`` / ``CustomJoint`` target, which the engine compiles
+with hipRTC and differentiates.  ``potential = -logprob``.
 """
 from __future__ import annotations
 
@@ -229,3 +231,45 @@ class CustomGLM(Target):
         d = {f"p{k}": v for k, v in enumerate(self.param_list)}
         d.update(X=self.X, y=self.y)
         return d
+
+
+def from_callable(fn, dim, scalar=False, args=()):
+    """A Python ``logprob_fn`` (reference: README.md:27-36, aehmc/hmc.py:16-40 -- any function of the position) as a
+    Target: ``fn`` is called ONCE on a proxy of one chain's position (a scalar proxy if ``scalar``, else a vector of
+    ``dim`` entries; see ``aehmc_amd.tracing`` for what it may do with it) and the recorded expression is emitted as the
+    ``aehmc_logp`` template -- a sum of per-coordinate terms becomes a ``Custom`` target (every kernel family),
+    anything else a ``CustomJoint`` target (dim <= 2048).  numpy arrays the function closes over are captured as the
+    target's parameter arrays AT TRACE TIME (trace again after changing them).  An operation that cannot be traced
+    raises ``TypeError`` here, not in the compiler.
+
+        logprob_fn = lambda y: -0.5 * y**2 - 0.5 * np.log(2 * np.pi)             # README.md:27-36, scalar position
+        target = targets.from_callable(logprob_fn, 1, scalar=True)
+
+    ``hmc.new_state`` / ``new_kernel`` and ``nuts.new_state`` / ``new_kernel`` call this themselves when they are handed a
+    function instead of a Target (``as_target``)."""
+    from . import tracing
+    tr = tracing.trace(fn, dim, scalar=scalar, args=args)
+    tgt = Custom(tr.source, params=tr.params, dim=tr.dim) if tr.elementwise else CustomJoint(tr.source, tr.dim, params=tr.params)
+    tgt.traced_from = fn
+    return tgt
+
+
+_TRACED = {}  # (id(fn), dim, scalar) -> (fn, Target): one trace (and one compilation) per function and shape
+
+
+def as_target(logprob_fn, dim, scalar=None):
+    """``logprob_fn`` itself if it is a Target, else the Target traced from the Python function (cached per function).
+    ``scalar``: the position of a chain is a scalar (the function is called on a scalar proxy); None: as it was traced
+    before for this dimension, else a vector."""
+    if isinstance(logprob_fn, Target):
+        return logprob_fn
+    if not callable(logprob_fn):
+        raise TypeError(f"logprob_fn must be a targets.Target or a Python function of the position, got {type(logprob_fn).__name__}")
+    for sc in ((True, False) if scalar is None else (bool(scalar),)):
+        hit = _TRACED.get((id(logprob_fn), int(dim), sc))
+        if hit is not None and hit[0] is logprob_fn:
+            return hit[1]
+    sc = bool(scalar)
+    tgt = from_callable(logprob_fn, dim, scalar=sc)
+    _TRACED[(id(logprob_fn), int(dim), sc)] = (logprob_fn, tgt)
+    return tgt

@@ -1,0 +1,616 @@
+"""A Python ``logprob_fn`` as the reference takes it (README.md:27-36, aehmc/hmc.py:16-40: any function of the
+position): traced ONCE with proxy objects and emitted as the ``aehmc_logp`` template that ``targets.Custom`` /
+``targets.CustomJoint`` compile with hipRTC and the engine differentiates (csrc/dual.cuh).
+
+    logprob_fn = lambda y: (-0.5 * y**2 - 0.5 * np.log(2 * np.pi)).sum()       # coordinate-wise  -> targets.Custom
+    logprob_fn = lambda y: -0.5 * (y - loc) @ (P @ (y - loc))                  # joint            -> targets.CustomJoint
+    kernel = nuts.new_kernel(srng, logprob_fn); state = nuts.new_state(q, logprob_fn)
+
+What a traced function may do with its argument (a scalar for a scalar position, else a vector of ``dim`` entries):
+``+ - * / **`` and unary ``-`` with numbers, numpy arrays (captured as device parameter arrays) and other traced values;
+numpy ufuncs ``exp log log1p expm1 sqrt sin cos tanh abs square power reciprocal negative maximum minimum logaddexp``
+and ``scipy.special.erf``; ``softplus`` and ``where`` from this module; comparisons (inside ``where`` only);
+``.sum()`` / ``np.sum`` / ``.mean()``, ``@`` / ``np.dot`` (vector . vector, constant matrix @ vector, vector @ constant
+matrix); indexing and slicing with static bounds; iteration over a vector.  Anything else -- Python ``if`` on a traced
+value, ``float()``, ``math.exp``, fancy indexing -- raises ``TypeError`` at trace time and says what it was.
+"""
+from __future__ import annotations
+
+import numbers
+
+import numpy as np
+
+__all__ = ["trace", "where", "softplus", "TraceError"]
+
+
+class TraceError(TypeError):
+    pass
+
+
+# ------------------------------------------------------------------------------------------------------ indices
+class Idx:
+    """An affine index: const + sum coef * loop variable."""
+
+    __slots__ = ("c", "terms")
+
+    def __init__(self, c=0, terms=()):
+        self.c, self.terms = int(c), tuple(sorted((v, k) for v, k in terms if k != 0))
+
+    @staticmethod
+    def var(v):
+        return Idx(0, ((v, 1),))
+
+    def __add__(self, o):
+        o = o if isinstance(o, Idx) else Idx(o)
+        d = dict(self.terms)
+        for v, k in o.terms:
+            d[v] = d.get(v, 0) + k
+        return Idx(self.c + o.c, d.items())
+
+    def __mul__(self, k):
+        return Idx(self.c * k, ((v, c * k) for v, c in self.terms))
+
+    def key(self):
+        return (self.c, self.terms)
+
+    def is_var(self, v):
+        return self.c == 0 and self.terms == ((v, 1),)
+
+    def code(self, names):
+        parts = [f"{names[v]}" if k == 1 else f"{k} * {names[v]}" for v, k in self.terms]
+        if self.c or not parts:
+            parts.append(str(self.c))
+        return " + ".join(parts)
+
+
+# ------------------------------------------------------------------------------------------------------ scalars
+_UNARY = {"exp": "exp", "log": "log", "log1p": "log1p", "expm1": "expm1", "sqrt": "sqrt", "sin": "sin", "cos": "cos",
+          "tanh": "tanh", "absolute": "fabs", "fabs": "fabs", "erf": "erf", "softplus": "softplus"}
+_CMP = {"less": "<", "greater": ">", "less_equal": "<=", "greater_equal": ">=", "equal": "==", "not_equal": "!="}
+
+
+def _lit(x):
+    x = float(x)
+    if x != x:
+        return "NAN"
+    if x in (float("inf"), float("-inf")):
+        return "INFINITY" if x > 0 else "(-INFINITY)"
+    r = repr(x)
+    return r if ("." in r or "e" in r or "n" in r) else r + ".0"
+
+
+class S:
+    """A traced scalar: a node of the expression tree.  ``t``: depends on the position (its C++ type is the template's
+    arithmetic type; otherwise plain double).  ``b``: a comparison (usable in ``where`` only)."""
+
+    __array_priority__ = 1000
+    __slots__ = ("op", "args", "t", "b", "ctx")
+
+    def __init__(self, ctx, op, args, t, b=False):
+        self.ctx, self.op, self.args, self.t, self.b = ctx, op, args, t, b
+
+    # -- construction helpers
+    def _lift(self, x):
+        return _lift(self.ctx, x)
+
+    def _bin(self, op, a, b):
+        a, b = self._lift(a), self._lift(b)
+        if isinstance(a, V) or isinstance(b, V):
+            return V._ew2(self.ctx, lambda x, y: x._bin(op, x, y), a, b)
+        if a.b or b.b:
+            raise TraceError("arithmetic on a comparison result: use where(cond, a, b)")
+        if a.op == "const" and b.op == "const":  # folded in Python: what numpy itself would have computed
+            x, y = a.args[0], b.args[0]
+            with np.errstate(all="ignore"):
+                return S(self.ctx, "const", (float({"+": np.add, "-": np.subtract, "*": np.multiply, "/": np.divide}[op](x, y)),), False)
+        return S(self.ctx, "bin", (op, a, b), a.t or b.t)
+
+    def __add__(self, o): return self._bin("+", self, o)
+    def __radd__(self, o): return self._bin("+", o, self)
+    def __sub__(self, o): return self._bin("-", self, o)
+    def __rsub__(self, o): return self._bin("-", o, self)
+    def __mul__(self, o): return self._bin("*", self, o)
+    def __rmul__(self, o): return self._bin("*", o, self)
+    def __truediv__(self, o): return self._bin("/", self, o)
+    def __rtruediv__(self, o): return self._bin("/", o, self)
+
+    def __neg__(self):
+        if self.op == "const":
+            return S(self.ctx, "const", (-self.args[0],), False)
+        return S(self.ctx, "neg", (self,), self.t)
+
+    def __pos__(self): return self
+
+    def __pow__(self, o):
+        return _pow(self.ctx, self, o)
+
+    def __rpow__(self, o):
+        return _pow(self.ctx, o, self)
+
+    def __abs__(self): return _unary(self.ctx, "fabs", self)
+
+    def _cmp(self, name, o):
+        o = self._lift(o)
+        if isinstance(o, V):
+            return V._ew2(self.ctx, lambda x, y: x._cmp(name, y), self, o)
+        return S(self.ctx, "cmp", (_CMP[name], self, o), self.t or o.t, b=True)
+
+    def __lt__(self, o): return self._cmp("less", o)
+    def __gt__(self, o): return self._cmp("greater", o)
+    def __le__(self, o): return self._cmp("less_equal", o)
+    def __ge__(self, o): return self._cmp("greater_equal", o)
+    __hash__ = None
+
+    def __eq__(self, o): return self._cmp("equal", o)
+    def __ne__(self, o): return self._cmp("not_equal", o)
+
+    def __bool__(self):
+        raise TraceError("the truth value of a traced quantity was asked for (an `if`, `and`, `or`, `max()` ... on a value that "
+                         "depends on the position): Python control flow cannot be traced -- use aehmc_amd.tracing.where(cond, a, b)")
+
+    def __float__(self):
+        raise TraceError("float() of a traced quantity (math.exp / math.log / float(...) on a value that depends on the "
+                         "position): use the numpy functions (np.exp, np.log, ...), which trace")
+
+    __int__ = __index__ = __float__
+
+    def sum(self): return self
+    def mean(self): return self
+
+    @property
+    def shape(self): return ()
+
+    @property
+    def ndim(self): return 0
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        return _ufunc(self.ctx, ufunc, method, inputs, kw)
+
+    def __array_function__(self, func, types, args, kwargs):
+        return _array_function(self.ctx, func, args, kwargs)
+
+
+def _const(ctx, x):
+    return S(ctx, "const", (float(x),), False)
+
+
+def _lift(ctx, x):
+    if isinstance(x, (S, V, M)):
+        return x
+    if isinstance(x, (numbers.Real, np.floating, np.integer, np.bool_)):
+        return _const(ctx, x)
+    a = np.asarray(x)
+    if a.dtype == object or not (np.issubdtype(a.dtype, np.number) or a.dtype == bool):
+        raise TraceError(f"cannot use a {type(x).__name__} in a traced logprob_fn (numbers, numpy arrays and traced values only)")
+    if a.ndim == 0:
+        return _const(ctx, a.item())
+    if a.ndim == 1:
+        k = ctx.param(a)
+        return V(ctx, a.shape[0], lambda i, k=k: S(ctx, "par", (k, i), False))
+    if a.ndim == 2:
+        return M(ctx, a)
+    raise TraceError(f"arrays of {a.ndim} dimensions are not supported in a traced logprob_fn")
+
+
+def _unary(ctx, name, x):
+    x = _lift(ctx, x)
+    if isinstance(x, V):
+        return V(ctx, x.n, lambda i: _unary(ctx, name, x.at(i)))
+    if isinstance(x, M):
+        raise TraceError(f"{name} of a matrix is not supported")
+    if x.b:
+        raise TraceError(f"{name} of a comparison result")
+    if x.op == "const":
+        with np.errstate(all="ignore"):
+            f = {"fabs": np.fabs, "erf": _erf_np, "softplus": lambda z: np.logaddexp(0.0, z)}.get(name) or getattr(np, name)
+            return _const(ctx, f(x.args[0]))
+    return S(ctx, "un", (name, x), x.t)
+
+
+def _erf_np(z):
+    import math
+    return math.erf(float(z))
+
+
+def _pow(ctx, a, b):
+    a, b = _lift(ctx, a), _lift(ctx, b)
+    if isinstance(a, V) or isinstance(b, V):
+        return V._ew2(ctx, lambda x, y: _pow(ctx, x, y), a, b)
+    if b.op == "const":
+        p = b.args[0]
+        if p == 2.0:
+            return S(ctx, "un", ("square", a), a.t) if a.op != "const" else _const(ctx, a.args[0] ** 2)
+        if p == 1.0:
+            return a
+        if p == 0.5:
+            return _unary(ctx, "sqrt", a)
+        if p == -1.0:
+            return _const(ctx, 1.0) / a
+        if p == 3.0:
+            return a * S(ctx, "un", ("square", a), a.t) if a.op != "const" else _const(ctx, a.args[0] ** 3)
+    if a.op == "const" and b.op == "const":
+        return _const(ctx, a.args[0] ** b.args[0])
+    if a.op == "const" and a.args[0] > 0:  # c ** x = exp(x log c)
+        return _unary(ctx, "exp", b * float(np.log(a.args[0])))
+    return S(ctx, "pow", (a, b), a.t or b.t)
+
+
+def where(cond, a, b):
+    """``a`` where ``cond`` holds, else ``b`` (the traceable form of an ``if`` on a value that depends on the position)."""
+    ctx = next((x.ctx for x in (cond, a, b) if isinstance(x, (S, V))), None)
+    if ctx is None:
+        return np.where(cond, a, b)
+    cond, a, b = _lift(ctx, cond), _lift(ctx, a), _lift(ctx, b)
+    if any(isinstance(x, V) for x in (cond, a, b)):
+        n = next(x.n for x in (cond, a, b) if isinstance(x, V))
+        at = lambda x, i: x.at(i) if isinstance(x, V) else x
+        for x in (cond, a, b):
+            if isinstance(x, V) and x.n != n:
+                raise TraceError(f"where: vectors of lengths {n} and {x.n}")
+        return V(ctx, n, lambda i: where(at(cond, i), at(a, i), at(b, i)))
+    if cond.op == "const":
+        return a if cond.args[0] else b
+    if not cond.b:
+        raise TraceError("where: the condition must be a comparison")
+    return S(ctx, "where", (cond, a, b), cond.t or a.t or b.t)
+
+
+def softplus(x):
+    """log(1 + exp(x)) without overflow (the logistic log-likelihood's building block)."""
+    if isinstance(x, (S, V)):
+        return _unary(x.ctx, "softplus", x)
+    return np.logaddexp(0.0, x)
+
+
+# ------------------------------------------------------------------------------------------------------ vectors
+class V:
+    """A traced vector of static length: a function from an index to a traced scalar (nothing is materialised)."""
+
+    __array_priority__ = 1000
+    __slots__ = ("ctx", "n", "_at")
+
+    def __init__(self, ctx, n, at):
+        self.ctx, self.n, self._at = ctx, int(n), at
+
+    def at(self, i):
+        return self._at(i if isinstance(i, Idx) else Idx(i))
+
+    @staticmethod
+    def _ew2(ctx, f, a, b):
+        a, b = _lift(ctx, a), _lift(ctx, b)
+        if isinstance(a, M) or isinstance(b, M):
+            raise TraceError("elementwise arithmetic with a matrix is not supported (use M @ v)")
+        n = a.n if isinstance(a, V) else b.n
+        if isinstance(a, V) and isinstance(b, V) and a.n != b.n:
+            if a.n == 1:
+                a = a.at(0)
+            elif b.n == 1:
+                b = b.at(0)
+            else:
+                raise TraceError(f"operands of lengths {a.n} and {b.n} do not broadcast")
+            n = a.n if isinstance(a, V) else b.n
+        return V(ctx, n, lambda i: f(a.at(i) if isinstance(a, V) else a, b.at(i) if isinstance(b, V) else b))
+
+    def _bin(self, op, a, b):
+        return V._ew2(self.ctx, lambda x, y: x._bin(op, x, y), a, b)
+
+    def __add__(self, o): return self._bin("+", self, o)
+    def __radd__(self, o): return self._bin("+", o, self)
+    def __sub__(self, o): return self._bin("-", self, o)
+    def __rsub__(self, o): return self._bin("-", o, self)
+    def __mul__(self, o): return self._bin("*", self, o)
+    def __rmul__(self, o): return self._bin("*", o, self)
+    def __truediv__(self, o): return self._bin("/", self, o)
+    def __rtruediv__(self, o): return self._bin("/", o, self)
+    def __neg__(self): return V(self.ctx, self.n, lambda i: -self.at(i))
+    def __pos__(self): return self
+    def __abs__(self): return _unary(self.ctx, "fabs", self)
+    def __pow__(self, o): return _pow(self.ctx, self, o)
+    def __rpow__(self, o): return _pow(self.ctx, o, self)
+
+    def _cmp(self, name, o):
+        return V._ew2(self.ctx, lambda x, y: x._cmp(name, y), self, o)
+
+    def __lt__(self, o): return self._cmp("less", o)
+    def __gt__(self, o): return self._cmp("greater", o)
+    def __le__(self, o): return self._cmp("less_equal", o)
+    def __ge__(self, o): return self._cmp("greater_equal", o)
+    __hash__ = None
+
+    def __eq__(self, o): return self._cmp("equal", o)
+    def __ne__(self, o): return self._cmp("not_equal", o)
+
+    def __bool__(self):
+        raise TraceError("the truth value of a traced vector was asked for: Python control flow cannot be traced -- use "
+                         "aehmc_amd.tracing.where(cond, a, b)")
+
+    def __len__(self): return self.n
+
+    @property
+    def shape(self): return (self.n,)
+
+    @property
+    def ndim(self): return 1
+
+    @property
+    def size(self): return self.n
+
+    def __iter__(self):
+        return (self.at(k) for k in range(self.n))
+
+    def __getitem__(self, k):
+        if isinstance(k, (int, np.integer)):
+            k = int(k)
+            if not -self.n <= k < self.n:
+                raise IndexError(f"index {k} out of range for a vector of {self.n}")
+            return self.at(k % self.n)
+        if isinstance(k, slice):
+            start, stop, step = k.indices(self.n)
+            m = len(range(start, stop, step))
+            return V(self.ctx, m, lambda i: self.at(i * step + start))
+        if k is Ellipsis:
+            return self
+        raise TraceError(f"indexing a traced vector with {type(k).__name__}: only integers and slices with static bounds are supported")
+
+    def sum(self, axis=None):
+        if self.n == 0:
+            return _const(self.ctx, 0.0)
+        v = self.ctx.new_var()
+        body = self.at(Idx.var(v))
+        if body.b:
+            raise TraceError("sum of comparison results")
+        return S(self.ctx, "sum", (v, self.n, body), body.t)
+
+    def mean(self, axis=None):
+        return self.sum() / float(self.n)
+
+    def dot(self, o):
+        return self @ o
+
+    def __matmul__(self, o):
+        o = _lift(self.ctx, o)
+        if isinstance(o, V):
+            if o.n != self.n:
+                raise TraceError(f"dot of vectors of lengths {self.n} and {o.n}")
+            return (self * o).sum()
+        if isinstance(o, M):
+            return o.rmatvec(self)
+        raise TraceError("vector @ scalar")
+
+    def __rmatmul__(self, o):
+        o = _lift(self.ctx, o)
+        if isinstance(o, M):
+            return o.matvec(self)
+        if isinstance(o, V):
+            return o @ self
+        raise TraceError("scalar @ vector")
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        return _ufunc(self.ctx, ufunc, method, inputs, kw)
+
+    def __array_function__(self, func, types, args, kwargs):
+        return _array_function(self.ctx, func, args, kwargs)
+
+
+class M:
+    """A constant matrix (a captured 2-D numpy array): only products with traced vectors."""
+
+    def __init__(self, ctx, a):
+        self.ctx, self.rows, self.cols = ctx, a.shape[0], a.shape[1]
+        self.k = ctx.param(np.ascontiguousarray(a, dtype=np.float64).reshape(-1))
+
+    def matvec(self, v):
+        if v.n != self.cols:
+            raise TraceError(f"matrix [{self.rows}, {self.cols}] @ vector of {v.n}")
+        ctx, k, m = self.ctx, self.k, self.cols
+        return V(ctx, self.rows, lambda i: V(ctx, m, lambda j: S(ctx, "par", (k, i * m + j), False) * v.at(j)).sum())
+
+    def rmatvec(self, v):
+        if v.n != self.rows:
+            raise TraceError(f"vector of {v.n} @ matrix [{self.rows}, {self.cols}]")
+        ctx, k, m = self.ctx, self.k, self.cols
+        return V(ctx, self.cols, lambda j: V(ctx, self.rows, lambda i: v.at(i) * S(ctx, "par", (k, i * m + j), False)).sum())
+
+
+def _ufunc(ctx, ufunc, method, inputs, kw):
+    name = ufunc.__name__
+    if method != "__call__" or kw.get("out") is not None:
+        if method == "reduce" and name == "add" and len(inputs) == 1:
+            return _lift(ctx, inputs[0]).sum()
+        raise TraceError(f"numpy.{name}.{method} is not supported in a traced logprob_fn")
+    x = [_lift(ctx, i) for i in inputs]
+    if name in _UNARY:
+        return _unary(ctx, _UNARY[name], x[0])
+    if name == "square":
+        return _pow(ctx, x[0], 2.0)
+    if name == "negative":
+        return -x[0]
+    if name == "positive":
+        return x[0]
+    if name == "reciprocal":
+        return 1.0 / x[0]
+    if name in ("add", "subtract", "multiply", "divide", "true_divide"):
+        a, b = x
+        return {"add": lambda: a + b, "subtract": lambda: a - b, "multiply": lambda: a * b}.get(name, lambda: a / b)()
+    if name in ("power", "float_power"):
+        return _pow(ctx, x[0], x[1])
+    if name in _CMP:
+        a, b = x
+        return (a if isinstance(a, (S, V)) else _lift(ctx, a))._cmp(name, b)
+    if name in ("maximum", "fmax"):
+        return where(x[0] >= x[1], x[0], x[1])
+    if name in ("minimum", "fmin"):
+        return where(x[0] <= x[1], x[0], x[1])
+    if name == "logaddexp":  # numpy's own formulation
+        a, b = x
+        d = a - b
+        return where(d > 0, a + _unary(ctx, "log1p", _unary(ctx, "exp", -d)), b + _unary(ctx, "log1p", _unary(ctx, "exp", d)))
+    if name == "matmul":
+        a, b = x
+        return a @ b if isinstance(a, V) else b.__rmatmul__(a)
+    raise TraceError(f"numpy.{name} is not supported in a traced logprob_fn (supported: + - * / **, exp log log1p expm1 sqrt "
+                     "sin cos tanh abs square power reciprocal maximum minimum logaddexp, scipy.special.erf, sum, dot, where)")
+
+
+def _array_function(ctx, func, args, kwargs):
+    name = getattr(func, "__name__", str(func))
+    if name == "sum" and len(args) == 1 and kwargs.get("axis") in (None, 0, -1):
+        return _lift(ctx, args[0]).sum()
+    if name == "mean" and len(args) == 1 and kwargs.get("axis") in (None, 0, -1):
+        return _lift(ctx, args[0]).mean()
+    if name in ("dot", "inner", "vdot", "matmul") and len(args) == 2:
+        a, b = _lift(ctx, args[0]), _lift(ctx, args[1])
+        if isinstance(a, M):
+            return a.matvec(b)
+        return a @ b
+    if name == "where" and len(args) == 3:
+        return where(*args)
+    raise TraceError(f"numpy.{name} is not supported in a traced logprob_fn (supported: sum, mean, dot, where and the ufuncs "
+                     "listed in aehmc_amd.tracing)")
+
+
+# ------------------------------------------------------------------------------------------------------ tracing
+class _Ctx:
+    def __init__(self):
+        self.params, self._ids, self.nvars = [], {}, 0
+
+    def param(self, a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+        key = a.tobytes()
+        if key not in self._ids:
+            self._ids[key] = len(self.params)
+            self.params.append(a.copy())
+        return self._ids[key]
+
+    def new_var(self):
+        self.nvars += 1
+        return self.nvars - 1
+
+
+class Traced:
+    """The result of tracing: ``source`` (HIP source defining ``aehmc_logp``), ``params`` (the captured arrays, in
+    ``prm[k]`` order), ``elementwise`` (a sum of per-coordinate terms: ``targets.Custom``) or a joint density
+    (``targets.CustomJoint``), and ``dim``."""
+
+    def __init__(self, source, params, elementwise, dim):
+        self.source, self.params, self.elementwise, self.dim = source, params, elementwise, dim
+
+
+class _Gen:
+    def __init__(self, elem_var=None, scalar=False):
+        self.lines, self.ind, self.ntmp = [], 1, 0
+        self.names = {}            # loop variable -> C++ name
+        self.elem_var, self.scalar = elem_var, scalar
+
+    def put(self, s):
+        self.lines.append("  " * self.ind + s)
+
+    def q(self, idx):
+        if self.scalar or (self.elem_var is not None and idx.is_var(self.elem_var)):
+            return "q"
+        return f"q[{idx.code(self.names)}]"
+
+    def ex(self, e):
+        op, a = e.op, e.args
+        if op == "const":
+            return _lit(a[0])
+        if op == "par":
+            return f"prm[{a[0]}][{a[1].code(self.names)}]"
+        if op == "q":
+            return self.q(a[0])
+        if op == "neg":
+            return f"(-{self.ex(a[0])})"
+        if op == "un":
+            return f"{a[0]}({self.ex(a[1])})"
+        if op == "bin":
+            return f"({self.ex(a[1])} {a[0]} {self.ex(a[2])})"
+        if op == "pow":
+            base = self.ex(a[0])
+            return f"pow({base if a[0].t or not e.t else 'T(' + base + ')'}, {self.ex(a[1])})"
+        if op == "cmp":
+            return f"({self.ex(a[1])} {a[0]} {self.ex(a[2])})"
+        if op == "where":
+            c, x, y = self.ex(a[0]), self.ex(a[1]), self.ex(a[2])
+            if e.t:
+                return f"({c} ? T({x}) : T({y}))"
+            return f"({c} ? {x} : {y})"
+        if op == "sum":
+            v, n, body = a
+            acc = f"s{self.ntmp}"
+            self.ntmp += 1
+            iv = f"i{v}"
+            self.names[v] = iv
+            self.put(f"{'T' if e.t else 'double'} {acc} = {'T(0.0)' if e.t else '0.0'};")
+            self.put(f"for (int {iv} = 0; {iv} < {n}; {iv}++) {{")
+            self.ind += 1
+            b = self.ex(body)
+            self.put(f"{acc} += {b};")
+            self.ind -= 1
+            self.put("}")
+            return acc
+        raise AssertionError(op)
+
+
+def _elementwise_var(root, dim, scalar):
+    """The loop variable of a root that is ONE sum over the coordinates of per-coordinate terms (q read at the loop index
+    only, no inner reduction that reads q), else None."""
+    if scalar or root.op != "sum" or root.args[1] != dim:
+        return None
+    v = root.args[0]
+
+    def ok(e):
+        if e.op == "q":
+            return e.args[0].is_var(v)
+        if e.op == "par":
+            return e.args[1].terms in ((), ((v, 1),))
+        if e.op == "sum":
+            return False
+        return all(ok(x) for x in e.args if isinstance(x, S))
+
+    return v if ok(root.args[2]) else None
+
+
+def trace(fn, dim, scalar=False, args=()):
+    """Call ``fn`` once on a proxy of the position (a scalar if ``scalar``, else a vector of ``dim`` entries) and emit
+    the ``aehmc_logp`` template.  ``args``: further constant arguments handed to ``fn`` (numbers / numpy arrays)."""
+    dim = int(dim)
+    ctx = _Ctx()
+    if scalar:
+        if dim != 1:
+            raise ValueError("a scalar position has dim 1")
+        arg = S(ctx, "q", (Idx(0),), True)
+    else:
+        arg = V(ctx, dim, lambda i: S(ctx, "q", (i,), True))
+    out = fn(arg, *[_lift(ctx, a) if isinstance(a, np.ndarray) else a for a in args])
+    if isinstance(out, V):
+        if out.n == 1:
+            out = out.at(0)
+        else:
+            raise TraceError(f"logprob_fn returned a vector of {out.n} entries: it must return a scalar (call .sum() on it?)")
+    if not isinstance(out, S):
+        raise TraceError(f"logprob_fn returned a {type(out).__name__} that does not depend on the position")
+    if out.b:
+        raise TraceError("logprob_fn returned a comparison result")
+    if not out.t:
+        raise TraceError("logprob_fn returned a value that does not depend on the position")
+    def has_sum(e):
+        return e.op == "sum" or any(has_sum(x) for x in e.args if isinstance(x, S))
+
+    if dim == 1 and not scalar and not has_sum(out):  # a vector of one entry used entry by entry: the scalar form
+        scalar = True
+    ev = _elementwise_var(out, dim, scalar)
+    if scalar or ev is not None:
+        g = _Gen(elem_var=ev, scalar=scalar)
+        if ev is not None:
+            g.names[ev] = "i"
+            body = g.ex(out.args[2])
+        else:
+            body = g.ex(out)
+        src = ("template <class T> __device__ T aehmc_logp(T q, long long i, const double *const *prm) {\n"
+               + "\n".join(g.lines) + ("\n" if g.lines else "") + f"  return T({body});\n}}\n")
+        return Traced(src, ctx.params, True, dim)
+    g = _Gen()
+    body = g.ex(out)
+    src = ("template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm) {\n"
+           "  typedef decltype(q[0]) T;\n" + "\n".join(g.lines) + ("\n" if g.lines else "") + f"  return T({body});\n}}\n")
+    return Traced(src, ctx.params, False, dim)

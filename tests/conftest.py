@@ -27,7 +27,7 @@ _FIRST_IN_PARITY = ("test_g1_readme_bit_exact_on_gpu", "test_g2_g3_regression_on
 _FILE_ORDER = ("test_gpu_parity.py", "test_golden_fixtures.py", "test_dense_pin.py", "test_gpu_configs.py",
                "test_gpu_block_dense.py", "test_gpu_pc_dense.py", "test_gpu_fp_contract.py", "test_gpu_statistics.py",
                "test_gpu_building_blocks.py", "test_gpu_adaptation.py", "test_gpu_edges.py", "test_gpu_boundary.py",
-               "test_gpu_custom_target.py", "test_gpu_autodiff.py", "test_gpu_fuzz.py", "test_gpu_bench_contract.py")
+               "test_gpu_custom_target.py", "test_gpu_autodiff.py", "test_gpu_callable.py", "test_gpu_fuzz.py", "test_gpu_bench_contract.py")
 
 
 def _rank(item):

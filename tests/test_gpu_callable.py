@@ -1,0 +1,161 @@
+"""``logprob_fn`` as a Python function of the position -- what the reference takes (README.md:27-36, aehmc/hmc.py:16-40) --
+traced once (aehmc_amd/tracing.py), compiled with hipRTC and differentiated by the engine (csrc/dual.cuh).
+Parity: the README value bit for bit; whole transitions against the numpy restatement (oracle/np_oracle.py) driven by
+THE SAME Python function on plain numpy arrays with central-difference-free analytic gradients; statistics as
+/root/reference/tests/test_hmc.py:190-264 with the model written as a Python function."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import np_oracle as no  # noqa: E402
+
+RTOL = 1e-9
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), device="cuda", dtype=torch.float64)
+
+
+def test_readme_example_with_a_python_logprob_fn_is_bit_exact():
+    """README.md:22-54 (config c1): RandomStream(seed=0), logprob of N(0, 1) written as a Python function, y0 = 0,
+    step size 1e-2, unit inverse mass matrix -> 1.1034719409361107."""
+    from aehmc_amd import RandomStream, nuts
+    logprob_fn = lambda y: -0.5 * y**2 - 0.5 * np.log(2 * np.pi)  # noqa: E731
+    kernel = nuts.new_kernel(RandomStream(seed=0), logprob_fn)
+    state = nuts.new_state(0.0, logprob_fn)
+    assert state.potential_energy.item() == 0.5 * np.log(2 * np.pi) and state.potential_energy_grad.item() == 0.0
+    info, _ = kernel(state, 1e-2, 1.0)
+    assert info.state.position.item() == 1.1034719409361107
+    assert info.num_doublings.item() == 8 and info.n_leapfrog.item() == 136 and not info.is_diverging.item()
+    assert info.acceptance_probability.item() == pytest.approx(0.9999767760191554, rel=1e-12)
+
+
+LOC, SCALE, RHO = np.array([0.0, 3.0]), np.array([1.0, 2.0]), 0.5
+COV = np.diag(SCALE**2)
+COV[0, 1] = COV[1, 0] = RHO * SCALE[0] * SCALE[1]
+PREC = np.linalg.inv(COV)
+PREC = 0.5 * (PREC + PREC.T)
+
+
+def mvn_logprob(y):  # /root/reference/tests/test_hmc.py:170-187 (multivariate_normal_model), up to the constant
+    d = y - LOC
+    return -0.5 * d @ (PREC @ d)
+
+
+def test_hmc_mcse_with_the_model_as_a_python_function():
+    # /root/reference/tests/test_hmc.py:190-264: mu = [0, 3], sigma = [1, 2], rho = .5, eps = 1, L = 30, imm = sigma (sic)
+    from scipy import stats
+    from aehmc_amd import RandomStream, hmc
+    C = 512
+    kernel = hmc.new_kernel(RandomStream(seeds=[10_000 + c for c in range(C)]), mvn_logprob)
+    q0 = np.random.default_rng(0).standard_normal((C, 2))
+    state = hmc.new_state(dev(q0), mvn_logprob)
+    _, info, _, _ = kernel.sample(state, 1.0, SCALE, 30, 300, keep_samples=False)   # burn-in
+    samples, info, acc, div = kernel.sample(info.state._replace(momentum=None), 1.0, SCALE, 30, 400)
+    s = samples.cpu().numpy()  # [400, C, 2]
+    assert not div.any().item()
+
+    def pvalue(delta):  # chains are independent: MCSE from the spread of per-chain means
+        m = delta.mean(axis=0)
+        return stats.norm.sf(np.abs(m.mean(axis=0)) / (m.std(axis=0, ddof=1) / np.sqrt(C)))
+
+    assert np.all(pvalue(s - LOC) > 0.001)
+    assert np.all(pvalue(np.square(s - LOC) - SCALE**2) > 0.001)
+    assert np.all(pvalue(np.prod(s - LOC, axis=2) / np.prod(SCALE) - RHO) > 0.001)
+
+
+class NumpyTarget:
+    """The numpy restatement's target from the SAME Python function (called on plain arrays) and an analytic gradient."""
+
+    def __init__(self, fn, grad):
+        self.fn, self.grad = fn, grad
+
+    def __call__(self, q):
+        q = np.asarray(q, dtype=np.float64)
+        return float(-self.fn(q)), -np.asarray(self.grad(q), dtype=np.float64)
+
+
+R = np.random.default_rng(8)
+NU, SC = 3.0 + 5 * R.random(70), 0.5 + R.random(70)
+
+
+def student_t(q):
+    return (-0.5 * (NU + 1.0) * np.log1p((q / SC) ** 2 / NU)).sum()
+
+
+def student_t_grad(q):
+    z = q / SC
+    return -(NU + 1.0) * z / (NU + z * z) / SC
+
+
+def funnel(q):
+    v, x = q[0], q[1:]
+    return -v * v / 18.0 + (-0.5 * x * x * np.exp(-v) - 0.5 * v).sum()
+
+
+def funnel_grad(q):
+    v, x = q[0], q[1:]
+    g = np.empty_like(q)
+    g[0] = -v / 9.0 + 0.5 * np.sum(x * x) * np.exp(-v) - 0.5 * (len(q) - 1)
+    g[1:] = -x * np.exp(-v)
+    return g
+
+
+def mvn_grad(y):
+    return -(PREC @ (y - LOC))
+
+
+MODELS = {"student_t": (student_t, student_t_grad, 70, "Custom"), "funnel": (funnel, funnel_grad, 10, "CustomJoint"),
+          "funnel100": (funnel, funnel_grad, 100, "CustomJoint"), "mvn": (mvn_logprob, mvn_grad, 2, "CustomJoint")}
+
+
+@pytest.mark.parametrize("model", sorted(MODELS))
+@pytest.mark.parametrize("sampler", ["nuts", "hmc"])
+def test_python_logprob_fn_transitions_match_numpy_restatement(model, sampler):
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    fn, grad, D, cls = MODELS[model]
+    assert type(targets.as_target(fn, D)).__name__ == cls
+    otgt = NumpyTarget(fn, grad)
+    r = np.random.default_rng(len(model))
+    C, n, eps = 4, 3, 0.1
+    q0 = 0.5 * r.normal(size=(C, D))
+    imm = 0.5 + r.random(D)
+    seeds = [300 + c for c in range(C)]
+    mod, omk, extra = (nuts, no.nuts_kernel, ()) if sampler == "nuts" else (hmc, no.hmc_kernel, (7,))
+    kw = dict(max_num_expansions=5) if sampler == "nuts" else {}
+    kern = mod.new_kernel(RandomStream(seeds=seeds), fn, **kw)
+    state = mod.new_state(dev(q0), fn)
+    okern = [omk(no.RandomStream(sd), otgt, **kw) for sd in seeds]
+    ostate = [no.new_state(q0[c].copy(), otgt) for c in range(C)]
+    for _ in range(n):
+        info, _ = kern(state, eps, imm, *extra)
+        state = info.state._replace(momentum=None)
+        for c in range(C):
+            o = okern[c](ostate[c], eps, imm, *extra)
+            ostate[c] = o.state._replace(momentum=None)
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-11)
+            np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL, atol=1e-11)
+            np.testing.assert_allclose(info.state.potential_energy_grad[c].cpu().numpy(), o.state.potential_energy_grad,
+                                       rtol=RTOL, atol=1e-10)
+            assert bool(info.is_diverging[c]) == bool(o.is_diverging)
+            if sampler == "nuts":
+                assert info.n_leapfrog[c].item() == o.n_leapfrog and info.num_doublings[c].item() == o.num_doublings
+                assert bool(info.is_turning[c]) == bool(o.is_turning)
+
+
+def test_python_logprob_fn_under_window_adaptation_and_sample():
+    from aehmc_amd import RandomStream, nuts, window_adaptation
+    C, D = 64, 10
+    kernel = nuts.new_kernel(RandomStream(seeds=range(C)), funnel, max_num_expansions=6)
+    state = nuts.new_state(dev(0.3 * np.random.default_rng(1).normal(size=(C, D))), funnel)
+    state, (step_size, imm), _ = window_adaptation.run(kernel, state, num_steps=80)
+    samples, info, acc, div = kernel.sample(state, step_size, imm, 10)
+    assert samples.shape == (10, C, D) and torch.isfinite(samples).all()
+
+
+def test_untraceable_python_logprob_fn_raises_typeerror_before_anything_is_compiled():
+    from aehmc_amd import nuts
+    with pytest.raises(TypeError, match="control flow cannot be traced"):
+        nuts.new_state(dev(np.zeros((3, 4))), lambda q: q.sum() if q[0] > 0 else -q.sum())

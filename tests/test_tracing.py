@@ -1,0 +1,146 @@
+"""aehmc_amd/tracing.py: a Python ``logprob_fn`` (reference: README.md:27-36, aehmc/hmc.py:16-40) traced into the
+``aehmc_logp`` template.  The emitted source is compiled as plain C++ against csrc/dual.cuh (the way tests/test_dual.py
+does) and evaluated with double and with Dual: value == the Python function on plain numpy arrays, gradient == central
+differences of it.  (The GPU side -- the same sources through hipRTC, whole transitions against the numpy
+restatement -- is tests/test_gpu_callable.py.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from aehmc_amd import targets, tracing
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = np.random.default_rng(5)
+NU, SC = 3.0 + 5 * R.random(7), 0.5 + R.random(7)
+LOC = np.array([0.0, 3.0])
+PREC = np.linalg.inv(np.array([[1.0, 1.0], [1.0, 4.0]]))
+A6 = R.normal(size=(4, 6))
+Y4 = R.normal(size=4)
+
+
+def student_t(q):
+    return (-0.5 * (NU + 1.0) * np.log1p((q / SC) ** 2 / NU)).sum()
+
+
+def mvn(y):
+    return -0.5 * (y - LOC) @ (PREC @ (y - LOC))
+
+
+def funnel(q):
+    v, x = q[0], q[1:]
+    return -v * v / 18.0 + (-0.5 * x * x * np.exp(-v) - 0.5 * v).sum()
+
+
+def regression(q):  # a small linear model with a matrix captured from the closure, sigma = exp(q[-1])
+    w, ls = q[:-1], q[-1]
+    r = Y4 - A6[:, :5] @ w
+    return -0.5 * np.sum(r * r) * np.exp(-2.0 * ls) - 4 * ls - 0.5 * np.dot(w, w) - 0.5 * ls**2
+
+
+def kitchen_sink(q):
+    a = np.tanh(q[0]) + np.sin(q[1]) * np.cos(q[2]) + np.sqrt(1.0 + np.square(q[3])) + np.expm1(-np.abs(q[4]))
+    b = tracing.where(q[0] > 0.1, q[0] ** 3, -q[0]) + np.maximum(q[1], q[2]) + np.minimum(q[3], 0.3) + np.logaddexp(q[4], q[0])
+    c = tracing.softplus(q[1]) + 2.0 ** q[2] + np.power(1.5 + q[3] ** 2, 0.3) + (1.0 / (2.0 + q[4] ** 2)) + np.mean(q) + sum(q[1:3])
+    return a + b - c + (q @ q) * 0.1
+
+
+CASES = {"student_t": (student_t, 7, True), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
+         "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
+
+HARNESS = r"""
+#include <cstdio>
+#include <cmath>
+#define __device__
+#include "dual.cuh"
+using aehmc::Dual;
+%(source)s
+template <class T> struct Row {
+  const double *q; int seed, D;
+  T operator[](int i) const;
+  int size() const { return D; }
+};
+template <> double Row<double>::operator[](int i) const { return q[i]; }
+template <> Dual Row<Dual>::operator[](int i) const { return Dual(q[i], i == seed ? 1.0 : 0.0); }
+%(params)s
+int main() {
+  const int D = %(D)d;
+  const double q[] = {%(q)s};
+#if %(elem)d
+  double v = 0.0;
+  for (int i = 0; i < D; i++) v += aehmc_logp(q[i], (long long)i, prm);
+  std::printf("%%.17g\n", v);
+  for (int i = 0; i < D; i++) std::printf("%%.17g\n", aehmc_logp(Dual(q[i], 1.0), (long long)i, prm).d);
+#else
+  Row<double> r{q, 0, D};
+  std::printf("%%.17g\n", (double)aehmc_logp(r, prm));
+  for (int i = 0; i < D; i++) { Row<Dual> rd{q, i, D}; std::printf("%%.17g\n", aehmc_logp(rd, prm).d); }
+#endif
+  return 0;
+}
+"""
+
+
+def run_cpp(tr, q, tmp_path, name):
+    params = "".join(f"static const double prm{k}[] = {{{', '.join(repr(float(x)) for x in p)}}};\n" for k, p in enumerate(tr.params))
+    params += "static const double *const prm[] = {" + ", ".join([f"prm{k}" for k in range(len(tr.params))] + ["nullptr"]) + "};\n"
+    src = tmp_path / f"{name}.cpp"
+    src.write_text(HARNESS % dict(source=tr.source, params=params, D=len(q), q=", ".join(repr(float(x)) for x in q), elem=int(tr.elementwise)))
+    exe = tmp_path / name
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "aehmc_amd", "csrc"), "-o", str(exe), str(src)])
+    out = [float(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    return out[0], np.array(out[1:])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_traced_density_and_gradient_match_the_python_function(name, tmp_path):
+    fn, D, elementwise = CASES[name]
+    tr = tracing.trace(fn, D)
+    assert tr.elementwise == elementwise and tr.dim == D
+    for trial in range(2):
+        q = 0.7 * np.random.default_rng(trial).normal(size=D)
+        v, g = run_cpp(tr, q, tmp_path, f"{name}{trial}")
+        assert v == pytest.approx(float(fn(q)), rel=1e-13, abs=1e-13)
+        h = 1e-6
+        fd = np.array([(fn(q + h * np.eye(D)[i]) - fn(q - h * np.eye(D)[i])) / (2 * h) for i in range(D)])
+        np.testing.assert_allclose(g, fd, rtol=2e-7, atol=2e-8)
+
+
+def test_readme_function_is_the_builtin_standard_normal_expression():
+    """README.md:27-36: logprob of N(0, 1) at a scalar position.  The emitted expression is, operation for operation,
+    the built-in StdNormal target's (engine.cuh: u = 0.5 (q q) + log sqrt(2 pi), g = q), so the README value is
+    reproduced bit for bit on the GPU (tests/test_gpu_callable.py)."""
+    tr = tracing.trace(lambda y: -0.5 * y**2 - 0.5 * np.log(2 * np.pi), 1, scalar=True)
+    assert tr.elementwise and tr.params == []
+    assert "return T(((-0.5 * square(q)) - 0.9189385332046727));" in tr.source
+    # the same function handed a vector of one entry (a [C, 1] position) takes the same form
+    assert tracing.trace(lambda y: -0.5 * y**2 - 0.5 * np.log(2 * np.pi), 1).source == tr.source
+
+
+def test_targets_from_callable_picks_the_target_class():
+    t1 = targets.from_callable(student_t, 7)
+    assert isinstance(t1, targets.Custom) and not t1.hand_gradient and len(t1.param_list) == 3 and t1.dim == 7
+    t2 = targets.from_callable(mvn, 2)
+    assert isinstance(t2, targets.CustomJoint) and t2.dim == 2 and "aehmc_logp" in t2.source
+    assert targets.as_target(t2, 2) is t2
+    assert targets.as_target(mvn, 2) is targets.as_target(mvn, 2)  # traced once per function and shape
+    with pytest.raises(TypeError, match="Target or a Python function"):
+        targets.as_target(3.0, 2)
+
+
+@pytest.mark.parametrize("fn, match", [
+    (lambda q: q.sum() if q[0] > 0 else 0.0, "control flow cannot be traced"),
+    (lambda q: __import__("math").exp(q[0]), "use the numpy functions"),
+    (lambda q: np.arctan(q).sum(), "numpy.arctan is not supported"),
+    (lambda q: q * 2.0, "must return a scalar"),
+    (lambda q: 1.0, "does not depend on the position"),
+    (lambda q: q[np.array([0, 1])].sum(), "only integers and slices"),
+    (lambda q: (q > 0).sum(), "comparison"),
+    (lambda q: np.cumsum(q)[-1], "numpy.cumsum is not supported"),
+    (lambda q: (q[:2] + q).sum(), "do not broadcast"),
+    (lambda q: (np.ones((2, 2, 2)) * q[0]).sum(), "dimensions are not supported"),
+])
+def test_untraceable_operations_raise_typeerror_at_trace_time(fn, match):
+    with pytest.raises(TypeError, match=match):
+        tracing.trace(fn, 3)
