@@ -747,7 +747,7 @@ AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_nuts_fused(EngineArgs a)
 // too), one rounding per product and per sum.  Literal dense mode (metrics.py:71: imm p_half and imm p' are formed,
 // 3 products per leapfrog).
 constexpr int FUSED_DENSE_MAX_D = 64;
-constexpr int JOINT_ROWS_MAX_D = 2048;  // joint (non-separable) user targets on the lock-step path: four wavefronts' rows in 64 KB of LDS (k_target_joint_rows)
+constexpr int JOINT_ROWS_MAX_D = 2048;  // joint (non-separable) user targets on the lock-step path: four wavefronts' position and gradient rows in 128 KB of LDS (k_target_joint_rows)
 constexpr int FUSED_DENSE_BLOCK = 512;  // eight chains per workgroup share the matrices
 // y[i] = sum_k M[i][k] x[k] for i < D; MT = M transposed in LDS (MT[k * D + i] = M[i][k]); x, y rows in global memory,
 // element i read and written by lane i only
@@ -1131,9 +1131,26 @@ __global__ __launch_bounds__(256) void k_new_state_joint(EngineArgs a) {  // hmc
 // ceil(D / 64) times, lane l carrying the derivative with respect to coordinate l + 64 k in pass k (dual.cuh: JointRow):
 // O(D^2 / 64) density terms per gradient and wavefront, every lane ends each pass with the same value bits.
 // U -> ctl[c].U_cur (leapfrog; finished chains are skipped) or U[c] (new_state).
-// (device part: `qr` = this wavefront's D doubles of LDS; returns U on every lane)
+// A density that comes with its reverse-mode program (AEHMC_JOINT_GRAD: aehmc_logp_grad, emitted by aehmc_amd/tracing.py for
+// a traced Python logprob_fn -- round 6; the reference differentiates in reverse mode too, aesara.grad, hmc.py:33-34) takes
+// ONE sweep whatever D: the wavefront runs the forward and the adjoint program together, loops over the coordinates
+// distributed over its lanes, the gradient accumulated in a second LDS row.
+// (device part: `qr` = this wavefront's 2 D doubles of LDS -- the position row and the gradient row; returns U on every lane)
 __device__ inline double joint_rows_eval(const EngineArgs &a, const double *q, double *g, double *qr, int lane) {
   const int D = (int)a.D;
+#ifdef AEHMC_JOINT_GRAD
+  double *const gr = qr + D;
+  for (int i = lane; i < D; i += 64) {
+    qr[i] = q[i];
+    gr[i] = 0.0;
+  }
+  __threadfence_block();  // (the rows are read and updated through other lanes' addresses)
+  const double lp = aehmc_logp_grad(qr, gr, lane, a.cparams);
+  __threadfence_block();
+  for (int i = lane; i < D; i += 64) g[i] = -gr[i];
+  __threadfence_block();  // (the stage that follows reads g through other lanes' addresses)
+  return -lp;
+#else
   for (int i = lane; i < D; i += 64) qr[i] = q[i];
   __threadfence_block();  // (the row is read back through other lanes' addresses)
   double Uv = 0.0;
@@ -1145,6 +1162,7 @@ __device__ inline double joint_rows_eval(const EngineArgs &a, const double *q, d
   }
   __threadfence_block();  // (the stage that follows reads g through other lanes' addresses)
   return Uv;
+#endif
 }
 __global__ __launch_bounds__(256) void k_target_joint_rows(EngineArgs a, const double *q, double *g, double *U, int to_ctl,
                                                            const int *row_idx, const int *n_rows) {
@@ -1160,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_target_joint_rows(EngineArgs a, const d
   }
   if (to_ctl && a.ctl[c].done) return;
   const size_t row = (size_t)c * a.D;
-  const double Uv = joint_rows_eval(a, q + row, g + row, joint_rows + (size_t)wave * a.D, lane);
+  const double Uv = joint_rows_eval(a, q + row, g + row, joint_rows + (size_t)wave * 2 * a.D, lane);
   if (lane == 0) {
     if (to_ctl) a.ctl[c].U_cur = Uv;
     else U[c] = Uv;
@@ -1174,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_nuts_joint_rows(EngineArgs a, NutsSampl
   extern __shared__ __attribute__((aligned(16))) double joint_rows[];
   AEHMC_CHAIN_OF_WAVE();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  double *const qr = joint_rows + (size_t)wave * a.D;
+  double *const qr = joint_rows + (size_t)wave * 2 * a.D;
   const size_t row = (size_t)c * a.D;
   ChainRng rng = rng_load(a, c);
   ChainCtl ct = {};
@@ -1211,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_hmc_joint_rows(EngineArgs a, long long 
   extern __shared__ __attribute__((aligned(16))) double joint_rows[];
   AEHMC_CHAIN_OF_WAVE();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  double *const qr = joint_rows + (size_t)wave * a.D;
+  double *const qr = joint_rows + (size_t)wave * 2 * a.D;
   const size_t row = (size_t)c * a.D;
   Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4), g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
   double U_state = a.U[c];

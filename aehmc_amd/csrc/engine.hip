@@ -1099,7 +1099,7 @@ static int launch_glm(aehmc_ctx *ctx, const EngineArgs &a, const double *q, doub
 // joint user-defined target on the lock-step path: U and dU/dq of the (live) chains from their position rows
 static int launch_joint_rows(aehmc_ctx *ctx, const EngineArgs &a, const double *q, double *g, double *U, int to_ctl,
                              hipStream_t st, const int *ri, const int *nr) {
-  return rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[1], chain_grid(a.C), dim3(256), (size_t)4 * a.D * sizeof(double), st, a, q, g, U,
+  return rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[1], chain_grid(a.C), dim3(256), (size_t)8 * a.D * sizeof(double), st, a, q, g, U,
                     to_ctl, ri, nr);
 }
 
@@ -1291,7 +1291,11 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   // -- up to D = 192: beyond, the density's O(D^2 / 64) terms are the whole cost and a wavefront that carries its chain
   // through a deep tree holds its SIMD slot while finished chains idle, where the lock-step path compacts the live
   // chains (funnel, 4096 chains: D = 100 3.1 -> 4.9e7 leapfrog/s in one launch, D = 256 1.41 -> 1.35e7: profiles/r5/INDEX.md)
-  if (want_resident && tkind == AEHMC_T_JOINT && nd < 2 && D <= 192) return NUTS_PATH_JOINT_ROWS;
+  // (a density with a reverse-mode program -- AEHMC_JOINT_GRAD, a traced Python logprob_fn -- costs O(D / 64) per gradient:
+  //  one launch whatever D)
+  if (want_resident && tkind == AEHMC_T_JOINT && nd < 2 &&
+      (D <= 192 || ctx->custom_src.find("#define AEHMC_JOINT_GRAD") != std::string::npos))
+    return NUTS_PATH_JOINT_ROWS;
   if (want_resident && nuts_resident_dense_supported(tkind, nd, D))
     return NUTS_PATH_FUSED_DENSE;  // (per-chain dense metrics included: each wavefront reads its own matrices)
   // mid-size dense problems (shared dense metric, 64 < D <= 512, linear dense mode): a workgroup per 16 chains runs
@@ -1456,7 +1460,7 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     }
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (int rc = rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[2], chain_grid(C), dim3(256), (size_t)4 * a.D * sizeof(double), st, a, m))
+    if (int rc = rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[2], chain_grid(C), dim3(256), (size_t)8 * a.D * sizeof(double), st, a, m))
       return rc;
     return prof_end(ctx, st, p);
   }
@@ -1825,7 +1829,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   if (ctx->opt_fused_hmc && tjoint && a.met_ndim < 2) {
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (int rc = rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[3], chain_grid(C), dim3(256), (size_t)4 * D * sizeof(double), st, a,
+    if (int rc = rtc_launch(ctx, "jbase", RTC_JBASE, RTC_JBASE[3], chain_grid(C), dim3(256), (size_t)8 * D * sizeof(double), st, a,
                             (long long)L, (long long)T, samples, acc_hist, (int *)div_hist))
       return rc;
     if (int rc = prof_end(ctx, st, p)) return rc;

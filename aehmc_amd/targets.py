@@ -167,17 +167,21 @@ class CustomJoint(Target):
     Up to 64 coordinates NUTS and HMC run in single launches (any number of transitions) with a scalar, diagonal or
     dense metric, shared or per chain, and under ``window_adaptation``.  Above 64 (round 5) the target runs on the
     lock-step path: the chain's row waits in LDS and the wavefront evaluates the density ceil(dim / 64) times per
-    gradient, lane l seeding coordinate l + 64 k in pass k -- O(dim^2 / 64) density terms per leapfrog and chain."""
+    gradient, lane l seeding coordinate l + 64 k in pass k -- O(dim^2 / 64) density terms per leapfrog and chain.
+    A density traced from a Python function (``from_callable``) brings its reverse-mode program (``grad_source``):
+    one sweep per gradient whatever the dimension, its loops spread over the wavefront's lanes."""
 
     kind = T_JOINT
 
-    def __init__(self, source: str, dim: int, params=()):
+    def __init__(self, source: str, dim: int, params=(), grad_source=None):
         if "aehmc_logp" not in source:
             raise ValueError("CustomJoint: the source must define aehmc_logp(const V &q, const double *const *prm)")
         if not 1 <= int(dim) <= 2048:
             raise ValueError("CustomJoint: 1 <= dim <= 2048")
         self.user_source = str(source)
-        self.source = _DUAL + self.user_source
+        # grad_source: the density's reverse-mode program (aehmc_logp_grad + AEHMC_JOINT_GRAD), emitted by
+        # aehmc_amd/tracing.py for a traced Python function: above 64 coordinates ONE sweep per gradient
+        self.source = _DUAL + self.user_source + (grad_source or "")
         self.param_list, self.dim = list(params), int(dim)
         self.hand_gradient, self.gradient_checked = False, True
 
@@ -249,7 +253,8 @@ def from_callable(fn, dim, scalar=False, args=()):
     function instead of a Target (``as_target``)."""
     from . import tracing
     tr = tracing.trace(fn, dim, scalar=scalar, args=args)
-    tgt = Custom(tr.source, params=tr.params, dim=tr.dim) if tr.elementwise else CustomJoint(tr.source, tr.dim, params=tr.params)
+    tgt = (Custom(tr.source, params=tr.params, dim=tr.dim) if tr.elementwise
+           else CustomJoint(tr.source, tr.dim, params=tr.params, grad_source=tr.grad_source))
     tgt.traced_from = fn
     return tgt
 

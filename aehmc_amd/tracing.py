@@ -179,6 +179,18 @@ def _lift(ctx, x):
         return x
     if isinstance(x, (numbers.Real, np.floating, np.integer, np.bool_)):
         return _const(ctx, x)
+    if isinstance(x, (list, tuple)) or (isinstance(x, np.ndarray) and x.dtype == object and x.ndim == 1):
+        items = [_lift(ctx, y) for y in x]  # a Python list of traced scalars / numbers: a vector with static entries
+        if any(not isinstance(y, S) for y in items):
+            raise TraceError("a list used as a vector must hold scalars")
+        if all(y.op == "const" for y in items):
+            return _lift(ctx, np.array([y.args[0] for y in items]))
+
+        def at(i, items=items):
+            if i.terms:
+                raise TraceError("internal: a vector built from a Python list was indexed by a loop variable")
+            return items[i.c]
+        return V(ctx, len(items), at, unroll=True)
     a = np.asarray(x)
     if a.dtype == object or not (np.issubdtype(a.dtype, np.number) or a.dtype == bool):
         raise TraceError(f"cannot use a {type(x).__name__} in a traced logprob_fn (numbers, numpy arrays and traced values only)")
@@ -195,7 +207,7 @@ def _lift(ctx, x):
 def _unary(ctx, name, x):
     x = _lift(ctx, x)
     if isinstance(x, V):
-        return V(ctx, x.n, lambda i: _unary(ctx, name, x.at(i)))
+        return V(ctx, x.n, lambda i: _unary(ctx, name, x.at(i)), x.unroll)
     if isinstance(x, M):
         raise TraceError(f"{name} of a matrix is not supported")
     if x.b:
@@ -247,7 +259,7 @@ def where(cond, a, b):
         for x in (cond, a, b):
             if isinstance(x, V) and x.n != n:
                 raise TraceError(f"where: vectors of lengths {n} and {x.n}")
-        return V(ctx, n, lambda i: where(at(cond, i), at(a, i), at(b, i)))
+        return V(ctx, n, lambda i: where(at(cond, i), at(a, i), at(b, i)), any(isinstance(x, V) and x.unroll for x in (cond, a, b)))
     if cond.op == "const":
         return a if cond.args[0] else b
     if not cond.b:
@@ -267,10 +279,12 @@ class V:
     """A traced vector of static length: a function from an index to a traced scalar (nothing is materialised)."""
 
     __array_priority__ = 1000
-    __slots__ = ("ctx", "n", "_at")
+    __slots__ = ("ctx", "n", "_at", "unroll")
 
-    def __init__(self, ctx, n, at):
-        self.ctx, self.n, self._at = ctx, int(n), at
+    def __init__(self, ctx, n, at, unroll=False):
+        # unroll: built from a Python list of traced scalars (np.array([a, b, c])): its entries exist at static indices
+        # only, so reductions over it are written out term by term instead of as a loop
+        self.ctx, self.n, self._at, self.unroll = ctx, int(n), at, bool(unroll)
 
     def at(self, i):
         return self._at(i if isinstance(i, Idx) else Idx(i))
@@ -289,7 +303,8 @@ class V:
             else:
                 raise TraceError(f"operands of lengths {a.n} and {b.n} do not broadcast")
             n = a.n if isinstance(a, V) else b.n
-        return V(ctx, n, lambda i: f(a.at(i) if isinstance(a, V) else a, b.at(i) if isinstance(b, V) else b))
+        un = (isinstance(a, V) and a.unroll) or (isinstance(b, V) and b.unroll)
+        return V(ctx, n, lambda i: f(a.at(i) if isinstance(a, V) else a, b.at(i) if isinstance(b, V) else b), un)
 
     def _bin(self, op, a, b):
         return V._ew2(self.ctx, lambda x, y: x._bin(op, x, y), a, b)
@@ -302,7 +317,7 @@ class V:
     def __rmul__(self, o): return self._bin("*", o, self)
     def __truediv__(self, o): return self._bin("/", self, o)
     def __rtruediv__(self, o): return self._bin("/", o, self)
-    def __neg__(self): return V(self.ctx, self.n, lambda i: -self.at(i))
+    def __neg__(self): return V(self.ctx, self.n, lambda i: -self.at(i), self.unroll)
     def __pos__(self): return self
     def __abs__(self): return _unary(self.ctx, "fabs", self)
     def __pow__(self, o): return _pow(self.ctx, self, o)
@@ -347,7 +362,7 @@ class V:
         if isinstance(k, slice):
             start, stop, step = k.indices(self.n)
             m = len(range(start, stop, step))
-            return V(self.ctx, m, lambda i: self.at(i * step + start))
+            return V(self.ctx, m, lambda i: self.at(i * step + start), self.unroll)
         if k is Ellipsis:
             return self
         raise TraceError(f"indexing a traced vector with {type(k).__name__}: only integers and slices with static bounds are supported")
@@ -355,6 +370,14 @@ class V:
     def sum(self, axis=None):
         if self.n == 0:
             return _const(self.ctx, 0.0)
+        if self.unroll:
+            if self.n > 64:
+                raise TraceError(f"a reduction over a Python list of {self.n} traced scalars: build long vectors from the position by "
+                                 "slicing and arithmetic instead")
+            out = self.at(0)
+            for k in range(1, self.n):
+                out = out + self.at(k)
+            return out
         v = self.ctx.new_var()
         body = self.at(Idx.var(v))
         if body.b:
@@ -403,13 +426,13 @@ class M:
         if v.n != self.cols:
             raise TraceError(f"matrix [{self.rows}, {self.cols}] @ vector of {v.n}")
         ctx, k, m = self.ctx, self.k, self.cols
-        return V(ctx, self.rows, lambda i: V(ctx, m, lambda j: S(ctx, "par", (k, i * m + j), False) * v.at(j)).sum())
+        return V(ctx, self.rows, lambda i: V(ctx, m, lambda j: S(ctx, "par", (k, i * m + j), False) * v.at(j), v.unroll).sum())
 
     def rmatvec(self, v):
         if v.n != self.rows:
             raise TraceError(f"vector of {v.n} @ matrix [{self.rows}, {self.cols}]")
         ctx, k, m = self.ctx, self.k, self.cols
-        return V(ctx, self.cols, lambda j: V(ctx, self.rows, lambda i: v.at(i) * S(ctx, "par", (k, i * m + j), False)).sum())
+        return V(ctx, self.cols, lambda j: V(ctx, self.rows, lambda i: v.at(i) * S(ctx, "par", (k, i * m + j), False), v.unroll).sum())
 
 
 def _ufunc(ctx, ufunc, method, inputs, kw):
@@ -570,6 +593,289 @@ def _elementwise_var(root, dim, scalar):
     return v if ok(root.args[2]) else None
 
 
+# ------------------------------------------------------------------------------------------------------ reverse mode
+# The gradient of a joint density in ONE sweep (the reference differentiates in reverse mode: aesara.grad,
+# aehmc/hmc.py:33-34, integrators.py:61-65 -- one sweep whatever the dimension).  The recorded expression is a tree whose
+# only repetition is its `sum` nodes, so the adjoint program is written down directly: a forward sweep that names every
+# intermediate value, then the tree walked from the root with the adjoint of each node; a sum is a loop in the forward
+# sweep and a loop again in the backward sweep (its body's values are recomputed there).  The chain's WAVEFRONT runs it:
+#   * sub-expressions of a loop body that do not depend on the loop index (exp(-v) in a funnel) are hoisted -- computed
+#     once before the loop, their adjoint collected in an accumulator during the backward loop;
+#   * a loop at the outermost level whose body reads the position only at indices a * i + c (a != 0) is DISTRIBUTED over
+#     the 64 lanes (i = lane, lane + 64, ...): partial sums and the accumulators of hoisted values are reduced across the
+#     wavefront behind the loop (a xor butterfly: every lane ends with the same bits), the gradient entries written by
+#     the lane that owns the iteration -- O(dim / 64) per gradient;
+#   * everything else runs on all lanes alike (same values), lane 0 adding to the gradient row.
+_UN_BWD = {"exp": "{a} * {v}", "log": "{a} / {x}", "log1p": "{a} / (1.0 + {x})", "expm1": "{a} * exp({x})",
+           "sqrt": "0.5 * {a} / {v}", "sin": "{a} * cos({x})", "cos": "-({a} * sin({x}))", "tanh": "{a} * (1.0 - {v} * {v})",
+           "fabs": "({x} < 0 ? -{a} : {a})", "erf": "{a} * 1.1283791670955126 * exp(-{x} * {x})",
+           "softplus": "{a} / (1.0 + exp(-{x}))", "square": "2.0 * {x} * {a}"}
+
+
+def _free_vars(e):
+    """loop variables an expression reads (those of sums inside it are bound there)"""
+    if e.op in ("q",):
+        return frozenset(v for v, _ in e.args[0].terms)
+    if e.op == "par":
+        return frozenset(v for v, _ in e.args[1].terms)
+    if e.op == "sum":
+        inner = _free_vars(e.args[2]) - {e.args[0]}
+        for _, x in (e.args[3] if len(e.args) > 3 else ()):
+            inner |= _free_vars(x)
+        return inner
+    out = frozenset()
+    for x in e.args:
+        if isinstance(x, S):
+            out |= _free_vars(x)
+    return out
+
+
+def _hoist(e, counter):
+    """The tree with, in every sum, the position-dependent sub-expressions that do not read its loop variable replaced by
+    `ref` nodes; the sum node gains a fourth argument: the list of (k, hoisted expression)."""
+    if e.op == "sum":
+        v, n, body = e.args[:3]
+        lets = []
+
+        def go(x):
+            if not isinstance(x, S) or not x.t:
+                return x
+            if x.op != "ref" and v not in _free_vars(x):
+                k = counter[0]
+                counter[0] += 1
+                lets.append((k, _hoist(x, counter)))
+                return S(x.ctx, "ref", (k,), True)
+            if x.op in ("q", "ref"):
+                return x
+            if x.op == "sum":
+                return _hoist(x, counter)
+            return S(x.ctx, x.op, tuple(go(y) for y in x.args), x.t, x.b)
+
+        return S(e.ctx, "sum", (v, n, go(body), lets), e.t)
+    if e.op in ("const", "par", "q", "ref"):
+        return e
+    return S(e.ctx, e.op, tuple(_hoist(x, counter) if isinstance(x, S) else x for x in e.args), e.t, e.b)
+
+
+def _distributable(e):
+    """a sum whose body reads (and so writes the gradient of) the position at indices a * i + c only, a != 0"""
+    v = e.args[0]
+
+    def ok(x):
+        if x.op == "q":
+            t = x.args[0].terms
+            return len(t) == 1 and t[0][0] == v and t[0][1] != 0
+        if x.op == "sum":
+            return ok(x.args[2])  # (what it hoisted is position-dependent and invariant in ITS variable: checked where it is bound... )
+        return all(ok(y) for y in x.args if isinstance(y, S))
+
+    def lets_ok(x):  # hoisted expressions of inner sums live inside this loop's body: they must obey the same rule
+        if x.op == "sum":
+            return all(ok(h) and lets_ok(h) for _, h in x.args[3]) and lets_ok(x.args[2])
+        return all(lets_ok(y) for y in x.args if isinstance(y, S))
+
+    return ok(e.args[2]) and lets_ok(e.args[2])
+
+
+class _RevGen:
+    def __init__(self):
+        self.lines, self.ind, self.n = [], 1, 0
+        self.names = {}  # loop variable -> C++ name
+        self.depth = 0   # loop nesting
+
+    def put(self, s):
+        self.lines.append("  " * self.ind + s)
+
+    def tmp(self, prefix="t"):
+        self.n += 1
+        return f"{prefix}{self.n}"
+
+    def let(self, expr, prefix="t"):
+        name = self.tmp(prefix)
+        self.put(f"const double {name} = {expr};")
+        return name
+
+    # ---- forward: the value of e as a C++ expression; every position-dependent inner node gets a name in env
+    def fwd(self, e, env):
+        op, a = e.op, e.args
+        if op == "const":
+            return _lit(a[0])
+        if op == "par":
+            return f"prm[{a[0]}][{a[1].code(self.names)}]"
+        if op == "q":
+            return f"q[{a[0].code(self.names)}]"
+        if op == "ref":
+            return env[("let", a[0])]
+        if not e.t and op != "sum":  # parameters and constants only: inlined
+            g = _Gen()
+            g.names = self.names
+            return g.ex(e)
+        if op == "neg":
+            r = f"(-{self.fwd(a[0], env)})"
+        elif op == "un":
+            r = f"{'aehmc_sq' if a[0] == 'square' else ('aehmc_softplus' if a[0] == 'softplus' else a[0])}({self.fwd(a[1], env)})"
+        elif op == "bin":
+            r = f"({self.fwd(a[1], env)} {a[0]} {self.fwd(a[2], env)})"
+        elif op == "pow":
+            r = f"pow({self.fwd(a[0], env)}, {self.fwd(a[1], env)})"
+        elif op == "cmp":
+            return f"({self.fwd(a[1], env)} {a[0]} {self.fwd(a[2], env)})"
+        elif op == "where":
+            c, x, y = self.fwd(a[0], env), self.fwd(a[1], env), self.fwd(a[2], env)
+            r = f"({c} ? {x} : {y})"
+        elif op == "sum":
+            return self.fwd_sum(e, env)
+        else:
+            raise AssertionError(op)
+        name = self.let(r)
+        env[id(e)] = name
+        return name
+
+    def loop_head(self, e, dist):
+        v, n = e.args[0], e.args[1]
+        iv = f"i{v}"
+        self.names[v] = iv
+        return f"for (int {iv} = {'lane' if dist else '0'}; {iv} < {n}; {iv} {'+= AEHMC_LANES' if dist else '++'}) {{"
+
+    def fwd_sum(self, e, env):
+        v, n, body, lets = e.args
+        dist = self.depth == 0 and _distributable(e)
+        env[("dist", id(e))] = dist
+        for k, x in lets:
+            env[("let", k)] = self.fwd(x, env)
+        acc = self.tmp("s")
+        self.put(f"double {acc} = 0.0;")
+        self.put(self.loop_head(e, dist))
+        self.ind += 1
+        self.depth += 1
+        self.put(f"{acc} += {self.fwd(body, dict(env))};")
+        self.depth -= 1
+        self.ind -= 1
+        self.put("}")
+        if dist:
+            self.put(f"{acc} = AEHMC_WSUM({acc});")
+        env[id(e)] = acc
+        return acc
+
+    def val(self, e, env):
+        """the forward value of a child as it was named (or its inlined expression)"""
+        if e.op == "ref":
+            return env[("let", e.args[0])]
+        if id(e) in env:
+            return env[id(e)]
+        return self.fwd(e, env)  # (leaves and parameter-only expressions: no statements)
+
+    # ---- backward: propagate the adjoint `adj` (a name or a literal) of e into the position
+    def bwd(self, e, adj, env):
+        if not e.t:
+            return
+        op, a = e.op, e.args
+        if op == "q":
+            tgt = f"g[{a[0].code(self.names)}]"
+            self.put(f"{tgt} += {adj};" if self.depth > 0 and self.lane_owned else f"if (lane == 0) {tgt} += {adj};")
+        elif op == "ref":
+            self.put(f"ah{a[0]} += {adj};")
+        elif op == "neg":
+            self.bwd(a[0], self.let(f"-{adj}", "a"), env)
+        elif op == "un":
+            x = a[1]
+            expr = _UN_BWD[a[0]].format(a=adj, v=env[id(e)], x=self.val(x, env))
+            self.bwd(x, self.let(expr, "a"), env)
+        elif op == "bin":
+            o, x, y = a
+            if o == "+":
+                self.bwd(x, adj, env)
+                self.bwd(y, adj, env)
+            elif o == "-":
+                self.bwd(x, adj, env)
+                if y.t:
+                    self.bwd(y, self.let(f"-{adj}", "a"), env)
+            elif o == "*":
+                if x.t:
+                    self.bwd(x, self.let(f"{adj} * {self.val(y, env)}", "a"), env)
+                if y.t:
+                    self.bwd(y, self.let(f"{adj} * {self.val(x, env)}", "a"), env)
+            else:
+                if x.t:
+                    self.bwd(x, self.let(f"{adj} / {self.val(y, env)}", "a"), env)
+                if y.t:
+                    self.bwd(y, self.let(f"-({adj} * {env[id(e)]} / {self.val(y, env)})", "a"), env)
+        elif op == "pow":
+            x, y = a
+            if x.t:
+                self.bwd(x, self.let(f"{adj} * {self.val(y, env)} * pow({self.val(x, env)}, {self.val(y, env)} - 1.0)", "a"), env)
+            if y.t:
+                self.bwd(y, self.let(f"{adj} * {env[id(e)]} * log({self.val(x, env)})", "a"), env)
+        elif op == "where":
+            c, x, y = a
+            self.put(f"if ({self.fwd(c, env)}) {{")
+            self.ind += 1
+            self.bwd(x, adj, env)
+            self.ind -= 1
+            self.put("} else {")
+            self.ind += 1
+            self.bwd(y, adj, env)
+            self.ind -= 1
+            self.put("}")
+        elif op == "sum":
+            v, n, body, lets = a
+            dist = env[("dist", id(e))]
+            for k, x in lets:
+                self.put(f"double ah{k} = 0.0;")
+            if adj[0] not in "at" or not adj[1:].isdigit():  # (an expression: named once, outside the loop)
+                adj = self.let(adj, "a")
+            self.put(self.loop_head(e, dist))
+            self.ind += 1
+            self.depth += 1
+            outer_owned = self.lane_owned
+            if dist:
+                self.lane_owned = True
+            benv = dict(env)
+            self.fwd(body, benv)  # (the body's values again)
+            self.bwd(body, adj, benv)
+            self.lane_owned = outer_owned
+            self.depth -= 1
+            self.ind -= 1
+            self.put("}")
+            for k, x in reversed(lets):
+                if dist:
+                    self.put(f"ah{k} = AEHMC_WSUM(ah{k});")
+                self.bwd(x, f"ah{k}", env)
+        else:
+            raise AssertionError(op)
+
+    lane_owned = False  # inside a distributed loop: the lane owns the gradient entries its iterations touch
+
+
+_REV_PRELUDE = """
+#ifndef AEHMC_LANES  /* (plain C++ builds for the CPU tests define AEHMC_LANES 1 and AEHMC_WSUM(x) (x)) */
+#define AEHMC_LANES 64
+__device__ inline double aehmc_wsum_(double x) {  // xor butterfly: a + b == b + a bit for bit, so every lane ends with the same bits
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+  return x;
+}
+#define AEHMC_WSUM(x) aehmc_wsum_(x)
+#endif
+__device__ inline double aehmc_sq(double x) { return x * x; }
+__device__ inline double aehmc_softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+#define AEHMC_JOINT_GRAD 1
+// log-density and its gradient in one reverse sweep, run by the chain's wavefront: q = the position row, g = the gradient
+// row (both in LDS; g zeroed by the caller); every lane returns the same log-density
+__device__ double aehmc_logp_grad(const double *q, double *g, int lane, const double *const *prm) {
+"""
+
+
+def _reverse_source(root):
+    tree = _hoist(root, [0])
+    gen = _RevGen()
+    env = {}
+    val = gen.fwd(tree, env)
+    if not isinstance(val, str):
+        raise AssertionError
+    gen.bwd(tree, "1.0", env)
+    return _REV_PRELUDE + "\n".join(gen.lines) + f"\n  return {val};\n}}\n"
+
+
 def trace(fn, dim, scalar=False, args=()):
     """Call ``fn`` once on a proxy of the position (a scalar if ``scalar``, else a vector of ``dim`` entries) and emit
     the ``aehmc_logp`` template.  ``args``: further constant arguments handed to ``fn`` (numbers / numpy arrays)."""
@@ -613,4 +919,6 @@ def trace(fn, dim, scalar=False, args=()):
     body = g.ex(out)
     src = ("template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm) {\n"
            "  typedef decltype(q[0]) T;\n" + "\n".join(g.lines) + ("\n" if g.lines else "") + f"  return T({body});\n}}\n")
-    return Traced(src, ctx.params, False, dim)
+    tr = Traced(src, ctx.params, False, dim)
+    tr.grad_source = _reverse_source(out)  # (above 64 coordinates the engine takes this instead of ceil(dim / 64) forward passes)
+    return tr

@@ -145,6 +145,72 @@ def test_python_logprob_fn_transitions_match_numpy_restatement(model, sampler):
                 assert bool(info.is_turning[c]) == bool(o.is_turning)
 
 
+SCHOOLS_Y = np.array([28.0, 8.0, -3.0, 7.0, -1.0, 1.0, 18.0, 12.0])
+SCHOOLS_SIGMA = np.array([15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0])
+
+
+def schools(q, J):
+    """eight schools, non-centred, tiled to J schools: q = [mu, log tau, eta_1..J] (tests/test_gpu_autodiff.py's model)"""
+    y, sg = np.resize(SCHOOLS_Y, J), np.resize(SCHOOLS_SIGMA, J)
+    mu, lt, eta = q[0], q[1], q[2:]
+    tau = np.exp(lt)
+    z = (y - (mu + tau * eta)) / sg
+    return -0.5 * mu * mu / 25.0 - np.log1p(tau * tau / 25.0) + lt + (-0.5 * eta * eta - 0.5 * z * z).sum()
+
+
+def schools_grad(q, J):
+    y, sg = np.resize(SCHOOLS_Y, J), np.resize(SCHOOLS_SIGMA, J)
+    mu, lt, eta = q[0], q[1], q[2:]
+    tau = np.exp(lt)
+    z = (y - (mu + tau * eta)) / sg
+    g = np.empty_like(q)
+    g[0] = -mu / 25.0 + np.sum(z / sg)
+    g[1] = -(2.0 * tau * tau / 25.0) / (1.0 + tau * tau / 25.0) + 1.0 + np.sum(z * tau * eta / sg)
+    g[2:] = -eta + z * tau / sg
+    return g
+
+
+@pytest.mark.parametrize("D", [65, 200, 1000, 2048])
+@pytest.mark.parametrize("model", ["funnel", "schools"])
+def test_reverse_mode_joint_densities_match_numpy_restatement(model, D):
+    """above 64 coordinates a traced density is differentiated in ONE reverse sweep (the reference:
+    aesara.grad, /root/reference/aehmc/hmc.py:33-34, integrators.py:61-65).  NUTS transitions against the numpy
+    restatement driven by the same Python function and the analytic gradient: 1e-9, every discrete output identical."""
+    from aehmc_amd import RandomStream, nuts, targets
+    if model == "funnel":
+        fn, grad = funnel, funnel_grad
+    else:
+        fn, grad = (lambda q: schools(q, D - 2)), (lambda q: schools_grad(q, D - 2))
+    tgt = targets.as_target(fn, D)
+    assert isinstance(tgt, targets.CustomJoint) and "#define AEHMC_JOINT_GRAD 1" in tgt.source
+    otgt = NumpyTarget(fn, grad)
+    r = np.random.default_rng(D)
+    C, n, eps = 3, 2, (0.02 if model == "funnel" else 0.05)
+    q0 = 0.3 * r.normal(size=(C, D))
+    imm = 0.5 + r.random(D)
+    seeds = [900 + c for c in range(C)]
+    kern = nuts.new_kernel(RandomStream(seeds=seeds), fn, max_num_expansions=4)
+    state = nuts.new_state(dev(q0), fn)
+    for c in range(C):  # new_state: U and the whole gradient from one sweep
+        U, g = otgt(q0[c])
+        np.testing.assert_allclose(state.potential_energy[c].item(), U, rtol=1e-12)
+        np.testing.assert_allclose(state.potential_energy_grad[c].cpu().numpy(), g, rtol=1e-11, atol=1e-12)
+    okern = [no.nuts_kernel(no.RandomStream(sd), otgt, max_num_expansions=4) for sd in seeds]
+    ostate = [no.new_state(q0[c].copy(), otgt) for c in range(C)]
+    for _ in range(n):
+        info, _ = kern(state, eps, imm)
+        state = info.state._replace(momentum=None)
+        for c in range(C):
+            o = okern[c](ostate[c], eps, imm)
+            ostate[c] = o.state._replace(momentum=None)
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-11)
+            np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL)
+            np.testing.assert_allclose(info.state.potential_energy_grad[c].cpu().numpy(), o.state.potential_energy_grad,
+                                       rtol=RTOL, atol=1e-10)
+            assert info.n_leapfrog[c].item() == o.n_leapfrog and info.num_doublings[c].item() == o.num_doublings
+            assert bool(info.is_turning[c]) == bool(o.is_turning) and bool(info.is_diverging[c]) == bool(o.is_diverging)
+
+
 def test_python_logprob_fn_under_window_adaptation_and_sample():
     from aehmc_amd import RandomStream, nuts, window_adaptation
     C, D = 64, 10

@@ -86,12 +86,28 @@ template __global__ void aehmc::k_hmc_glm_rows<16>(aehmc::EngineArgs, long long,
 '''
 
 
+def traced_joint():
+    """a Python logprob_fn through aehmc_amd/tracing.py: the forward-mode template AND the reverse-mode program
+    (AEHMC_JOINT_GRAD: engine.cuh's joint_rows_eval takes it above 64 coordinates), as targets.CustomJoint hands them over"""
+    import numpy as np
+    from aehmc_amd import targets
+    w = np.linspace(-1.0, 1.0, 99)
+
+    def funnel_plus(q):
+        v, x = q[0], q[1:]
+        return -v * v / 18.0 + (-0.5 * x * x * np.exp(-v) - 0.5 * v).sum() - np.sum(np.log1p(np.square(x - w))) * np.tanh(v)
+
+    tgt = targets.from_callable(funnel_plus, 100)
+    assert isinstance(tgt, targets.CustomJoint) and "#define AEHMC_JOINT_GRAD 1" in tgt.source
+    return "#define AEHMC_JOINT_TARGET 1\n" + tgt.source + '#include "engine.cuh"\n#include "nuts_resident.cuh"\n'
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("name,source", [("elementwise", ELEMENTWISE), ("joint", JOINT), ("glm", GLM)],
-                         ids=["elementwise", "joint", "glm"])
+@pytest.mark.parametrize("name,source", [("elementwise", ELEMENTWISE), ("joint", JOINT), ("glm", GLM), ("traced_joint", traced_joint)],
+                         ids=["elementwise", "joint", "glm", "traced_joint"])
 def test_kernel_templates_instantiate_against_a_user_density(tmp_path, name, source):
     path = tmp_path / f"{name}.hip"
-    path.write_text(source)
+    path.write_text(source() if callable(source) else source)
     out = subprocess.run([HIPCC, "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I", CSRC, "--cuda-device-only",
                           "-fsyntax-only", "-Wno-unused-value", str(path)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-4000:]

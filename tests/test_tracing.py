@@ -82,11 +82,43 @@ int main() {
 """
 
 
-def run_cpp(tr, q, tmp_path, name):
+REV_HARNESS = r"""
+#include <cstdio>
+#include <cmath>
+#define __device__
+#define AEHMC_LANES 1
+#define AEHMC_WSUM(x) (x)
+%(source)s
+%(params)s
+int main() {
+  const int D = %(D)d;
+  const double q[] = {%(q)s};
+  double g[%(D)d] = {0};
+  std::printf("%%.17g\n", aehmc_logp_grad(q, g, 0, prm));
+  for (int i = 0; i < D; i++) std::printf("%%.17g\n", g[i]);
+  return 0;
+}
+"""
+
+
+def params_decl(tr):
     params = "".join(f"static const double prm{k}[] = {{{', '.join(repr(float(x)) for x in p)}}};\n" for k, p in enumerate(tr.params))
-    params += "static const double *const prm[] = {" + ", ".join([f"prm{k}" for k in range(len(tr.params))] + ["nullptr"]) + "};\n"
+    return params + "static const double *const prm[] = {" + ", ".join([f"prm{k}" for k in range(len(tr.params))] + ["nullptr"]) + "};\n"
+
+
+def run_cpp_reverse(tr, q, tmp_path, name):
+    """the reverse-mode program (one lane: the loops run whole, the wavefront reductions are identities)"""
+    src = tmp_path / f"{name}_rev.cpp"
+    src.write_text(REV_HARNESS % dict(source=tr.grad_source, params=params_decl(tr), D=len(q), q=", ".join(repr(float(x)) for x in q)))
+    exe = tmp_path / f"{name}_rev"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", str(exe), str(src)])
+    out = [float(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    return out[0], np.array(out[1:])
+
+
+def run_cpp(tr, q, tmp_path, name):
     src = tmp_path / f"{name}.cpp"
-    src.write_text(HARNESS % dict(source=tr.source, params=params, D=len(q), q=", ".join(repr(float(x)) for x in q), elem=int(tr.elementwise)))
+    src.write_text(HARNESS % dict(source=tr.source, params=params_decl(tr), D=len(q), q=", ".join(repr(float(x)) for x in q), elem=int(tr.elementwise)))
     exe = tmp_path / name
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "aehmc_amd", "csrc"), "-o", str(exe), str(src)])
     out = [float(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
@@ -105,6 +137,54 @@ def test_traced_density_and_gradient_match_the_python_function(name, tmp_path):
         h = 1e-6
         fd = np.array([(fn(q + h * np.eye(D)[i]) - fn(q - h * np.eye(D)[i])) / (2 * h) for i in range(D)])
         np.testing.assert_allclose(g, fd, rtol=2e-7, atol=2e-8)
+        if not tr.elementwise:  # the reverse sweep (taken above 64 coordinates) == the forward passes
+            vr, gr = run_cpp_reverse(tr, q, tmp_path, f"{name}{trial}")
+            assert vr == pytest.approx(v, rel=1e-14, abs=1e-14)
+            np.testing.assert_allclose(gr, g, rtol=1e-12, atol=1e-13)
+
+
+def random_density(seed, D):
+    """a random joint density: hyper-parameters at the head of the position, vector terms over slices of the rest, nested
+    reductions, where / maximum, captured arrays"""
+    r = np.random.default_rng(seed)
+    n = D - 3
+    w, c = r.normal(size=n), 0.5 + r.random(n)
+    A = r.normal(size=(3, n)) / np.sqrt(n)
+    picks = r.integers(0, 6, size=4)
+
+    def fn(q):
+        a, b, s = q[0], q[1], q[2]
+        x = q[3:]
+        terms = [lambda: (-0.5 * (x - a) ** 2 * np.exp(-2.0 * s)).sum() - n * s,
+                 lambda: -np.sum(np.log1p(np.square((x - w) / c))) * (1.0 + b * b) ** 0.5,
+                 lambda: np.tanh(a) * (x[: n // 2] * x[n - n // 2:]).sum() - 0.5 * np.dot(x, x) / (1.0 + tracing.softplus(b)),
+                 lambda: -0.5 * np.sum((A @ x - np.array([a, b, s])) ** 2),
+                 lambda: np.sum(tracing.where(x > a, np.sin(x) * b, -np.abs(x - a))) * 0.3 - np.logaddexp(a, b),
+                 lambda: -(np.maximum(x, w) * c).sum() * np.exp(-np.abs(s)) + (x[1:] - x[:-1]).mean() * np.cos(a)]
+        out = -0.5 * (a * a + b * b + s * s)
+        for k in picks:
+            out = out + terms[k]()
+        return out
+
+    return fn
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_reverse_mode_equals_forward_mode_on_random_densities(seed, tmp_path):
+    """forward- and reverse-mode gradients equal to 1e-12 on random densities (both compiled as plain
+    C++: the Dual template against the reverse sweep), and both equal to central differences of the Python function"""
+    D = [9, 17, 70][seed % 3]
+    fn = random_density(seed, D)
+    tr = tracing.trace(fn, D)
+    assert not tr.elementwise and "aehmc_logp_grad" in tr.grad_source
+    q = 0.6 * np.random.default_rng(100 + seed).normal(size=D)
+    v, g = run_cpp(tr, q, tmp_path, f"rnd{seed}")
+    vr, gr = run_cpp_reverse(tr, q, tmp_path, f"rnd{seed}")
+    assert v == pytest.approx(float(fn(q)), rel=1e-12, abs=1e-12) and vr == pytest.approx(v, rel=1e-13, abs=1e-13)
+    np.testing.assert_allclose(gr, g, rtol=1e-12, atol=1e-12)
+    h = 1e-6
+    fd = np.array([(fn(q + h * np.eye(D)[i]) - fn(q - h * np.eye(D)[i])) / (2 * h) for i in range(D)])
+    np.testing.assert_allclose(gr, fd, rtol=5e-7, atol=5e-7)
 
 
 def test_readme_function_is_the_builtin_standard_normal_expression():
