@@ -14,7 +14,7 @@
 //     density with the derivative seeded at ITS coordinate -- the D forward passes of the gradient run side by side
 //     in the lanes, every lane ends with the same value and with dlogp/dq_lane (JointArg below).
 // Supported: + - * / (Dual with Dual or double), unary -, comparisons (on the value), exp, log, log1p, expm1, sqrt,
-// pow(x, double), pow(x, y), sin, cos, tanh, fabs, erf, lgamma is NOT (no digamma on the device), square(x).
+// pow(x, double), pow(x, y), sin, cos, tanh, fabs, erf, lgamma (with digamma below), square(x), softplus(x).
 #pragma once
 #if defined(__HIPCC_RTC__) || defined(__HIPCC__)
 #ifndef __HIPCC_RTC__  /* (hipRTC supplies the runtime and the math functions itself) */
@@ -103,9 +103,36 @@ AEHMC_HD Dual tanh(Dual x) {
 }
 AEHMC_HD Dual fabs(Dual x) { return x.v < 0 ? -x : x; }
 AEHMC_HD Dual erf(Dual x) { return Dual(::erf(x.v), 1.1283791670955126 * ::exp(-x.v * x.v) * x.d); }
+// digamma = d/dx lgamma(x) (round 6: Gamma / Beta / Student-t / negative-binomial densities with traced shape parameters):
+// the recurrence psi(x) = psi(x + 1) - 1 / x up to x >= 10, there the asymptotic series ln x - 1 / (2x) - sum B_2k / (2k x^2k)
+// to x^-14 (truncation error below 1e-17); for x <= 0 the reflection psi(x) = psi(1 - x) - pi / tan(pi x).
+// Against scipy.special.digamma: 2e-15 relative on [1e-3, 1e3] (tests/test_dual.py).
+AEHMC_HD double digamma(double x) {
+  double refl = 0.0;
+  if (x <= 0.0) {
+    refl = -3.14159265358979323846 / ::tan(3.14159265358979323846 * x);
+    x = 1.0 - x;
+  }
+  double r = 0.0;
+  while (x < 10.0) {
+    r -= 1.0 / x;
+    x += 1.0;
+  }
+  const double i2 = 1.0 / (x * x);
+  const double ser = i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0 - i2 * (1.0 / 132.0 -
+                     i2 * (691.0 / 32760.0 - i2 * (1.0 / 12.0)))))));
+  return refl + r + ::log(x) - 0.5 / x - ser;
+}
+AEHMC_HD Dual lgamma(Dual x) { return Dual(::lgamma(x.v), digamma(x.v) * x.d); }
 // log(1 + exp(x)) without overflow (the logistic log-likelihood's building block) and the logistic function
 AEHMC_HD double softplus(double x) { return x > 0 ? x + ::log1p(::exp(-x)) : ::log1p(::exp(x)); }
-AEHMC_HD Dual softplus(Dual x) { return Dual(softplus(x.v), x.d / (1.0 + ::exp(-x.v))); }
+// (value and derivative from ONE exponential, e = exp(-|x|): softplus = max(x, 0) + log1p(e), its derivative the logistic
+//  function 1 / (1 + e) or e / (1 + e) -- round 6: the density-only logistic regression spent a third of its row function
+//  on the second exponential, profiles/r6/INDEX.md)
+AEHMC_HD Dual softplus(Dual x) {
+  const double e = ::exp(x.v > 0 ? -x.v : x.v), l = ::log1p(e), s = 1.0 / (1.0 + e);
+  return Dual(x.v > 0 ? x.v + l : l, x.d * (x.v > 0 ? s : e * s));
+}
 AEHMC_HD double value_of(double x) { return x; }
 AEHMC_HD double value_of(Dual x) { return x.v; }
 
@@ -164,3 +191,4 @@ struct JointRow<Dual> {
 using aehmc::ad::square;
 using aehmc::ad::softplus;
 using aehmc::ad::value_of;
+using aehmc::ad::digamma;

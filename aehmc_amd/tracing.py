@@ -9,7 +9,7 @@ position): traced ONCE with proxy objects and emitted as the ``aehmc_logp`` temp
 What a traced function may do with its argument (a scalar for a scalar position, else a vector of ``dim`` entries):
 ``+ - * / **`` and unary ``-`` with numbers, numpy arrays (captured as device parameter arrays) and other traced values;
 numpy ufuncs ``exp log log1p expm1 sqrt sin cos tanh abs square power reciprocal negative maximum minimum logaddexp``
-and ``scipy.special.erf``; ``softplus`` and ``where`` from this module; comparisons (inside ``where`` only);
+``scipy.special.erf`` and ``scipy.special.gammaln``; ``softplus`` and ``where`` from this module; comparisons (inside ``where`` only);
 ``.sum()`` / ``np.sum`` / ``.mean()``, ``@`` / ``np.dot`` (vector . vector, constant matrix @ vector, vector @ constant
 matrix); indexing and slicing with static bounds; iteration over a vector.  Anything else -- Python ``if`` on a traced
 value, ``float()``, ``math.exp``, fancy indexing -- raises ``TypeError`` at trace time and says what it was.
@@ -65,7 +65,7 @@ class Idx:
 
 # ------------------------------------------------------------------------------------------------------ scalars
 _UNARY = {"exp": "exp", "log": "log", "log1p": "log1p", "expm1": "expm1", "sqrt": "sqrt", "sin": "sin", "cos": "cos",
-          "tanh": "tanh", "absolute": "fabs", "fabs": "fabs", "erf": "erf", "softplus": "softplus"}
+          "tanh": "tanh", "absolute": "fabs", "fabs": "fabs", "erf": "erf", "softplus": "softplus", "gammaln": "lgamma", "lgamma": "lgamma"}
 _CMP = {"less": "<", "greater": ">", "less_equal": "<=", "greater_equal": ">=", "equal": "==", "not_equal": "!="}
 
 
@@ -214,7 +214,8 @@ def _unary(ctx, name, x):
         raise TraceError(f"{name} of a comparison result")
     if x.op == "const":
         with np.errstate(all="ignore"):
-            f = {"fabs": np.fabs, "erf": _erf_np, "softplus": lambda z: np.logaddexp(0.0, z)}.get(name) or getattr(np, name)
+            f = {"fabs": np.fabs, "erf": _erf_np, "softplus": lambda z: np.logaddexp(0.0, z),
+                 "lgamma": lambda z: __import__("math").lgamma(float(z))}.get(name) or getattr(np, name)
             return _const(ctx, f(x.args[0]))
     return S(ctx, "un", (name, x), x.t)
 
@@ -557,8 +558,12 @@ class _Gen:
             if e.t:
                 return f"({c} ? T({x}) : T({y}))"
             return f"({c} ? {x} : {y})"
+        if op == "ref":
+            return f"h{a[0]}"
         if op == "sum":
-            v, n, body = a
+            v, n, body = a[:3]
+            for k, x in (a[3] if len(a) > 3 else ()):  # loop-invariant sub-expressions (tracing._hoist): once, before the loop
+                self.put(f"const T h{k} = T({self.ex(x)});")
             acc = f"s{self.ntmp}"
             self.ntmp += 1
             iv = f"i{v}"
@@ -609,7 +614,7 @@ def _elementwise_var(root, dim, scalar):
 _UN_BWD = {"exp": "{a} * {v}", "log": "{a} / {x}", "log1p": "{a} / (1.0 + {x})", "expm1": "{a} * exp({x})",
            "sqrt": "0.5 * {a} / {v}", "sin": "{a} * cos({x})", "cos": "-({a} * sin({x}))", "tanh": "{a} * (1.0 - {v} * {v})",
            "fabs": "({x} < 0 ? -{a} : {a})", "erf": "{a} * 1.1283791670955126 * exp(-{x} * {x})",
-           "softplus": "{a} / (1.0 + exp(-{x}))", "square": "2.0 * {x} * {a}"}
+           "softplus": "{a} / (1.0 + exp(-{x}))", "square": "2.0 * {x} * {a}", "lgamma": "{a} * aehmc::ad::digamma({x})"}
 
 
 def _free_vars(e):
@@ -916,7 +921,7 @@ def trace(fn, dim, scalar=False, args=()):
                + "\n".join(g.lines) + ("\n" if g.lines else "") + f"  return T({body});\n}}\n")
         return Traced(src, ctx.params, True, dim)
     g = _Gen()
-    body = g.ex(out)
+    body = g.ex(_hoist(out, [0]))
     src = ("template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm) {\n"
            "  typedef decltype(q[0]) T;\n" + "\n".join(g.lines) + ("\n" if g.lines else "") + f"  return T({body});\n}}\n")
     tr = Traced(src, ctx.params, False, dim)

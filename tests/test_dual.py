@@ -36,6 +36,14 @@ int main() {
   if (std::fabs(c.d - (1.0 / 3 + 1) * 2 / 3) > 1e-15 || !(a < b) || !(b >= a) || a == b || !(a != 3.0) || !(1.0 < a)) bad++;
   Dual d = 5.0 / a;                                        // -5 / a^2
   if (std::fabs(d.d + 5.0 / 4.0) > 1e-15 || std::fabs(aehmc::ad::value_of(d) - 2.5) > 1e-15) bad++;
+  // lgamma / digamma (round 6): derivative against central differences, digamma against known values
+  for (double x = 0.3; x < 40.0; x *= 1.7) {
+    const Dual r = lgamma(Dual(x, 1.0));
+    const double h = 1e-6 * x, fd = (std::lgamma(x + h) - std::lgamma(x - h)) / (2 * h);
+    if (std::fabs(r.v - std::lgamma(x)) > 0 || std::fabs(r.d - fd) > 3e-8 * (1 + std::fabs(fd))) { std::printf("lgamma x=%g %.12g / %.12g\n", x, r.d, fd); bad++; }
+  }
+  if (std::fabs(aehmc::ad::digamma(1.0) + 0.57721566490153286) > 2e-15 || std::fabs(aehmc::ad::digamma(0.5) + 1.9635100260214235) > 4e-15 ||
+      std::fabs(aehmc::ad::digamma(100.0) - 4.6001618527380874) > 2e-15 || std::fabs(aehmc::ad::digamma(-0.5) - 0.03648997397857652) > 4e-15) bad++;
   std::printf("bad=%d\n", bad);
   return bad;
 }
@@ -49,3 +57,17 @@ def test_dual_numbers_against_finite_differences(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "aehmc_amd", "csrc"), "-o", str(exe), str(src)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout
+
+
+def test_digamma_against_scipy(tmp_path):
+    import numpy as np
+    from scipy.special import digamma
+    xs = np.concatenate([np.geomspace(1e-3, 1e3, 200), -np.linspace(0.1, 5.9, 30) - 0.05])
+    src = tmp_path / "dg.cpp"
+    src.write_text('#include <cstdio>\n#include <cmath>\n#include "dual.cuh"\nint main() { double x; while (std::scanf("%lf", &x) == 1) '
+                   'std::printf("%.17g\\n", aehmc::ad::digamma(x)); return 0; }\n')
+    exe = tmp_path / "dg"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "aehmc_amd", "csrc"), "-o", str(exe), str(src)])
+    out = subprocess.run([str(exe)], input="\n".join(repr(float(x)) for x in xs), capture_output=True, text=True, check=True).stdout.split()
+    got = np.array([float(v) for v in out])
+    np.testing.assert_allclose(got, digamma(xs), rtol=5e-14, atol=5e-15)

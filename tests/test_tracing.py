@@ -46,7 +46,14 @@ def kitchen_sink(q):
     return a + b - c + (q @ q) * 0.1
 
 
-CASES = {"student_t": (student_t, 7, True), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
+def gamma_mixture(q):  # Gamma(shape = exp(q[0]), rate = exp(q[1])) observations: lgamma of a traced shape parameter
+    from scipy.special import gammaln
+    a, b = np.exp(q[0]), np.exp(q[1])
+    x = np.exp(q[2:])
+    return np.sum(a * q[1] - gammaln(a) + (a - 1.0) * q[2:] - b * x) + q[2:].sum() - 0.5 * (q[0] ** 2 + q[1] ** 2)
+
+
+CASES = {"student_t": (student_t, 7, True), "gamma": (gamma_mixture, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
          "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
 
 HARNESS = r"""
@@ -88,6 +95,7 @@ REV_HARNESS = r"""
 #define __device__
 #define AEHMC_LANES 1
 #define AEHMC_WSUM(x) (x)
+#include "dual.cuh"
 %(source)s
 %(params)s
 int main() {
@@ -111,7 +119,7 @@ def run_cpp_reverse(tr, q, tmp_path, name):
     src = tmp_path / f"{name}_rev.cpp"
     src.write_text(REV_HARNESS % dict(source=tr.grad_source, params=params_decl(tr), D=len(q), q=", ".join(repr(float(x)) for x in q)))
     exe = tmp_path / f"{name}_rev"
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", str(exe), str(src)])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "aehmc_amd", "csrc"), "-o", str(exe), str(src)])
     out = [float(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     return out[0], np.array(out[1:])
 
