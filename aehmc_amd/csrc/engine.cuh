@@ -179,11 +179,27 @@ __device__ __forceinline__ void target_elem(const EngineArgs &a, long long i, do
 #ifdef AEHMC_JOINT_TARGET  // run-time compiled copy (aehmc_set_custom_joint_target): the user's joint log-density
 // Wave-wide evaluation (D <= 64): lane i holds q_i; returns U = -logp (the same bits in every lane) and this lane's
 // dU/dq_i -- forward mode, the derivative seeded at the lane's own coordinate (dual.cuh: JointArg<Dual>).
+// A density whose reductions run over far more terms than it has coordinates (a regression's sum over its data rows: the
+// tracer sets AEHMC_JOINT_GRAD_SMALL) takes its reverse-mode program here too: the loops spread over the 64 lanes instead
+// of every lane running all of them for its own directional derivative.
 __device__ __forceinline__ double target_joint(const EngineArgs &a, int lane, int D, double q, double &g) {
+#ifdef AEHMC_JOINT_GRAD_SMALL
+  __shared__ double aehmc_joint_small[16][128];  // per wavefront: the position row and the gradient row (<= 1024 threads per workgroup)
+  double *const qr = aehmc_joint_small[threadIdx.x >> 6], *const gr = qr + 64;
+  qr[lane] = lane < D ? q : 0.0;
+  gr[lane] = 0.0;
+  __threadfence_block();
+  const double lp = aehmc_logp_grad(qr, gr, lane, a.cparams);
+  __threadfence_block();
+  g = -gr[lane];
+  __threadfence_block();  // (the rows are rewritten by the next evaluation)
+  return -lp;
+#else
   const JointArg<Dual> arg{q, lane, D};
   const Dual r = aehmc_logp(arg, a.cparams);
   g = -r.d;
   return -r.v;
+#endif
 }
 #endif
 __device__ __forceinline__ double target_finish(const EngineArgs &a, double usum) {

@@ -525,6 +525,7 @@ class _Gen:
         self.lines, self.ind, self.ntmp = [], 1, 0
         self.names = {}            # loop variable -> C++ name
         self.elem_var, self.scalar = elem_var, scalar
+        self.par_local = None
 
     def put(self, s):
         self.lines.append("  " * self.ind + s)
@@ -539,6 +540,9 @@ class _Gen:
         if op == "const":
             return _lit(a[0])
         if op == "par":
+            if self.par_local is not None:  # (the reverse-mode program reads its parameter arrays through local restrict pointers)
+                self.par_local.add(a[0])
+                return f"prm{a[0]}[{a[1].code(self.names)}]"
             return f"prm[{a[0]}][{a[1].code(self.names)}]"
         if op == "q":
             return self.q(a[0])
@@ -682,11 +686,30 @@ def _distributable(e):
     return ok(e.args[2]) and lets_ok(e.args[2])
 
 
+def _spine(root):
+    """sums joined to the root by + / - / unary minus only: id -> their adjoint as a literal"""
+    out = {}
+
+    def go(e, sign):
+        if e.op == "sum":
+            out[id(e)] = "1.0" if sign > 0 else "-1.0"
+        elif e.op == "neg":
+            go(e.args[0], -sign)
+        elif e.op == "bin" and e.args[0] in "+-":
+            go(e.args[1], sign)
+            go(e.args[2], sign if e.args[0] == "+" else -sign)
+
+    go(root, 1)
+    return out
+
+
 class _RevGen:
-    def __init__(self):
+    def __init__(self, spine=None):
         self.lines, self.ind, self.n = [], 1, 0
         self.names = {}  # loop variable -> C++ name
         self.depth = 0   # loop nesting
+        self.spine, self.done = spine or {}, set()
+        self.used_params = set()
 
     def put(self, s):
         self.lines.append("  " * self.ind + s)
@@ -706,7 +729,8 @@ class _RevGen:
         if op == "const":
             return _lit(a[0])
         if op == "par":
-            return f"prm[{a[0]}][{a[1].code(self.names)}]"
+            self.used_params.add(a[0])
+            return f"prm{a[0]}[{a[1].code(self.names)}]"
         if op == "q":
             return f"q[{a[0].code(self.names)}]"
         if op == "ref":
@@ -714,6 +738,7 @@ class _RevGen:
         if not e.t and op != "sum":  # parameters and constants only: inlined
             g = _Gen()
             g.names = self.names
+            g.par_local = self.used_params
             return g.ex(e)
         if op == "neg":
             r = f"(-{self.fwd(a[0], env)})"
@@ -740,6 +765,8 @@ class _RevGen:
         v, n = e.args[0], e.args[1]
         iv = f"i{v}"
         self.names[v] = iv
+        if dist and n >= 512:  # (a long sweep over data: four iterations' loads in flight)
+            self.put("#pragma unroll 4")
         return f"for (int {iv} = {'lane' if dist else '0'}; {iv} < {n}; {iv} {'+= AEHMC_LANES' if dist else '++'}) {{"
 
     def fwd_sum(self, e, env):
@@ -750,15 +777,32 @@ class _RevGen:
             env[("let", k)] = self.fwd(x, env)
         acc = self.tmp("s")
         self.put(f"double {acc} = 0.0;")
+        # a sum on the additive spine of the density (log-density = term + term + ...) has the adjoint +1 / -1 whatever the
+        # other terms are: its backward sweep rides in the forward loop -- one pass over the data instead of two
+        fused = self.spine.get(id(e)) if self.depth == 0 else None
+        if fused:
+            for k, x in lets:
+                self.put(f"double ah{k} = 0.0;")
         self.put(self.loop_head(e, dist))
         self.ind += 1
         self.depth += 1
-        self.put(f"{acc} += {self.fwd(body, dict(env))};")
+        benv = dict(env)
+        self.put(f"{acc} += {self.fwd(body, benv)};")
+        if fused:
+            outer_owned, self.lane_owned = self.lane_owned, dist
+            self.bwd(body, fused, benv)
+            self.lane_owned = outer_owned
         self.depth -= 1
         self.ind -= 1
         self.put("}")
         if dist:
             self.put(f"{acc} = AEHMC_WSUM({acc});")
+        if fused:
+            for k, x in reversed(lets):
+                if dist:
+                    self.put(f"ah{k} = AEHMC_WSUM(ah{k});")
+                self.bwd(x, f"ah{k}", env)
+            self.done.add(id(e))
         env[id(e)] = acc
         return acc
 
@@ -823,6 +867,8 @@ class _RevGen:
             self.ind -= 1
             self.put("}")
         elif op == "sum":
+            if id(e) in self.done:  # (its backward sweep rode in its forward loop)
+                return
             v, n, body, lets = a
             dist = env[("dist", id(e))]
             for k, x in lets:
@@ -870,15 +916,30 @@ __device__ double aehmc_logp_grad(const double *q, double *g, int lane, const do
 """
 
 
-def _reverse_source(root):
+def _distributed_terms(e, top=True):
+    """how many loop iterations the reverse-mode program spreads over the lanes (outermost distributable sums)"""
+    if e.op == "sum":
+        if top and _distributable(e):
+            return e.args[1] + sum(_distributed_terms(x) for _, x in e.args[3])
+        return sum(_distributed_terms(x, top) for _, x in e.args[3])  # (what it hoisted is evaluated outside it)
+    return sum(_distributed_terms(x, top) for x in e.args if isinstance(x, S))
+
+
+def _reverse_source(root, dim):
     tree = _hoist(root, [0])
-    gen = _RevGen()
+    gen = _RevGen(_spine(tree))
     env = {}
     val = gen.fwd(tree, env)
     if not isinstance(val, str):
         raise AssertionError
     gen.bwd(tree, "1.0", env)
-    return _REV_PRELUDE + "\n".join(gen.lines) + f"\n  return {val};\n}}\n"
+    ptrs = "".join(f"  const double *__restrict__ const prm{k} = prm[{k}];\n" for k in sorted(gen.used_params))
+    src = _REV_PRELUDE + ptrs + "\n".join(gen.lines) + f"\n  return {val};\n}}\n"
+    # up to 64 coordinates the engine's one-launch kernels differentiate in forward mode, every lane running the whole
+    # density for its own coordinate: right for a funnel, 64 times too much for a sum over 10^4 data rows
+    if dim <= 64 and _distributed_terms(tree) >= 256:
+        src += "#define AEHMC_JOINT_GRAD_SMALL 1\n"
+    return src
 
 
 def trace(fn, dim, scalar=False, args=()):
@@ -925,5 +986,5 @@ def trace(fn, dim, scalar=False, args=()):
     src = ("template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm) {\n"
            "  typedef decltype(q[0]) T;\n" + "\n".join(g.lines) + ("\n" if g.lines else "") + f"  return T({body});\n}}\n")
     tr = Traced(src, ctx.params, False, dim)
-    tr.grad_source = _reverse_source(out)  # (above 64 coordinates the engine takes this instead of ceil(dim / 64) forward passes)
+    tr.grad_source = _reverse_source(out, dim)  # (above 64 coordinates the engine takes this instead of ceil(dim / 64) forward passes)
     return tr

@@ -42,3 +42,28 @@ for D in (10, 64, 100, 256, 1000):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         nl = int(info.n_leapfrog.sum())
         print(f"funnel D={D} C={C} {form:8s}: {dt / T * 1e3:.2f} ms/transition, {nl / T / C:.1f} leapfrogs/chain, {nl / dt:.3e} leapfrog/s", flush=True)
+
+# ---- the notebook's regression (examples/LinearRegression.ipynb) written as a Python function over N data rows, beside
+#      the built-in LinearRegression target (k_nuts_linreg: chains of a workgroup share each pass over the data)
+for N, Cr in ((10_000, 4096), (100_000, 1024)):
+    rng = np.random.default_rng(0)
+    X = rng.normal(0, 1, size=(N,)); y = 3 * X + rng.normal(0, 1)
+    h = 0.5 * np.log(2 * np.pi)
+
+    def regression(q):
+        w, ls = q[0], q[1]
+        n = np.exp(ls)
+        r = y - X * w
+        return (-0.5 * w * w - h) + (ls - n) + ls + (-0.5 * (r / n) ** 2 - ls - h).sum()
+
+    for form, tgt in (("python", targets.from_callable(regression, 2)), ("builtin", targets.LinearRegression(X, y))):
+        q0 = torch.as_tensor(np.array([3.0, 0.0]) + 0.01 * rng.standard_normal((Cr, 2)), device="cuda")
+        imm = np.array([1.0 / N, 0.5 / N])
+        kernel = nuts.new_kernel(RandomStream(seeds=list(range(Cr))), tgt, max_num_expansions=6)
+        state = nuts.new_state(q0, tgt)
+        state = kernel.sample(state, 0.5, imm, 3, keep_samples=False)[1].state._replace(momentum=None)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        samples, info, acc, div = kernel.sample(state, 0.5, imm, 5, keep_samples=False)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        nl = int(info.n_leapfrog.sum())
+        print(f"regression N={N} C={Cr} {form:8s}: {dt / 5 * 1e3:.2f} ms/transition, {nl / 5 / Cr:.1f} leapfrogs/chain, {nl / dt:.3e} leapfrog/s", flush=True)
