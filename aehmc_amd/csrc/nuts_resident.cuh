@@ -96,10 +96,16 @@ __device__ __forceinline__ void team_sum2(double &x, double &y, bool single = fa
 #define AEHMC_RES_MIN_WAVES 1
 #endif
 constexpr int res_min_waves(int T, int R, bool MULTI) { return (AEHMC_RES_MIN_WAVES && T == 64 && MULTI && R <= 4) ? 4 : 1; }
+// (the dense instantiations run 512-thread workgroups: two wavefronts per SIMD have to fit.  Said explicitly since round 6:
+//  with amdgpu_waves_per_eu(1) the compiler took the freedom to use 328 registers for a user density with long unrolled
+//  inner loops -- a code object that cannot be launched, HSA_STATUS_ERROR_INVALID_ISA)
+constexpr int res_min_waves_dense(int T, int R, bool MULTI, int DENSE) {
+  return DENSE ? (res_min_waves(T, R, MULTI) > 2 ? res_min_waves(T, R, MULTI) : 2) : res_min_waves(T, R, MULTI);
+}
 
 template <int T, int R, bool MULTI, int DENSE = 0, bool CKL = false>
 __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK)
-    __attribute__((amdgpu_waves_per_eu(res_min_waves(T, R, MULTI)))) void k_nuts_resident(EngineArgs a, NutsSampleArgs m) {
+    __attribute__((amdgpu_waves_per_eu(res_min_waves_dense(T, R, MULTI, DENSE)))) void k_nuts_resident(EngineArgs a, NutsSampleArgs m) {
   using TM = Team<T>;
   static_assert(DENSE == 0 || (T == 64 && R == 1), "dense products: one wavefront per chain, one element per lane");
   static_assert(!CKL || (DENSE == 0 && T == 64 && R == 1), "LDS checkpoints: one wavefront per chain, one element per lane");

@@ -280,15 +280,22 @@ class V:
     """A traced vector of static length: a function from an index to a traced scalar (nothing is materialised)."""
 
     __array_priority__ = 1000
-    __slots__ = ("ctx", "n", "_at", "unroll")
+    __slots__ = ("ctx", "n", "_at", "unroll", "_memo")
 
     def __init__(self, ctx, n, at, unroll=False):
         # unroll: built from a Python list of traced scalars (np.array([a, b, c])): its entries exist at static indices
         # only, so reductions over it are written out term by term instead of as a loop
         self.ctx, self.n, self._at, self.unroll = ctx, int(n), at, bool(unroll)
+        self._memo = {}
 
     def at(self, i):
-        return self._at(i if isinstance(i, Idx) else Idx(i))
+        # the entry at an index is ONE node however often it is asked for (z = X @ q used twice in a row's term: its
+        # value is computed once in the emitted code)
+        i = i if isinstance(i, Idx) else Idx(i)
+        k = i.key()
+        if k not in self._memo:
+            self._memo[k] = self._at(i)
+        return self._memo[k]
 
     @staticmethod
     def _ew2(ctx, f, a, b):
@@ -639,51 +646,78 @@ def _free_vars(e):
     return out
 
 
-def _hoist(e, counter):
-    """The tree with, in every sum, the position-dependent sub-expressions that do not read its loop variable replaced by
-    `ref` nodes; the sum node gains a fourth argument: the list of (k, hoisted expression)."""
+def _hoist(e, counter, memo=None):
+    """The expression with, in every sum, the position-dependent sub-expressions that do not read its loop variable replaced
+    by `ref` nodes; the sum node gains a fourth argument: the list of (k, hoisted expression).  Shared nodes stay shared."""
+    memo = {} if memo is None else memo
+    if id(e) in memo:
+        return memo[id(e)]
     if e.op == "sum":
         v, n, body = e.args[:3]
         lets = []
+        local = {}
 
         def go(x):
             if not isinstance(x, S) or not x.t:
                 return x
+            if id(x) in local:
+                return local[id(x)]
             if x.op != "ref" and v not in _free_vars(x):
                 k = counter[0]
                 counter[0] += 1
-                lets.append((k, _hoist(x, counter)))
-                return S(x.ctx, "ref", (k,), True)
-            if x.op in ("q", "ref"):
-                return x
-            if x.op == "sum":
-                return _hoist(x, counter)
-            return S(x.ctx, x.op, tuple(go(y) for y in x.args), x.t, x.b)
+                lets.append((k, _hoist(x, counter, memo)))
+                r = S(x.ctx, "ref", (k,), True)
+            elif x.op in ("q", "ref"):
+                r = x
+            elif x.op == "sum":
+                r = _hoist(x, counter, memo)
+            else:
+                r = S(x.ctx, x.op, tuple(go(y) for y in x.args), x.t, x.b)
+            local[id(x)] = r
+            return r
 
-        return S(e.ctx, "sum", (v, n, go(body), lets), e.t)
-    if e.op in ("const", "par", "q", "ref"):
-        return e
-    return S(e.ctx, e.op, tuple(_hoist(x, counter) if isinstance(x, S) else x for x in e.args), e.t, e.b)
+        out = S(e.ctx, "sum", (v, n, go(body), lets), e.t)
+    elif e.op in ("const", "par", "q", "ref"):
+        out = e
+    else:
+        out = S(e.ctx, e.op, tuple(_hoist(x, counter, memo) if isinstance(x, S) else x for x in e.args), e.t, e.b)
+    memo[id(e)] = out
+    return out
+
+
+PRIVATE_MAX = 32  # an inner reduction up to this long may read the position inside a distributed loop (private accumulators)
+
+
+def _private_leaves(e):
+    """For a sum that is to be distributed over the lanes: {id(q leaf): (inner sum node, a, c)} of the position reads that
+    do not depend on ITS variable but on the variable of ONE inner sum of at most PRIVATE_MAX terms (index a * j + c) -- a
+    data row's product with the coefficients, sum_j X[i, j] q[j].  Their adjoints collect in per-lane arrays indexed by j,
+    reduced over the wavefront behind the loop.  None if some read fits neither this form nor a * i + c."""
+    v = e.args[0]
+    out = {}
+
+    def walk(x, inner):
+        if x.op == "q":
+            t = x.args[0].terms
+            if len(t) == 1 and t[0][0] == v and t[0][1] != 0:
+                return True
+            if len(t) == 1 and t[0][0] in inner and t[0][1] != 0 and inner[t[0][0]].args[1] <= PRIVATE_MAX:
+                out[id(x)] = (inner[t[0][0]], t[0][1], x.args[0].c)
+                return True
+            return False
+        if x.op == "sum":
+            inner2 = dict(inner)
+            inner2[x.args[0]] = x
+            return all(walk(h, inner) for _, h in x.args[3]) and walk(x.args[2], inner2)
+        return all(walk(y, inner) for y in x.args if isinstance(y, S))
+
+    return out if walk(e.args[2], {}) else None
 
 
 def _distributable(e):
-    """a sum whose body reads (and so writes the gradient of) the position at indices a * i + c only, a != 0"""
-    v = e.args[0]
-
-    def ok(x):
-        if x.op == "q":
-            t = x.args[0].terms
-            return len(t) == 1 and t[0][0] == v and t[0][1] != 0
-        if x.op == "sum":
-            return ok(x.args[2])  # (what it hoisted is position-dependent and invariant in ITS variable: checked where it is bound... )
-        return all(ok(y) for y in x.args if isinstance(y, S))
-
-    def lets_ok(x):  # hoisted expressions of inner sums live inside this loop's body: they must obey the same rule
-        if x.op == "sum":
-            return all(ok(h) and lets_ok(h) for _, h in x.args[3]) and lets_ok(x.args[2])
-        return all(lets_ok(y) for y in x.args if isinstance(y, S))
-
-    return ok(e.args[2]) and lets_ok(e.args[2])
+    """a sum whose body reads (and so writes the gradient of) the position at indices a * i + c, a != 0, or through short
+    inner reductions (_private_leaves)"""
+    return _private_leaves(e) is not None
 
 
 def _spine(root):
@@ -710,6 +744,9 @@ class _RevGen:
         self.depth = 0   # loop nesting
         self.spine, self.done = spine or {}, set()
         self.used_params = set()
+        self.uses, self.cond = {}, set()
+        self.private = {}     # id(q leaf) -> (accumulator array, inner sum node)
+        self.unrolled = set()  # ids of inner sums whose loops are written out (their accumulator arrays stay in registers)
 
     def put(self, s):
         self.lines.append("  " * self.ind + s)
@@ -726,6 +763,8 @@ class _RevGen:
     # ---- forward: the value of e as a C++ expression; every position-dependent inner node gets a name in env
     def fwd(self, e, env):
         op, a = e.op, e.args
+        if id(e) in env:  # (a shared node: its value has a name already)
+            return env[id(e)]
         if op == "const":
             return _lit(a[0])
         if op == "par":
@@ -765,9 +804,14 @@ class _RevGen:
         v, n = e.args[0], e.args[1]
         iv = f"i{v}"
         self.names[v] = iv
-        if dist and n >= 512:  # (a long sweep over data: four iterations' loads in flight)
-            self.put("#pragma unroll 4")
+        if dist and n >= 512 and not self.has_inner_sum(e.args[2]):  # (a long sweep over data: four iterations' loads in flight;
+            self.put("#pragma unroll 4")                               #  with an inner reduction that one is written out instead)
+        if id(e) in self.unrolled:
+            self.put("#pragma unroll")
         return f"for (int {iv} = {'lane' if dist else '0'}; {iv} < {n}; {iv} {'+= AEHMC_LANES' if dist else '++'}) {{"
+
+    def has_inner_sum(self, e):
+        return isinstance(e, S) and (e.op == "sum" or any(self.has_inner_sum(x) for x in e.args if isinstance(x, S)))
 
     def fwd_sum(self, e, env):
         v, n, body, lets = e.args
@@ -780,9 +824,11 @@ class _RevGen:
         # a sum on the additive spine of the density (log-density = term + term + ...) has the adjoint +1 / -1 whatever the
         # other terms are: its backward sweep rides in the forward loop -- one pass over the data instead of two
         fused = self.spine.get(id(e)) if self.depth == 0 else None
+        priv = self.private_begin(e) if dist else []
         if fused:
             for k, x in lets:
                 self.put(f"double ah{k} = 0.0;")
+            self.private_declare(priv)
         self.put(self.loop_head(e, dist))
         self.ind += 1
         self.depth += 1
@@ -798,11 +844,13 @@ class _RevGen:
         if dist:
             self.put(f"{acc} = AEHMC_WSUM({acc});")
         if fused:
+            self.private_reduce(priv)
             for k, x in reversed(lets):
                 if dist:
                     self.put(f"ah{k} = AEHMC_WSUM(ah{k});")
                 self.bwd(x, f"ah{k}", env)
             self.done.add(id(e))
+        env[("priv", id(e))] = priv
         env[id(e)] = acc
         return acc
 
@@ -814,12 +862,57 @@ class _RevGen:
             return env[id(e)]
         return self.fwd(e, env)  # (leaves and parameter-only expressions: no statements)
 
+    def count_uses(self, root):
+        """how many parents every position-dependent inner node has (a shared node's adjoint is collected from all of them
+        and propagated ONCE), and which nodes are reached through a branch of a `where` (those are never merged: the
+        statement that would propagate the merged adjoint might sit in the branch that is not taken)"""
+        self.uses, self.cond = {}, set()
+
+        def go(e, cond):
+            if not isinstance(e, S) or not e.t or e.op in ("q", "ref", "const", "par"):
+                return
+            if cond:
+                self.cond.add(id(e))
+            self.uses[id(e)] = self.uses.get(id(e), 0) + 1
+            if self.uses[id(e)] > 1 and not cond:
+                return
+            if e.op == "where":
+                go(e.args[0], cond)
+                go(e.args[1], True)
+                go(e.args[2], True)
+            elif e.op == "sum":
+                for _, x in e.args[3]:
+                    go(x, cond)
+                go(e.args[2], cond)
+            else:
+                for x in e.args:
+                    go(x, cond)
+
+        go(root, False)
+
     # ---- backward: propagate the adjoint `adj` (a name or a literal) of e into the position
     def bwd(self, e, adj, env):
         if not e.t:
             return
         op, a = e.op, e.args
+        if op not in ("q", "ref") and self.uses.get(id(e), 1) > 1 and id(e) not in self.cond and id(e) in env:
+            # a shared node: collect, propagate behind the last parent
+            key = ("adj", id(e))
+            seen = env.get(("nadj", id(e)), 0) + 1
+            env[("nadj", id(e))] = seen
+            if seen == 1:
+                env[key] = self.tmp("ad")
+                self.put(f"double {env[key]} = {adj};")
+            else:
+                self.put(f"{env[key]} += {adj};")
+            if seen < self.uses[id(e)]:
+                return
+            adj = env[key]
         if op == "q":
+            if id(e) in self.private:  # (read through a short inner reduction inside a distributed loop: per-lane accumulator)
+                arr, inner = self.private[id(e)]
+                self.put(f"{arr}[{self.names[inner.args[0]]}] += {adj};")
+                return
             tgt = f"g[{a[0].code(self.names)}]"
             self.put(f"{tgt} += {adj};" if self.depth > 0 and self.lane_owned else f"if (lane == 0) {tgt} += {adj};")
         elif op == "ref":
@@ -873,6 +966,7 @@ class _RevGen:
             dist = env[("dist", id(e))]
             for k, x in lets:
                 self.put(f"double ah{k} = 0.0;")
+            self.private_declare(env.get(("priv", id(e)), []))
             if adj[0] not in "at" or not adj[1:].isdigit():  # (an expression: named once, outside the loop)
                 adj = self.let(adj, "a")
             self.put(self.loop_head(e, dist))
@@ -888,6 +982,7 @@ class _RevGen:
             self.depth -= 1
             self.ind -= 1
             self.put("}")
+            self.private_reduce(env.get(("priv", id(e)), []))
             for k, x in reversed(lets):
                 if dist:
                     self.put(f"ah{k} = AEHMC_WSUM(ah{k});")
@@ -896,6 +991,33 @@ class _RevGen:
             raise AssertionError(op)
 
     lane_owned = False  # inside a distributed loop: the lane owns the gradient entries its iterations touch
+
+    # ---- per-lane accumulators of position reads through short inner reductions (_private_leaves)
+    def private_begin(self, e):
+        """name one accumulator array per (inner sum, stride, offset) of the distributed sum e; returns [(array, n, a, c)]"""
+        arrays, out = {}, []
+        for leaf, (inner, a, c) in (_private_leaves(e) or {}).items():
+            key = (id(inner), a, c)
+            if key not in arrays:
+                arrays[key] = self.tmp("gp")
+                out.append((arrays[key], inner.args[1], a, c))
+            self.private[leaf] = (arrays[key], inner)
+            self.unrolled.add(id(inner))
+        return out
+
+    def private_declare(self, priv):
+        for arr, n, a, c in priv:
+            self.put(f"double {arr}[{n}];")
+            self.put("#pragma unroll")
+            self.put(f"for (int j = 0; j < {n}; j++) {arr}[j] = 0.0;")
+
+    def private_reduce(self, priv):
+        for arr, n, a, c in priv:
+            self.put("#pragma unroll")
+            self.put(f"for (int j = 0; j < {n}; j++) {{")
+            self.put(f"  const double r = AEHMC_WSUM({arr}[j]);")
+            self.put(f"  if (lane == 0) g[{a} * j + {c}] += r;")
+            self.put("}")
 
 
 _REV_PRELUDE = """
@@ -928,6 +1050,7 @@ def _distributed_terms(e, top=True):
 def _reverse_source(root, dim):
     tree = _hoist(root, [0])
     gen = _RevGen(_spine(tree))
+    gen.count_uses(tree)
     env = {}
     val = gen.fwd(tree, env)
     if not isinstance(val, str):

@@ -242,6 +242,53 @@ def test_notebook_regression_written_as_a_python_function(regression_data):
     assert info.acceptance_probability.item() == 1.0 and not info.is_diverging.item()
 
 
+@pytest.mark.parametrize("N, D", [(63, 3), (65, 8), (2500, 8), (10000, 20)])
+def test_logistic_regression_written_as_a_python_function(N, D):
+    """A GLM written the way a user of the reference writes it -- z = X @ q over a captured data matrix, a sum over the
+    rows, a Gaussian prior -- against targets.CustomGLM (the same model as HIP source, density only) and the numpy
+    restatement with the analytic gradient.  The rows are spread over the lanes of the chain's wavefront, the D
+    coefficient adjoints collected in per-lane accumulators (tracing._private_leaves)."""
+    from aehmc_amd import RandomStream, nuts, targets, tracing
+    r = np.random.default_rng(N + D)
+    X = r.normal(size=(N, D)) / np.sqrt(D)
+    y = (r.random(N) < 0.5).astype(np.float64)
+
+    def logprob_fn(q):
+        z = X @ q
+        return (y * z - tracing.softplus(z)).sum() - 0.5 * (q @ q) / 4.0
+
+    def grad(q):
+        return X.T @ (y - 1.0 / (1.0 + np.exp(-(X @ q)))) - q / 4.0
+
+    tgt = targets.as_target(logprob_fn, D)
+    assert isinstance(tgt, targets.CustomJoint) and ("AEHMC_JOINT_GRAD_SMALL" in tgt.source) == (N >= 256)
+    glm = targets.CustomGLM("""
+template <class T> __device__ T aehmc_glm_loglik(T z, double y, long long n, const double *const *prm) { return y * z - softplus(z); }
+template <class T> __device__ T aehmc_glm_logprior(T q, long long i, const double *const *prm) { return -0.5 * q * q / 4.0; }
+""", dev(X), dev(y))
+    C, eps = 4, 0.3 / np.sqrt(N)
+    q0 = 0.3 * r.normal(size=(C, D))
+    s1, s2 = nuts.new_state(dev(q0), logprob_fn), nuts.new_state(dev(q0), glm)
+    np.testing.assert_allclose(s1.potential_energy.cpu().numpy(), s2.potential_energy.cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(s1.potential_energy_grad.cpu().numpy(), s2.potential_energy_grad.cpu().numpy(), rtol=1e-10, atol=1e-11)
+    otgt = NumpyTarget(logprob_fn, grad)
+    seeds = [40 + c for c in range(C)]
+    kern = nuts.new_kernel(RandomStream(seeds=seeds), logprob_fn, max_num_expansions=5)
+    okern = [no.nuts_kernel(no.RandomStream(sd), otgt, max_num_expansions=5) for sd in seeds]
+    ostate = [no.new_state(q0[c].copy(), otgt) for c in range(C)]
+    state = s1
+    for _ in range(3):
+        info, _ = kern(state, eps, np.ones(D))
+        state = info.state._replace(momentum=None)
+        for c in range(C):
+            o = okern[c](ostate[c], eps, np.ones(D))
+            ostate[c] = o.state._replace(momentum=None)
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-11)
+            np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL)
+            assert info.n_leapfrog[c].item() == o.n_leapfrog and info.num_doublings[c].item() == o.num_doublings
+            assert bool(info.is_turning[c]) == bool(o.is_turning) and bool(info.is_diverging[c]) == bool(o.is_diverging)
+
+
 def test_python_logprob_fn_under_window_adaptation_and_sample():
     from aehmc_amd import RandomStream, nuts, window_adaptation
     C, D = 64, 10

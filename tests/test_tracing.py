@@ -53,7 +53,22 @@ def gamma_mixture(q):  # Gamma(shape = exp(q[0]), rate = exp(q[1])) observations
     return np.sum(a * q[1] - gammaln(a) + (a - 1.0) * q[2:] - b * x) + q[2:].sum() - 0.5 * (q[0] ** 2 + q[1] ** 2)
 
 
-CASES = {"student_t": (student_t, 7, True), "gamma": (gamma_mixture, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
+XL = R.normal(size=(300, 5)) / 2.0
+YL = (R.random(300) < 0.5).astype(np.float64)
+
+
+def logistic(q):  # a data matrix captured from the closure: z = X @ q is ONE node used twice (value and adjoint merged)
+    z = XL @ q
+    return (YL * z - tracing.softplus(z)).sum() - 0.5 * (q @ q) / 4.0
+
+
+def shared_under_where(q):  # a shared sub-expression with a use inside a where-branch (never merged: see _RevGen.count_uses)
+    u = np.exp(q[:3]) + q[3:6] ** 2
+    return np.sum(tracing.where(q[:3] > 0.1, u * q[3:6], -u) + np.sin(u)) - 0.5 * np.sum(q * q)
+
+
+CASES = {"student_t": (student_t, 7, True), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False),
+         "shared_under_where": (shared_under_where, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
          "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
 
 HARNESS = r"""

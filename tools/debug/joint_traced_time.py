@@ -67,3 +67,33 @@ for N, Cr in ((10_000, 4096), (100_000, 1024)):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         nl = int(info.n_leapfrog.sum())
         print(f"regression N={N} C={Cr} {form:8s}: {dt / 5 * 1e3:.2f} ms/transition, {nl / 5 / Cr:.1f} leapfrogs/chain, {nl / dt:.3e} leapfrog/s", flush=True)
+
+# ---- logistic regression: a Python function over a captured data matrix (z = X @ q) beside targets.CustomGLM (HIP source,
+#      density only: the one-launch row sweep / the GEMM path)
+from aehmc_amd import tracing
+for N, D, Cr in ((10_000, 8, 4096), (100_000, 8, 1024)):
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(N, D)); w = rng.normal(size=D)
+    y = (rng.random(N) < 1.0 / (1.0 + np.exp(-X @ w))).astype(np.float64)
+
+    def logistic(q):
+        z = X @ q
+        return (y * z - tracing.softplus(z)).sum() - 0.5 * (q @ q) / 4.0
+
+    GLM = """
+template <class T> __device__ T aehmc_glm_loglik(T z, double y, long long n, const double *const *prm) { return y * z - softplus(z); }
+template <class T> __device__ T aehmc_glm_logprior(T q, long long i, const double *const *prm) { return -0.5 * q * q / 4.0; }
+"""
+    for form, tgt in (("python", targets.from_callable(logistic, D)),
+                      ("CustomGLM", targets.CustomGLM(GLM, torch.as_tensor(X, device="cuda"), torch.as_tensor(y, device="cuda")))):
+        q0 = torch.as_tensor(w + 0.1 * rng.standard_normal((Cr, D)), device="cuda")
+        imm = torch.ones(D, dtype=torch.float64, device="cuda")
+        eps = 0.3 / np.sqrt(N)
+        kernel = nuts.new_kernel(RandomStream(seeds=list(range(Cr))), tgt, max_num_expansions=6)
+        state = nuts.new_state(q0, tgt)
+        state = kernel.sample(state, eps, imm, 3, keep_samples=False)[1].state._replace(momentum=None)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        samples, info, acc, div = kernel.sample(state, eps, imm, 6, keep_samples=False)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        nl = int(info.n_leapfrog.sum())
+        print(f"logistic N={N} D={D} C={Cr} {form:9s}: {dt / 6 * 1e3:.2f} ms/transition, {nl / 6 / Cr:.1f} leapfrogs/chain, {nl / dt:.3e} leapfrog/s", flush=True)
