@@ -253,6 +253,12 @@ def from_callable(fn, dim, scalar=False, args=()):
     function instead of a Target (``as_target``)."""
     from . import tracing
     tr = tracing.trace(fn, dim, scalar=scalar, args=args)
+    try:  # the captured arrays are fixed from here on: on the device once (a host array would be hashed and uploaded per call)
+        import torch
+        if torch.cuda.is_available():
+            tr.params = [torch.as_tensor(p, dtype=torch.float64, device="cuda") for p in tr.params]
+    except ImportError:
+        pass
     tgt = (Custom(tr.source, params=tr.params, dim=tr.dim) if tr.elementwise
            else CustomJoint(tr.source, tr.dim, params=tr.params, grad_source=tr.grad_source))
     tgt.traced_from = fn

@@ -11,7 +11,8 @@ What a traced function may do with its argument (a scalar for a scalar position,
 numpy ufuncs ``exp log log1p expm1 sqrt sin cos tanh abs square power reciprocal negative maximum minimum logaddexp``
 ``scipy.special.erf`` and ``scipy.special.gammaln``; ``softplus`` and ``where`` from this module; comparisons (inside ``where`` only);
 ``.sum()`` / ``np.sum`` / ``.mean()``, ``@`` / ``np.dot`` (vector . vector, constant matrix @ vector, vector @ constant
-matrix); indexing and slicing with static bounds; iteration over a vector.  Anything else -- Python ``if`` on a traced
+matrix); indexing and slicing with static bounds, gathers through a constant integer array (``theta[group]``);
+iteration over a vector.  Anything else -- Python ``if`` on a traced
 value, ``float()``, ``math.exp``, fancy indexing -- raises ``TypeError`` at trace time and says what it was.
 """
 from __future__ import annotations
@@ -29,12 +30,14 @@ class TraceError(TypeError):
 
 # ------------------------------------------------------------------------------------------------------ indices
 class Idx:
-    """An affine index: const + sum coef * loop variable."""
+    """An index: const + sum coef * loop variable + sum coef * LOOKUP(k, inner index) -- the last form is a gather through
+    a constant integer array (parameter array k, stored as doubles): theta[group] with `group` a captured numpy array."""
 
-    __slots__ = ("c", "terms")
+    __slots__ = ("c", "terms", "ind")
 
-    def __init__(self, c=0, terms=()):
+    def __init__(self, c=0, terms=(), ind=()):
         self.c, self.terms = int(c), tuple(sorted((v, k) for v, k in terms if k != 0))
+        self.ind = tuple((int(a), int(k), i) for a, k, i in ind if a != 0)
 
     @staticmethod
     def var(v):
@@ -45,19 +48,29 @@ class Idx:
         d = dict(self.terms)
         for v, k in o.terms:
             d[v] = d.get(v, 0) + k
-        return Idx(self.c + o.c, d.items())
+        return Idx(self.c + o.c, d.items(), self.ind + o.ind)
 
     def __mul__(self, k):
-        return Idx(self.c * k, ((v, c * k) for v, c in self.terms))
+        return Idx(self.c * k, ((v, c * k) for v, c in self.terms), ((a * k, p, i) for a, p, i in self.ind))
 
     def key(self):
-        return (self.c, self.terms)
+        return (self.c, self.terms, tuple((a, k, i.key()) for a, k, i in self.ind))
 
     def is_var(self, v):
-        return self.c == 0 and self.terms == ((v, 1),)
+        return self.c == 0 and self.terms == ((v, 1),) and not self.ind
 
-    def code(self, names):
+    def vars(self):
+        out = frozenset(v for v, _ in self.terms)
+        for _, _, i in self.ind:
+            out |= i.vars()
+        return out
+
+    def code(self, names, par=None):
+        par = par or (lambda k: f"prm[{k}]")
         parts = [f"{names[v]}" if k == 1 else f"{k} * {names[v]}" for v, k in self.terms]
+        for a, k, i in self.ind:
+            look = f"(int){par(k)}[{i.code(names, par)}]"
+            parts.append(look if a == 1 else f"{a} * {look}")
         if self.c or not parts:
             parts.append(str(self.c))
         return " + ".join(parts)
@@ -373,7 +386,15 @@ class V:
             return V(self.ctx, m, lambda i: self.at(i * step + start), self.unroll)
         if k is Ellipsis:
             return self
-        raise TraceError(f"indexing a traced vector with {type(k).__name__}: only integers and slices with static bounds are supported")
+        if isinstance(k, (np.ndarray, list)) and not self.unroll:
+            ia = np.asarray(k)
+            if ia.ndim == 1 and ia.dtype.kind in "iu" and ia.size:
+                if ia.min() < -self.n or ia.max() >= self.n:
+                    raise IndexError(f"index array out of range for a vector of {self.n}")
+                kk = self.ctx.param((ia % self.n).astype(np.float64))  # a gather through a constant index array: theta[group]
+                return V(self.ctx, ia.size, lambda i: self.at(Idx(0, (), ((1, kk, i),))))
+        raise TraceError(f"indexing a traced vector with {type(k).__name__}: integers, slices with static bounds and constant "
+                         "integer arrays (gathers) are supported")
 
     def sum(self, axis=None):
         if self.n == 0:
@@ -537,10 +558,16 @@ class _Gen:
     def put(self, s):
         self.lines.append("  " * self.ind + s)
 
+    def par(self, k):
+        if self.par_local is not None:
+            self.par_local.add(k)
+            return f"prm{k}"
+        return f"prm[{k}]"
+
     def q(self, idx):
         if self.scalar or (self.elem_var is not None and idx.is_var(self.elem_var)):
             return "q"
-        return f"q[{idx.code(self.names)}]"
+        return f"q[{idx.code(self.names, self.par)}]"
 
     def ex(self, e):
         op, a = e.op, e.args
@@ -549,7 +576,7 @@ class _Gen:
         if op == "par":
             if self.par_local is not None:  # (the reverse-mode program reads its parameter arrays through local restrict pointers)
                 self.par_local.add(a[0])
-                return f"prm{a[0]}[{a[1].code(self.names)}]"
+                return f"prm{a[0]}[{a[1].code(self.names, self.par)}]"
             return f"prm[{a[0]}][{a[1].code(self.names)}]"
         if op == "q":
             return self.q(a[0])
@@ -601,7 +628,7 @@ def _elementwise_var(root, dim, scalar):
         if e.op == "q":
             return e.args[0].is_var(v)
         if e.op == "par":
-            return e.args[1].terms in ((), ((v, 1),))
+            return e.args[1].terms in ((), ((v, 1),)) and not e.args[1].ind
         if e.op == "sum":
             return False
         return all(ok(x) for x in e.args if isinstance(x, S))
@@ -631,9 +658,9 @@ _UN_BWD = {"exp": "{a} * {v}", "log": "{a} / {x}", "log1p": "{a} / (1.0 + {x})",
 def _free_vars(e):
     """loop variables an expression reads (those of sums inside it are bound there)"""
     if e.op in ("q",):
-        return frozenset(v for v, _ in e.args[0].terms)
+        return e.args[0].vars()
     if e.op == "par":
-        return frozenset(v for v, _ in e.args[1].terms)
+        return e.args[1].vars()
     if e.op == "sum":
         inner = _free_vars(e.args[2]) - {e.args[0]}
         for _, x in (e.args[3] if len(e.args) > 3 else ()):
@@ -699,6 +726,8 @@ def _private_leaves(e):
     def walk(x, inner):
         if x.op == "q":
             t = x.args[0].terms
+            if x.args[0].ind:  # a gather: added atomically
+                return True
             if len(t) == 1 and t[0][0] == v and t[0][1] != 0:
                 return True
             if len(t) == 1 and t[0][0] in inner and t[0][1] != 0 and inner[t[0][0]].args[1] <= PRIVATE_MAX:
@@ -769,9 +798,9 @@ class _RevGen:
             return _lit(a[0])
         if op == "par":
             self.used_params.add(a[0])
-            return f"prm{a[0]}[{a[1].code(self.names)}]"
+            return f"prm{a[0]}[{a[1].code(self.names, self.par)}]"
         if op == "q":
-            return f"q[{a[0].code(self.names)}]"
+            return f"q[{a[0].code(self.names, self.par)}]"
         if op == "ref":
             return env[("let", a[0])]
         if not e.t and op != "sum":  # parameters and constants only: inlined
@@ -809,6 +838,10 @@ class _RevGen:
         if id(e) in self.unrolled:
             self.put("#pragma unroll")
         return f"for (int {iv} = {'lane' if dist else '0'}; {iv} < {n}; {iv} {'+= AEHMC_LANES' if dist else '++'}) {{"
+
+    def par(self, k):
+        self.used_params.add(k)
+        return f"prm{k}"
 
     def has_inner_sum(self, e):
         return isinstance(e, S) and (e.op == "sum" or any(self.has_inner_sum(x) for x in e.args if isinstance(x, S)))
@@ -913,8 +946,13 @@ class _RevGen:
                 arr, inner = self.private[id(e)]
                 self.put(f"{arr}[{self.names[inner.args[0]]}] += {adj};")
                 return
-            tgt = f"g[{a[0].code(self.names)}]"
-            self.put(f"{tgt} += {adj};" if self.depth > 0 and self.lane_owned else f"if (lane == 0) {tgt} += {adj};")
+            tgt = f"g[{a[0].code(self.names, self.par)}]"
+            if a[0].ind and self.depth > 0 and self.lane_owned:
+                # a gather inside a distributed loop: several lanes may hold the same entry -- an atomic add into the LDS row
+                # (the order of the additions of one wavefront instruction is the hardware's: rounding-level effects only)
+                self.put(f"AEHMC_ATOMIC_ADD(&{tgt}, {adj});")
+            else:
+                self.put(f"{tgt} += {adj};" if self.depth > 0 and self.lane_owned else f"if (lane == 0) {tgt} += {adj};")
         elif op == "ref":
             self.put(f"ah{a[0]} += {adj};")
         elif op == "neg":
@@ -1021,13 +1059,14 @@ class _RevGen:
 
 
 _REV_PRELUDE = """
-#ifndef AEHMC_LANES  /* (plain C++ builds for the CPU tests define AEHMC_LANES 1 and AEHMC_WSUM(x) (x)) */
+#ifndef AEHMC_LANES  /* (plain C++ builds for the CPU tests define AEHMC_LANES 1, AEHMC_WSUM(x) (x), AEHMC_ATOMIC_ADD(p, v) (*(p) += (v))) */
 #define AEHMC_LANES 64
 __device__ inline double aehmc_wsum_(double x) {  // xor butterfly: a + b == b + a bit for bit, so every lane ends with the same bits
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
   return x;
 }
 #define AEHMC_WSUM(x) aehmc_wsum_(x)
+#define AEHMC_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #endif
 __device__ inline double aehmc_sq(double x) { return x * x; }
 __device__ inline double aehmc_softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }

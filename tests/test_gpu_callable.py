@@ -289,6 +289,59 @@ template <class T> __device__ T aehmc_glm_logprior(T q, long long i, const doubl
             assert bool(info.is_turning[c]) == bool(o.is_turning) and bool(info.is_diverging[c]) == bool(o.is_diverging)
 
 
+@pytest.mark.parametrize("G, N", [(10, 1000), (200, 5000)])
+def test_hierarchical_model_with_a_gather_as_a_python_function(G, N):
+    """Random effects by group -- theta[group] with `group` a captured integer array (a gather; its adjoint is a scatter
+    with LDS atomics inside the loop over the observations) -- with G + 2 coordinates: 12 (forward-mode kernels' size, but
+    the reverse-mode program is taken for the 1000-term reductions) and 202 (reverse mode on the joint-rows kernels)."""
+    from aehmc_amd import RandomStream, nuts, targets
+    r = np.random.default_rng(G)
+    group = r.integers(0, G, size=N)
+    y = r.normal(size=N) + 0.5 * r.normal(size=G)[group]
+
+    def logprob_fn(q):
+        mu, lt, theta = q[0], q[1], q[2:]
+        tau2 = np.exp(2.0 * lt)
+        res = y - theta[group]
+        return -0.5 * mu * mu / 25.0 + lt - 0.5 * tau2 / 4.0 - G * lt - 0.5 * np.sum((theta - mu) ** 2) / tau2 - 0.5 * np.sum(res * res)
+
+    def grad(q):
+        mu, lt, theta = q[0], q[1], q[2:]
+        tau2 = np.exp(2.0 * lt)
+        res = y - theta[group]
+        g = np.empty_like(q)
+        g[0] = -mu / 25.0 + np.sum(theta - mu) / tau2
+        g[1] = 1.0 - tau2 / 4.0 - G + np.sum((theta - mu) ** 2) / tau2
+        g[2:] = -(theta - mu) / tau2 + np.bincount(group, weights=res, minlength=G)
+        return g
+
+    D = G + 2
+    tgt = targets.as_target(logprob_fn, D)
+    assert isinstance(tgt, targets.CustomJoint) and "AEHMC_ATOMIC_ADD(&g[" in tgt.source
+    otgt = NumpyTarget(logprob_fn, grad)
+    C, eps = 3, 0.02
+    q0 = 0.3 * r.normal(size=(C, D))
+    state = nuts.new_state(dev(q0), logprob_fn)
+    for c in range(C):
+        U, g = otgt(q0[c])
+        np.testing.assert_allclose(state.potential_energy[c].item(), U, rtol=1e-12)
+        np.testing.assert_allclose(state.potential_energy_grad[c].cpu().numpy(), g, rtol=1e-10, atol=1e-10)
+    seeds = [5 + c for c in range(C)]
+    kern = nuts.new_kernel(RandomStream(seeds=seeds), logprob_fn, max_num_expansions=4)
+    okern = [no.nuts_kernel(no.RandomStream(sd), otgt, max_num_expansions=4) for sd in seeds]
+    ostate = [no.new_state(q0[c].copy(), otgt) for c in range(C)]
+    for _ in range(2):
+        info, _ = kern(state, eps, np.ones(D))
+        state = info.state._replace(momentum=None)
+        for c in range(C):
+            o = okern[c](ostate[c], eps, np.ones(D))
+            ostate[c] = o.state._replace(momentum=None)
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-11)
+            np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL)
+            assert info.n_leapfrog[c].item() == o.n_leapfrog and info.num_doublings[c].item() == o.num_doublings
+            assert bool(info.is_turning[c]) == bool(o.is_turning) and bool(info.is_diverging[c]) == bool(o.is_diverging)
+
+
 def test_python_logprob_fn_under_window_adaptation_and_sample():
     from aehmc_amd import RandomStream, nuts, window_adaptation
     C, D = 64, 10

@@ -67,7 +67,19 @@ def shared_under_where(q):  # a shared sub-expression with a use inside a where-
     return np.sum(tracing.where(q[:3] > 0.1, u * q[3:6], -u) + np.sin(u)) - 0.5 * np.sum(q * q)
 
 
-CASES = {"student_t": (student_t, 7, True), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False),
+GROUP = R.integers(0, 7, size=120)
+YG = R.normal(size=120) + GROUP * 0.3
+
+
+def hierarchical(q):  # random effects by group: theta[group] is a gather through a captured integer array
+    mu, lt, theta = q[0], q[1], q[2:]
+    tau = np.exp(lt)
+    r = YG - theta[GROUP]
+    return (-0.5 * mu * mu / 25.0 + lt - 0.5 * tau * tau / 4.0 - 7 * lt - 0.5 * np.sum((theta - mu) ** 2) / (tau * tau)
+            - 0.5 * np.sum(r * r) + np.sum(np.tanh(q[2:][GROUP[:30]]) * YG[:30]))
+
+
+CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False),
          "shared_under_where": (shared_under_where, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
          "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
 
@@ -110,6 +122,7 @@ REV_HARNESS = r"""
 #define __device__
 #define AEHMC_LANES 1
 #define AEHMC_WSUM(x) (x)
+#define AEHMC_ATOMIC_ADD(p, v) (*(p) += (v))
 #include "dual.cuh"
 %(source)s
 %(params)s
@@ -192,6 +205,11 @@ def random_density(seed, D):
     return fn
 
 
+def test_gather_index_out_of_range_is_an_indexerror():
+    with pytest.raises(IndexError, match="out of range"):
+        tracing.trace(lambda q: q[np.array([0, 5])].sum(), 3)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_reverse_mode_equals_forward_mode_on_random_densities(seed, tmp_path):
     """forward- and reverse-mode gradients equal to 1e-12 on random densities (both compiled as plain
@@ -238,7 +256,7 @@ def test_targets_from_callable_picks_the_target_class():
     (lambda q: np.arctan(q).sum(), "numpy.arctan is not supported"),
     (lambda q: q * 2.0, "must return a scalar"),
     (lambda q: 1.0, "does not depend on the position"),
-    (lambda q: q[np.array([0, 1])].sum(), "only integers and slices"),
+    (lambda q: q[np.array([0.5, 1.0])].sum(), "integer arrays"),
     (lambda q: (q > 0).sum(), "comparison"),
     (lambda q: np.cumsum(q)[-1], "numpy.cumsum is not supported"),
     (lambda q: (q[:2] + q).sum(), "do not broadcast"),
