@@ -417,6 +417,42 @@ template <class T> __device__ T aehmc_logp(T q, long long i, const double *const
         return [{"config": f"custom-student-t-nuts-d{D}", "error": repr(e)[:300]}]
 
 
+def traced_secondary(eng, device, D=1000, C=4096, T=5):
+    """Neal's funnel written as a PYTHON logprob_fn (round 6: traced by aehmc_amd/tracing.py, differentiated in ONE reverse
+    sweep whose loops run over the lanes of the chain's wavefront) on the one-launch joint kernel -- VERDICT r5 item 5's
+    shape (D = 1000, 4096 chains; the hand-written HIP template in forward mode: 1.0e6 leapfrog/s).  The kernel runs the
+    lock-step engine's own stage / bookkeeping functions on L2 / HBM rows: 88 D bytes per leapfrog and chain (SURVEY 8d's
+    streaming NUTS figure) against the HBM peak."""
+    from aehmc_amd import RandomStream, nuts, targets
+    try:
+        def funnel(q):
+            v, x = q[0], q[1:]
+            return -v * v / 18.0 + (-0.5 * x * x * np.exp(-v) - 0.5 * v).sum()
+
+        r = np.random.default_rng(D)
+        tgt = targets.from_callable(funnel, D)
+        q0 = torch.as_tensor(0.3 * r.standard_normal((C, D)), device=device)
+        imm = torch.ones(D, dtype=torch.float64, device=device)
+        kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=6)
+        state = nuts.new_state(q0, tgt)
+        state = kernel.sample(state, 0.05, imm, 2, keep_samples=False)[1].state._replace(momentum=None)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        _, info, _, _ = kernel.sample(state, 0.05, imm, T, keep_samples=False)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        nl = int(info.n_leapfrog.sum().item())
+        gbs = nl / dt * 88.0 * D / 1e9
+        return [{"config": f"python-funnel-nuts-d{D}",
+                 "workload": f"Neal's funnel, {D} coordinates, as a Python function (traced, reverse-mode gradient), diagonal mass, NUTS depth 6, {C} chains",
+                 "value": nl / dt, "unit": "leapfrog-steps/s", "ms_per_transition": dt / T * 1e3,
+                 "kernel": "k_nuts_joint_rows (hipRTC) + generated aehmc_logp_grad",
+                 "roofline": {"bound": "hbm", "unit": "GB/s", "achieved": gbs, "peak": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS,
+                              "traffic": None, "launches": 1}}]
+    except Exception as e:  # a failing side measurement must not cost the main line
+        return [{"config": f"python-funnel-nuts-d{D}", "error": repr(e)[:300]}]
+
+
 def launch_ranks(n, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one process per
     GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches
@@ -696,6 +732,7 @@ def main():
         secondary += dense_mid_secondary(eng, device)
         secondary += pc_dense_secondary(eng, device)
         secondary += custom_secondary(eng, device)
+        secondary += traced_secondary(eng, device)
         torch.cuda.empty_cache()
         secondary += other_configs()
 
