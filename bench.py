@@ -86,7 +86,7 @@ def emit(obj, verbose=False):
         # `traffic_source` is always profiles/<round>/<config>_pmc_summary.json; long counter dicts shrink to the figures
         # the roofline argument uses; only then the prose (`workload`: the `config` names say which) and the rest
         for drop in ("<short counters_dropped>", "traffic_source", "<long counters>", "streaming_bytes_per_transition", "algorithmic_l2_bytes_per_launch",
-                     "algorithmic_flops_per_launch", "whole_call_leapfrogs_per_s", "workload", "counters", "hbm", "valu", "fp64_flops", "launches", "avg_launch_ms"):
+                     "algorithmic_flops_per_launch", "whole_call_leapfrogs_per_s", "kernel", "issued_ops_per_elem", "workload", "counters", "hbm", "valu", "fp64_flops", "launches", "avg_launch_ms"):
             for e in obj["secondary"]:
                 roof = e.get("roofline") if isinstance(e.get("roofline"), dict) else {}
                 if drop == "<short counters_dropped>":  # (the top-level roofline keeps the full sentence)
@@ -252,7 +252,7 @@ def bench_secondary(eng, device, steps, warmup, D=10_000, C=4096):
             peak_ops = 256 * 4 * 16 * 2.4e9 / 1e12
             per_elem = 2.0 if fc else 6.0
             ops = nl / dt * 6.0 * D / 1e12
-            roof = {"bound": "valu", "unit": "Tlane-op/s (fp64, 6 D algorithmic operations per leapfrog)", "achieved": ops,
+            roof = {"bound": "valu", "unit": "Tlane-op/s (fp64, 6 D per leapfrog)", "achieved": ops,
                     "peak": peak_ops, "frac": ops / peak_ops, "issued_ops_per_elem": per_elem,
                     "kernel": main_kernel + " (+ k_draw_momentum)", "avg_launch_ms": avg_ms, "launches": kern_n * per_call,
                     "traffic": traffic, "traffic_source": pmc_src if traffic else None, "hbm": hbm,
@@ -410,7 +410,7 @@ template <class T> __device__ T aehmc_logp(T q, long long i, const double *const
                  "builtin_over_custom": out["builtin"] / out["custom"], "kernel": "k_nuts_wide<512,16,LDS,custom> (hipRTC)",
                  # the pass is bound by VALU issue: 6 operations of the leapfrog + 9 of the density and its derivative (one of
                  # them the log1p, ~25 issued instructions) per element and leapfrog, against the fp64 lane-operation rate
-                 "roofline": {"bound": "valu", "unit": "Tlane-op/s (fp64, 15 D algorithmic operations per leapfrog)",
+                 "roofline": {"bound": "valu", "unit": "Tlane-op/s (fp64, 15 D per leapfrog)",
                               "achieved": out["custom"] * 15.0 * D / 1e12, "peak": 256 * 4 * 16 * 2.4e9 / 1e12,
                               "frac": out["custom"] * 15.0 * D / 1e12 / (256 * 4 * 16 * 2.4e9 / 1e12), "launches": T}}]
     except Exception as e:  # a failing side measurement must not cost the main line
@@ -444,7 +444,7 @@ def traced_secondary(eng, device, D=1000, C=4096, T=5):
         nl = int(info.n_leapfrog.sum().item())
         gbs = nl / dt * 88.0 * D / 1e9
         return [{"config": f"python-funnel-nuts-d{D}",
-                 "workload": f"Neal's funnel, {D} coordinates, as a Python function (traced, reverse-mode gradient), diagonal mass, NUTS depth 6, {C} chains",
+                 "workload": f"{D}-dim Neal's funnel as a Python function (traced, reverse-mode gradient), NUTS depth 6, {C} chains",
                  "value": nl / dt, "unit": "leapfrog-steps/s", "ms_per_transition": dt / T * 1e3,
                  "kernel": "k_nuts_joint_rows (hipRTC) + generated aehmc_logp_grad",
                  "roofline": {"bound": "hbm", "unit": "GB/s", "achieved": gbs, "peak": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS,
