@@ -902,15 +902,14 @@ class _RevGen:
         self.uses, self.cond = {}, set()
 
         def go(e, cond):
-            if not isinstance(e, S) or not e.t or e.op in ("q", "ref", "const", "par"):
-                return
+            if not isinstance(e, S) or not e.t or e.op in ("q", "ref", "const", "par", "cmp"):
+                return  # (a comparison passes no adjoint on: its operands' uses there do not count)
             if cond:
                 self.cond.add(id(e))
             self.uses[id(e)] = self.uses.get(id(e), 0) + 1
             if self.uses[id(e)] > 1 and not cond:
                 return
             if e.op == "where":
-                go(e.args[0], cond)
                 go(e.args[1], True)
                 go(e.args[2], True)
             elif e.op == "sum":

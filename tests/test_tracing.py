@@ -79,7 +79,12 @@ def hierarchical(q):  # random effects by group: theta[group] is a gather throug
             - 0.5 * np.sum(r * r) + np.sum(np.tanh(q[2:][GROUP[:30]]) * YG[:30]))
 
 
-CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False),
+def shared_in_comparison(q):  # a shared node whose other use is a comparison only (which passes no adjoint on)
+    z = XL[:40] @ q
+    return np.sum(tracing.where(z > 0.1, YL[:40], -YL[:40]) * 0.3 + z * z) + np.sum(tracing.where(q > 0.0, 1.0, 2.0) * q)
+
+
+CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False),
          "shared_under_where": (shared_under_where, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
          "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
 
