@@ -1275,6 +1275,134 @@ __global__ __launch_bounds__(256) void k_hmc_joint_rows(EngineArgs a, long long 
     pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
   }
 }
+#ifdef AEHMC_JOINT_GRAD
+// ---- a WORKGROUP per chain (round 6): a traced density whose reductions sweep long data (a regression over 10^5 rows) and
+// a call with fewer chains than the GPU has SIMDs.  With a wavefront per chain 1024 chains are one wavefront per SIMD,
+// each walking all the rows (latency-bound: profiles/r6/INDEX.md); here W wavefronts run the generated program together
+// (aehmc_logp_grad_t<W>: loops over 64 W lanes, sums through LDS) while wavefront 0 runs the lock-step engine's stage /
+// bookkeeping functions of the chain between the evaluations.  Same functions in the same order as k_nuts_joint_rows;
+// the density's sums are associated differently (64 W partial sums), results agree to rounding.
+template <int W>
+__device__ inline double joint_wg_eval(const EngineArgs &a, const double *q, double *g, double *qr, int tid) {
+  const int D = (int)a.D;
+  double *const gr = qr + D;
+  for (int i = tid; i < D; i += 64 * W) {
+    qr[i] = q[i];
+    gr[i] = 0.0;
+  }
+  __syncthreads();
+  const double lp = aehmc_logp_grad_t<W>(qr, gr, tid, a.cparams);
+  __syncthreads();
+  for (int i = tid; i < D; i += 64 * W) g[i] = -gr[i];
+  __threadfence_block();  // (wavefront 0 reads the row behind the caller's barrier)
+  return -lp;
+}
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_nuts_joint_wg(EngineArgs a, NutsSampleArgs m) {
+  extern __shared__ __attribute__((aligned(16))) double joint_rows[];
+  __shared__ int wg_done;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool leader = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+  const long long c = blockIdx.x;
+  double *const qr = joint_rows;
+  const size_t row = (size_t)c * a.D;
+  ChainRng rng = rng_load(a, c);
+  ChainCtl ct = {};
+  double U_state = a.U[c];
+  long long nleap_sum = 0;
+  for (long long t_idx = 0; t_idx < m.T; t_idx++) {
+    if (leader) {
+      draw_momentum<false>(a, c, lane, rng.g[0]);
+      nuts_init_chain<false>(a, c, lane, ct, rng, &U_state);
+    }
+    for (;;) {
+      double U_new = 0.0;
+      if (leader) {
+        leap_stages<true, true, false, false>(a, c, lane, ct.dir, U_new);  // p_half, q'
+        __threadfence_block();
+      }
+      __syncthreads();
+      const double Uv = joint_wg_eval<W>(a, a.cur_q + row, a.cur_g + row, qr, tid);
+      __syncthreads();
+      if (leader) {
+        ct.U_cur = Uv;
+        leap_stages<false, false, true, false>(a, c, lane, ct.dir, U_new);  // p' = p_half - b dU/dq'
+        nuts_book<false>(a, c, lane, ct, rng);
+        if (lane == 0) wg_done = ct.done;
+      }
+      __syncthreads();
+      if (wg_done) break;
+    }
+    if (leader) {
+      U_state = pick2(ct.U_slot, ct.prop_slot);
+      nleap_sum += ct.nleap;
+      __threadfence_block();
+      if (m.samples) {
+        double *dst = m.samples + ((size_t)t_idx * a.C + c) * a.D;
+        for (long long i = lane; i < a.D; i += 64) dst[i] = a.q[row + i];
+      }
+      if (lane == 0) {
+        if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
+        if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
+      }
+    }
+  }
+  if (leader) {
+    rng_store(a, c, lane, rng, 0, 3);
+    if (lane == 0 && m.nleap_total) m.nleap_total[c] = nleap_sum;
+  }
+}
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_hmc_joint_wg(EngineArgs a, long long L, long long nt, double *samples,
+                                                         double *acc_hist, int *div_hist) {
+  extern __shared__ __attribute__((aligned(16))) double joint_rows[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool leader = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+  const long long c = blockIdx.x;
+  double *const qr = joint_rows;
+  const size_t row = (size_t)c * a.D;
+  Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4), g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
+  double U_state = a.U[c];
+  for (long long tt = 0; tt < nt; tt++) {
+    ChainCtl ct = {};
+    if (leader) {
+      draw_momentum<false>(a, c, lane, g1);
+      ct = hmc_init_chain<false>(a, c, lane, &U_state);
+    }
+    for (long long l = 0; l < L; l++) {  // trajectory.py:86-95
+      double U_new = 0.0;
+      if (leader) {
+        leap_stages<true, true, false, false>(a, c, lane, 1, U_new);
+        __threadfence_block();
+      }
+      __syncthreads();
+      const double Uv = joint_wg_eval<W>(a, a.cur_q + row, a.cur_g + row, qr, tid);
+      __syncthreads();
+      if (leader) {
+        ct.U_cur = Uv;
+        leap_stages<false, false, true, false>(a, c, lane, 1, U_new);
+      }
+    }
+    if (leader) {
+      __threadfence_block();
+      const HmcEnd e = hmc_end_chain_rng<false>(a, c, lane, ct, L, g2);
+      if (e.acc) U_state = ct.U_cur;
+      if (samples) {
+        double *dst = samples + ((size_t)tt * a.C + c) * a.D;
+        for (long long i = lane; i < a.D; i += 64) dst[i] = a.q[row + i];
+      }
+      if (lane == 0) {
+        if (acc_hist) acc_hist[(size_t)tt * a.C + c] = e.pa;
+        if (div_hist) div_hist[(size_t)tt * a.C + c] = e.is_div;
+      }
+    }
+  }
+  if (leader && lane == 0) {
+    pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
+    pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
+  }
+}
+#endif  // AEHMC_JOINT_GRAD
 #endif
 AEHMC_TU_LOCAL __global__ __launch_bounds__(256) void k_residual(EngineArgs a, const double *q, double *r) {
   AEHMC_CHAIN_OF_WAVE();

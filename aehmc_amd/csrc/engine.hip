@@ -62,6 +62,7 @@ struct aehmc_ctx {
   bool opt_dense_linear = true;  // one metric GEMM per leapfrog (v carried by linearity)
   bool opt_compact = true;       // finished chains drop out of the GEMMs
   int opt_block_roll = 0;        // block-resident NUTS: waiting chains that trigger a begin round (0: kernel default)
+  int opt_joint_wg = 1;          // traced joint densities with long sweeps: a workgroup per chain (0 never, 1 when it pays, 2 always)
   bool opt_pc_dense = true;      // per-chain dense metrics, 64 < D <= 512: NUTS in one launch, a wavefront per chain streams its matrix
   int opt_block_dense = 1;       // mid-size dense problems (64 < D <= 512): one workgroup per 16 chains, whole call in one launch
                                  // (1: chain state in registers up to D = 256, in L2-resident work rows above; 2: always work rows)
@@ -505,6 +506,16 @@ extern "C" int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, i
   return 0;
 }
 
+// a workgroup of 8 wavefronts per chain (engine.cuh: k_nuts_joint_wg): traced densities with long data sweeps, few chains
+static const std::vector<std::string> RTC_JWG = {"aehmc::k_nuts_joint_wg<8>", "aehmc::k_hmc_joint_wg<8>"};
+static bool joint_wg_wanted(const aehmc_ctx *ctx, int64_t C) {
+  if (!ctx->opt_joint_wg) return false;
+  const size_t at = ctx->custom_src.find("#define AEHMC_JOINT_SWEEP_TERMS ");
+  if (at == std::string::npos) return false;
+  const long long terms = atoll(ctx->custom_src.c_str() + at + 32);
+  // (a wavefront per chain fills the GPU's 1024 SIMDs twice over at 2048 chains; a sweep of < 8192 terms is < 128 trips of a wavefront)
+  return ctx->opt_joint_wg > 1 || (terms >= 8192 && C <= 2048);
+}
 static const std::vector<std::string> RTC_JBASE = {"aehmc::k_new_state_joint", "aehmc::k_target_joint_rows", "aehmc::k_nuts_joint_rows",
                                                    "aehmc::k_hmc_joint_rows"};
 extern "C" int aehmc_set_custom_joint_target(aehmc_ctx *ctx, const char *source, int64_t D, const double *const *params,
@@ -845,6 +856,11 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
   }
   if (!strcmp(name, "fp_contract")) {
     ctx->opt_fp_contract = value != 0;
+    return 0;
+  }
+  if (!strcmp(name, "joint_wg")) {
+    if (value < 0 || value > 2) FAIL("joint_wg: 0 (never), 1 (default: when it pays), 2 (always)");
+    ctx->opt_joint_wg = (int)value;
     return 0;
   }
   FAIL(std::string("unknown option ") + name);
@@ -1234,7 +1250,7 @@ extern "C" int aehmc_new_state(aehmc_ctx *ctx, int64_t C, const double *q, doubl
 // which kernel family a NUTS call takes (one place: aehmc_nuts_warmup asks before it commits to a
 // single-launch warm-up)
 enum { NUTS_PATH_LOCKSTEP = 0, NUTS_PATH_LINREG, NUTS_PATH_TEAMS, NUTS_PATH_WIDE, NUTS_PATH_FUSED_DENSE,
-       NUTS_PATH_BLOCK_DENSE, NUTS_PATH_PC_DENSE, NUTS_PATH_JOINT_ROWS, NUTS_PATH_GLM_ROWS };
+       NUTS_PATH_BLOCK_DENSE, NUTS_PATH_PC_DENSE, NUTS_PATH_JOINT_ROWS, NUTS_PATH_GLM_ROWS, NUTS_PATH_JOINT_WG };
 // user-defined row-reduction target with few coordinates: the one-launch kernels of glm_rows.cuh keep D partial sums per lane
 constexpr int GLM_ROWS_MAX_D = 32;
 // Where they pay (tools/debug/glm_time.py, logistic regression; profiles/r5/INDEX.md): the sweep is bound by the user's row
@@ -1284,6 +1300,8 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   if (want_resident && nuts_wide_supported(tkind, nd, D)) return NUTS_PATH_WIDE;
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): one launch, the products
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
+  // a traced joint density with long data sweeps and few chains: a workgroup per chain (k_nuts_joint_wg, run-time compiled)
+  if (want_resident && tkind == AEHMC_T_JOINT && nd < 2 && joint_wg_wanted(ctx, C)) return NUTS_PATH_JOINT_WG;
   if (want_resident && tkind == AEHMC_T_JOINT && D <= FUSED_DENSE_MAX_D) return NUTS_PATH_FUSED_DENSE;  // (run-time compiled)
   if (want_resident && tkind == AEHMC_T_GLM && nd < 2 && glm_rows_wanted(D, C)) return NUTS_PATH_GLM_ROWS;  // (run-time compiled)
   // joint target of more than 64 coordinates, scalar / diagonal metric: the lock-step loop of a chain in one wavefront,
@@ -1448,6 +1466,19 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     if (int rc = prof_begin(ctx, st, p)) return rc;
     if (int rc = rtc_launch(ctx, "glmk", {name}, name, chain_grid(C), dim3(256), 0, st, a, m, (const double *)ctx->glm_XT,
                             ctx->glm_y, (long long)ctx->glm_N))
+      return rc;
+    return prof_end(ctx, st, p);
+  }
+  if (path == NUTS_PATH_JOINT_WG) {  // traced joint density, long sweeps, few chains: a workgroup per chain, one launch per call
+    NutsSampleArgs m{};
+    m.T = 1;
+    if (multi && multi_done && !multi->adapt) {
+      m = *multi;
+      *multi_done = true;
+    }
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (int rc = rtc_launch(ctx, "jwg", RTC_JWG, RTC_JWG[0], dim3((unsigned)C), dim3(512), (size_t)2 * a.D * sizeof(double), st, a, m))
       return rc;
     return prof_end(ctx, st, p);
   }
@@ -1773,7 +1804,7 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   // small dense problems (shared dense metric and / or dense-precision target, D <= 64): the transition in one
   // launch with the products inside the wavefront (k_hmc_fused_dense), as for NUTS
   const bool tjoint = a.tkind == AEHMC_T_JOINT;
-  const bool fused_dense = ctx->opt_fused_hmc && D <= FUSED_DENSE_MAX_D &&
+  const bool fused_dense = ctx->opt_fused_hmc && D <= FUSED_DENSE_MAX_D && !(tjoint && a.met_ndim < 2 && joint_wg_wanted(ctx, C)) &&
                            (tjoint || ((a.met_ndim == 2 || a.tkind == AEHMC_T_DENSE_MVN) &&
                                        (target_is_elem_host(a.tkind) || a.tkind == AEHMC_T_DENSE_MVN)));
   if (fused_dense) {  // all T transitions in one launch
@@ -1819,6 +1850,17 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     if (int rc = prof_begin(ctx, st, p)) return rc;
     if (int rc = rtc_launch(ctx, "glmk", {name}, name, chain_grid(C), dim3(256), 0, st, a, (long long)L, (long long)T, samples, acc_hist,
                             (int *)div_hist, (const double *)ctx->glm_XT, ctx->glm_y, (long long)ctx->glm_N))
+      return rc;
+    if (int rc = prof_end(ctx, st, p)) return rc;
+    if (out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));
+    return 0;
+  }
+  // traced joint density with long data sweeps, few chains: a workgroup per chain (k_hmc_joint_wg)
+  if (ctx->opt_fused_hmc && tjoint && a.met_ndim < 2 && joint_wg_wanted(ctx, C)) {
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (int rc = rtc_launch(ctx, "jwg", RTC_JWG, RTC_JWG[1], dim3((unsigned)C), dim3(512), (size_t)2 * D * sizeof(double), st, a,
+                            (long long)L, (long long)T, samples, acc_hist, (int *)div_hist))
       return rc;
     if (int rc = prof_end(ctx, st, p)) return rc;
     if (out->n_leapfrog) LAUNCH(k_fill_i64, C, st, (long long *)out->n_leapfrog, (long long)C, (long long)(L * T));

@@ -862,6 +862,8 @@ class _RevGen:
             for k, x in lets:
                 self.put(f"double ah{k} = 0.0;")
             self.private_declare(priv)
+        if fused and dist:
+            self.put("AEHMC_SYNC();")  # (gradient entries change owner between loops when several wavefronts run the program)
         self.put(self.loop_head(e, dist))
         self.ind += 1
         self.depth += 1
@@ -874,6 +876,8 @@ class _RevGen:
         self.depth -= 1
         self.ind -= 1
         self.put("}")
+        if fused and dist:
+            self.put("AEHMC_SYNC();")
         if dist:
             self.put(f"{acc} = AEHMC_WSUM({acc});")
         if fused:
@@ -1006,6 +1010,8 @@ class _RevGen:
             self.private_declare(env.get(("priv", id(e)), []))
             if adj[0] not in "at" or not adj[1:].isdigit():  # (an expression: named once, outside the loop)
                 adj = self.let(adj, "a")
+            if dist:
+                self.put("AEHMC_SYNC();")
             self.put(self.loop_head(e, dist))
             self.ind += 1
             self.depth += 1
@@ -1019,6 +1025,8 @@ class _RevGen:
             self.depth -= 1
             self.ind -= 1
             self.put("}")
+            if dist:
+                self.put("AEHMC_SYNC();")
             self.private_reduce(env.get(("priv", id(e)), []))
             for k, x in reversed(lets):
                 if dist:
@@ -1058,21 +1066,37 @@ class _RevGen:
 
 
 _REV_PRELUDE = """
-#ifndef AEHMC_LANES  /* (plain C++ builds for the CPU tests define AEHMC_LANES 1, AEHMC_WSUM(x) (x), AEHMC_ATOMIC_ADD(p, v) (*(p) += (v))) */
-#define AEHMC_LANES 64
-__device__ inline double aehmc_wsum_(double x) {  // xor butterfly: a + b == b + a bit for bit, so every lane ends with the same bits
+#ifndef AEHMC_LANES  /* (plain C++ builds for the CPU tests define AEHMC_LANES 1, AEHMC_WSUM(x) (x), AEHMC_SYNC(), AEHMC_ATOMIC_ADD(p, v) (*(p) += (v))) */
+// AEHMC_W wavefronts run the program together (1: the chain's wavefront; 8: a workgroup per chain, engine.cuh k_nuts_joint_wg)
+template <int W> __device__ inline double aehmc_wsum_(double x) {  // xor butterfly: a + b == b + a bit for bit, so every lane ends with the same bits
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+  if (W > 1) {  // the wavefronts' sums through LDS, added in wavefront order by every thread
+    __shared__ double aehmc_part[16];
+    __syncthreads();  // (the reads of the previous reduction are done)
+    if ((threadIdx.x & 63) == 0) aehmc_part[threadIdx.x >> 6] = x;
+    __syncthreads();
+    x = aehmc_part[0];
+    for (int w = 1; w < W; w++) x += aehmc_part[w];
+  }
   return x;
 }
-#define AEHMC_WSUM(x) aehmc_wsum_(x)
+#define AEHMC_LANES (64 * AEHMC_W)
+#define AEHMC_WSUM(x) aehmc_wsum_<AEHMC_W>(x)
+#define AEHMC_SYNC() do { if (AEHMC_W > 1) __syncthreads(); } while (0)
 #define AEHMC_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #endif
 __device__ inline double aehmc_sq(double x) { return x * x; }
 __device__ inline double aehmc_softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 #define AEHMC_JOINT_GRAD 1
-// log-density and its gradient in one reverse sweep, run by the chain's wavefront: q = the position row, g = the gradient
-// row (both in LDS; g zeroed by the caller); every lane returns the same log-density
-__device__ double aehmc_logp_grad(const double *q, double *g, int lane, const double *const *prm) {
+// log-density and its gradient in one reverse sweep, run by AEHMC_W wavefronts together (`lane` = the thread's index among
+// their 64 AEHMC_W lanes): q = the position row, g = the gradient row (both in LDS; g zeroed by the caller); every lane
+// returns the same log-density
+template <int AEHMC_W> __device__ double aehmc_logp_grad_t(const double *q, double *g, int lane, const double *const *prm) {
+"""
+_REV_EPILOGUE = """
+__device__ inline double aehmc_logp_grad(const double *q, double *g, int lane, const double *const *prm) {
+  return aehmc_logp_grad_t<1>(q, g, lane, prm);
+}
 """
 
 
@@ -1095,7 +1119,10 @@ def _reverse_source(root, dim):
         raise AssertionError
     gen.bwd(tree, "1.0", env)
     ptrs = "".join(f"  const double *__restrict__ const prm{k} = prm[{k}];\n" for k in sorted(gen.used_params))
-    src = _REV_PRELUDE + ptrs + "\n".join(gen.lines) + f"\n  return {val};\n}}\n"
+    src = _REV_PRELUDE + ptrs + "\n".join(gen.lines) + f"\n  return {val};\n}}\n" + _REV_EPILOGUE
+    # how many loop iterations the program spreads over its lanes: with few chains and long sweeps the engine gives a
+    # chain a whole workgroup (engine.hip: joint_wg_wanted)
+    src += f"#define AEHMC_JOINT_SWEEP_TERMS {_distributed_terms(tree)}\n"
     # up to 64 coordinates the engine's one-launch kernels differentiate in forward mode, every lane running the whole
     # density for its own coordinate: right for a funnel, 64 times too much for a sum over 10^4 data rows
     if dim <= 64 and _distributed_terms(tree) >= 256:

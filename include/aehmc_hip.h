@@ -241,7 +241,12 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   static trajectory merged -- 2 fp64 operations per element and leapfrog instead of 6.
  *                   The integrator of integrators.py:54-73 within 1e-6 relative (the north star's bar);
  *                   0 (default) rounds every product and sum as the reference does and is bit-identical
- *                   to the oracle.  Momentum draw, energies and accept step are the same code in both modes */
+ *                   to the oracle.  Momentum draw, energies and accept step are the same code in both modes
+ *  "joint_wg"    1  joint user-defined density that comes with its reverse-mode program (AEHMC_JOINT_GRAD) and sweeps
+ *                   long data (AEHMC_JOINT_SWEEP_TERMS >= 8192) in a call of <= 2048 chains: a WORKGROUP of eight
+ *                   wavefronts per chain runs the program (k_nuts_joint_wg / k_hmc_joint_wg); 0 = never (a wavefront
+ *                   per chain), 2 = always.  Discrete outputs identical, values to rounding (the sums are associated
+ *                   differently) */
 int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value);
 
 /* workspace the caller must provide to the step calls for C chains */

@@ -342,6 +342,42 @@ def test_hierarchical_model_with_a_gather_as_a_python_function(G, N):
             assert bool(info.is_turning[c]) == bool(o.is_turning) and bool(info.is_diverging[c]) == bool(o.is_diverging)
 
 
+def test_workgroup_per_chain_kernels_agree_with_the_wavefront_per_chain_ones(regression_data):
+    """A traced density with long data sweeps and few chains runs with a WORKGROUP per chain (k_nuts_joint_wg /
+    k_hmc_joint_wg: eight wavefronts run the generated program together); engine option joint_wg = 0 keeps the wavefront
+    per chain.  Same transitions: discrete outputs identical, values to rounding (the sums are associated differently)."""
+    from aehmc_amd import RandomStream, hmc, nuts
+    from aehmc_amd.engine import get_engine
+    X, y = regression_data
+    h = 0.5 * np.log(2 * np.pi)
+
+    def logprob_fn(q):
+        w, ls = q[0], q[1]
+        n = np.exp(ls)
+        r = y - X * w
+        return (-0.5 * w * w - h) + (ls - n) + ls + (-0.5 * (r / n) ** 2 - ls - h).sum()
+
+    eng = get_engine()
+    C = 6
+    q0 = np.array([3.0, 0.0]) + 0.01 * np.random.default_rng(3).normal(size=(C, 2))
+    imm = np.array([1e-4, 0.5e-4])
+    out = {}
+    try:
+        for mode in (0, 2):
+            eng.set_option("joint_wg", mode)
+            kern = nuts.new_kernel(RandomStream(seeds=range(C)), logprob_fn, max_num_expansions=6)
+            state = nuts.new_state(dev(q0), logprob_fn)
+            samples, info, acc, div = kern.sample(state, 0.5, imm, 4)
+            hk = hmc.new_kernel(RandomStream(seeds=range(C)), logprob_fn)
+            hs, hinfo, hacc, hdiv = hk.sample(hmc.new_state(dev(q0), logprob_fn), 0.3, imm, 9, 3)
+            out[mode] = (samples.cpu().numpy(), info.n_leapfrog.cpu().numpy(), acc.cpu().numpy(), hs.cpu().numpy(), hacc.cpu().numpy())
+    finally:
+        eng.set_option("joint_wg", 1)
+    assert np.array_equal(out[0][1], out[2][1]) and out[0][1].sum() > 4 * C
+    for k in (0, 2, 3, 4):
+        np.testing.assert_allclose(out[0][k], out[2][k], rtol=1e-10, atol=1e-12)
+
+
 def test_python_logprob_fn_under_window_adaptation_and_sample():
     from aehmc_amd import RandomStream, nuts, window_adaptation
     C, D = 64, 10

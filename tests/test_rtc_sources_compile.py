@@ -99,7 +99,9 @@ def traced_joint():
 
     tgt = targets.from_callable(funnel_plus, 100)
     assert isinstance(tgt, targets.CustomJoint) and "#define AEHMC_JOINT_GRAD 1" in tgt.source
-    return "#define AEHMC_JOINT_TARGET 1\n" + tgt.source + '#include "engine.cuh"\n#include "nuts_resident.cuh"\n'
+    wg = ("template __global__ void aehmc::k_nuts_joint_wg<8>(aehmc::EngineArgs, aehmc::NutsSampleArgs);\n"
+          "template __global__ void aehmc::k_hmc_joint_wg<8>(aehmc::EngineArgs, long long, long long, double *, double *, int *);\n")
+    return "#define AEHMC_JOINT_TARGET 1\n" + tgt.source + '#include "engine.cuh"\n#include "nuts_resident.cuh"\n' + wg
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

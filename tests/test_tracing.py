@@ -128,6 +128,7 @@ REV_HARNESS = r"""
 #define AEHMC_LANES 1
 #define AEHMC_WSUM(x) (x)
 #define AEHMC_ATOMIC_ADD(p, v) (*(p) += (v))
+#define AEHMC_SYNC()
 #include "dual.cuh"
 %(source)s
 %(params)s
