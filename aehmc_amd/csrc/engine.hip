@@ -1258,6 +1258,14 @@ constexpr int GLM_ROWS_MAX_D = 32;
 // chains, and puts the products with X on the matrix cores -- but pays five launches per leapfrog.  One launch wins with
 // few coordinates (<= 16: 144 - 152 registers) or few chains (<= 1024: the lock-step path's launches dominate).
 static bool glm_rows_wanted(int64_t D, int64_t C) { return D <= GLM_ROWS_MAX_D && (D <= 16 || C <= 1024); }
+// long data, few chains: a workgroup of eight wavefronts per chain (glm_rows.cuh: k_nuts_glm_wg / k_hmc_glm_wg)
+static bool glm_wg_wanted(const aehmc_ctx *ctx, int64_t D, int64_t C) {
+  if (!ctx->opt_joint_wg || D > GLM_ROWS_MAX_D) return false;
+  return ctx->opt_joint_wg > 1 || (ctx->glm_N >= 8192 && C <= 2048);
+}
+static std::string glm_wg_name(const char *kernel, int64_t D) {
+  return std::string("aehmc::") + kernel + "<" + (D <= 8 ? "8" : D <= 16 ? "16" : "32") + ", 8>";
+}
 static std::string glm_rows_name(const char *kernel, int64_t D) {
   return std::string("aehmc::") + kernel + "<" + (D <= 8 ? "8" : D <= 16 ? "16" : "32") + ">";
 }
@@ -1303,7 +1311,7 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   // a traced joint density with long data sweeps and few chains: a workgroup per chain (k_nuts_joint_wg, run-time compiled)
   if (want_resident && tkind == AEHMC_T_JOINT && nd < 2 && joint_wg_wanted(ctx, C)) return NUTS_PATH_JOINT_WG;
   if (want_resident && tkind == AEHMC_T_JOINT && D <= FUSED_DENSE_MAX_D) return NUTS_PATH_FUSED_DENSE;  // (run-time compiled)
-  if (want_resident && tkind == AEHMC_T_GLM && nd < 2 && glm_rows_wanted(D, C)) return NUTS_PATH_GLM_ROWS;  // (run-time compiled)
+  if (want_resident && tkind == AEHMC_T_GLM && nd < 2 && (glm_rows_wanted(D, C) || glm_wg_wanted(ctx, D, C))) return NUTS_PATH_GLM_ROWS;  // (run-time compiled)
   // joint target of more than 64 coordinates, scalar / diagonal metric: the lock-step loop of a chain in one wavefront,
   // one launch per call (k_nuts_joint_rows); with a dense metric the lock-step path itself (GEMMs over all chains)
   // -- up to D = 192: beyond, the density's O(D^2 / 64) terms are the whole cost and a wavefront that carries its chain
@@ -1461,11 +1469,12 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
       m = *multi;
       *multi_done = true;
     }
-    const std::string name = glm_rows_name("k_nuts_glm_rows", a.D);
+    const bool wg = glm_wg_wanted(ctx, a.D, C);
+    const std::string name = wg ? glm_wg_name("k_nuts_glm_wg", a.D) : glm_rows_name("k_nuts_glm_rows", a.D);
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (int rc = rtc_launch(ctx, "glmk", {name}, name, chain_grid(C), dim3(256), 0, st, a, m, (const double *)ctx->glm_XT,
-                            ctx->glm_y, (long long)ctx->glm_N))
+    if (int rc = rtc_launch(ctx, "glmk", {name}, name, wg ? dim3((unsigned)C) : chain_grid(C), dim3(wg ? 512 : 256), 0, st, a, m,
+                            (const double *)ctx->glm_XT, ctx->glm_y, (long long)ctx->glm_N))
       return rc;
     return prof_end(ctx, st, p);
   }
@@ -1844,11 +1853,13 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     return 0;
   }
   // row-reduction target with D <= 32, scalar / diagonal metric: all T transitions in one launch (glm_rows.cuh)
-  if (ctx->opt_fused_hmc && a.tkind == AEHMC_T_GLM && a.met_ndim < 2 && glm_rows_wanted(D, C)) {
-    const std::string name = glm_rows_name("k_hmc_glm_rows", D);
+  if (ctx->opt_fused_hmc && a.tkind == AEHMC_T_GLM && a.met_ndim < 2 && (glm_rows_wanted(D, C) || glm_wg_wanted(ctx, D, C))) {
+    const bool wg = glm_wg_wanted(ctx, D, C);
+    const std::string name = wg ? glm_wg_name("k_hmc_glm_wg", D) : glm_rows_name("k_hmc_glm_rows", D);
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (int rc = rtc_launch(ctx, "glmk", {name}, name, chain_grid(C), dim3(256), 0, st, a, (long long)L, (long long)T, samples, acc_hist,
+    if (int rc = rtc_launch(ctx, "glmk", {name}, name, wg ? dim3((unsigned)C) : chain_grid(C), dim3(wg ? 512 : 256), 0, st, a, (long long)L,
+                            (long long)T, samples, acc_hist,
                             (int *)div_hist, (const double *)ctx->glm_XT, ctx->glm_y, (long long)ctx->glm_N))
       return rc;
     if (int rc = prof_end(ctx, st, p)) return rc;

@@ -192,4 +192,165 @@ __global__ __launch_bounds__(256) void k_hmc_glm_rows(EngineArgs a, long long L,
   }
 }
 
+// ---- a WORKGROUP per chain (round 6): long data, few chains.  With <= 2048 chains a wavefront per chain leaves the GPU's
+// 1024 SIMDs with one or two wavefronts each, every one walking all N rows (latency-bound: profiles/r6/INDEX.md).  Here W
+// wavefronts share a chain's sweep -- thread t takes rows t, t + 64 W, ... --, their partial sums meet in LDS (added in
+// wavefront order by every thread: the same bits everywhere), and wavefront 0 runs the chain's stage / bookkeeping
+// functions between the sweeps.  The sums are associated differently than in glm_rows_eval: results agree to rounding.
+template <int DA, int W>
+__device__ inline double glm_rows_eval_wg(const EngineArgs &a, const double *XT, const double *y, long long N, const double *q,
+                                          double *g, double *qs, double *part, int tid) {
+  const int D = (int)a.D, lane = tid & 63, wave = tid >> 6;
+  if (tid < D) qs[tid] = q[tid];
+  __syncthreads();
+  double acc[DA], ls = 0.0;
+#pragma unroll
+  for (int d = 0; d < DA; d++) acc[d] = 0.0;
+  for (long long n = tid; n < N; n += 64 * W) {
+    double x[DA];
+#pragma unroll
+    for (int d = 0; d < DA; d++) x[d] = d < D ? XT[(size_t)d * N + n] : 0.0;
+    double z = 0.0;
+#pragma unroll
+    for (int d = 0; d < DA; d++)
+      if (d < D) z += x[d] * qs[d];
+    double l, dl;
+    aehmc_glm_row(z, y[n], n, a.cparams, l, dl);
+    ls += l;
+#pragma unroll
+    for (int d = 0; d < DA; d++) acc[d] += x[d] * dl;
+  }
+  ls = wave_sum(ls);
+#pragma unroll
+  for (int d = 0; d < DA; d++)
+    if (d < D) acc[d] = wave_sum(acc[d]);
+  if (lane == 0) {
+    part[wave * (DA + 1)] = ls;
+#pragma unroll
+    for (int d = 0; d < DA; d++) part[wave * (DA + 1) + 1 + d] = acc[d];
+  }
+  __syncthreads();
+  double tot = part[0];
+  for (int w = 1; w < W; w++) tot += part[w * (DA + 1)];
+  double us = 0.0;
+  if (tid < D) {  // thread d finishes dU/dq_d (wavefront 0: D <= 32)
+    double gl = part[1 + tid];
+    for (int w = 1; w < W; w++) gl += part[w * (DA + 1) + 1 + tid];
+    double u, pg;
+    aehmc_glm_prior(qs[tid], tid, a.cparams, u, pg);
+    g[tid] = gl + pg;
+    us = u;
+  }
+  if (wave == 0) {
+    us = wave_sum(us);
+    if (lane == 0) part[W * (DA + 1)] = us;
+  }
+  __threadfence_block();  // (wavefront 0's stage functions read g behind the caller's barrier)
+  __syncthreads();
+  return tot + part[W * (DA + 1)];
+}
+template <int DA, int W>
+__global__ __launch_bounds__(64 * W) void k_nuts_glm_wg(EngineArgs a, NutsSampleArgs m, const double *XT, const double *y, long long N) {
+  __shared__ double glm_q[DA];
+  __shared__ double glm_part[W * (DA + 1) + 1];
+  __shared__ int wg_done;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool leader = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+  const long long c = blockIdx.x;
+  const size_t row = (size_t)c * a.D;
+  ChainRng rng = rng_load(a, c);
+  ChainCtl ct = {};
+  double U_state = a.U[c];
+  long long nleap_sum = 0;
+  for (long long t_idx = 0; t_idx < m.T; t_idx++) {
+    if (leader) {
+      draw_momentum<false>(a, c, lane, rng.g[0]);
+      nuts_init_chain<false>(a, c, lane, ct, rng, &U_state);
+    }
+    for (;;) {
+      double U_new = 0.0;
+      if (leader) {
+        leap_stages<true, true, false, false>(a, c, lane, ct.dir, U_new);  // p_half, q'
+        __threadfence_block();
+      }
+      __syncthreads();
+      const double Uv = glm_rows_eval_wg<DA, W>(a, XT, y, N, a.cur_q + row, a.cur_g + row, glm_q, glm_part, tid);
+      if (leader) {
+        ct.U_cur = Uv;
+        leap_stages<false, false, true, false>(a, c, lane, ct.dir, U_new);  // p' = p_half - b dU/dq'
+        nuts_book<false>(a, c, lane, ct, rng);
+        if (lane == 0) wg_done = ct.done;
+      }
+      __syncthreads();
+      if (wg_done) break;
+    }
+    if (leader) {
+      U_state = pick2(ct.U_slot, ct.prop_slot);
+      nleap_sum += ct.nleap;
+      __threadfence_block();
+      if (m.samples) {
+        double *dst = m.samples + ((size_t)t_idx * a.C + c) * a.D;
+        for (long long i = lane; i < a.D; i += 64) dst[i] = a.q[row + i];
+      }
+      if (lane == 0) {
+        if (m.acc_hist) m.acc_hist[(size_t)t_idx * a.C + c] = ct.acc_prob;
+        if (m.div_hist) m.div_hist[(size_t)t_idx * a.C + c] = ct.out_div;
+      }
+    }
+  }
+  if (leader) {
+    rng_store(a, c, lane, rng, 0, 3);
+    if (lane == 0 && m.nleap_total) m.nleap_total[c] = nleap_sum;
+  }
+}
+template <int DA, int W>
+__global__ __launch_bounds__(64 * W) void k_hmc_glm_wg(EngineArgs a, long long L, long long nt, double *samples, double *acc_hist,
+                                                       int *div_hist, const double *XT, const double *y, long long N) {
+  __shared__ double glm_q[DA];
+  __shared__ double glm_part[W * (DA + 1) + 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool leader = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+  const long long c = blockIdx.x;
+  const size_t row = (size_t)c * a.D;
+  Pcg64 g1 = pcg_load(a.rng + (size_t)c * a.nsites * 4), g2 = pcg_load(a.rng + ((size_t)c * a.nsites + 1) * 4);
+  double U_state = a.U[c];
+  for (long long tt = 0; tt < nt; tt++) {
+    ChainCtl ct = {};
+    if (leader) {
+      draw_momentum<false>(a, c, lane, g1);
+      ct = hmc_init_chain<false>(a, c, lane, &U_state);
+    }
+    for (long long l = 0; l < L; l++) {  // trajectory.py:86-95
+      double U_new = 0.0;
+      if (leader) {
+        leap_stages<true, true, false, false>(a, c, lane, 1, U_new);
+        __threadfence_block();
+      }
+      __syncthreads();
+      const double Uv = glm_rows_eval_wg<DA, W>(a, XT, y, N, a.cur_q + row, a.cur_g + row, glm_q, glm_part, tid);
+      if (leader) {
+        ct.U_cur = Uv;
+        leap_stages<false, false, true, false>(a, c, lane, 1, U_new);
+      }
+    }
+    if (leader) {
+      __threadfence_block();
+      const HmcEnd e = hmc_end_chain_rng<false>(a, c, lane, ct, L, g2);
+      if (e.acc) U_state = ct.U_cur;
+      if (samples) {
+        double *dst = samples + ((size_t)tt * a.C + c) * a.D;
+        for (long long i = lane; i < a.D; i += 64) dst[i] = a.q[row + i];
+      }
+      if (lane == 0) {
+        if (acc_hist) acc_hist[(size_t)tt * a.C + c] = e.pa;
+        if (div_hist) div_hist[(size_t)tt * a.C + c] = e.is_div;
+      }
+    }
+  }
+  if (leader && lane == 0) {
+    pcg_store(a.rng + (size_t)c * a.nsites * 4, g1);
+    pcg_store(a.rng + ((size_t)c * a.nsites + 1) * 4, g2);
+  }
+}
+
 }  // namespace aehmc

@@ -383,6 +383,35 @@ def test_custom_glm_one_launch_equals_lockstep(eng):
         np.testing.assert_allclose(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy(), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("N, D", [(9000, 5), (8193, 17)])
+def test_custom_glm_workgroup_per_chain_equals_wavefront_per_chain(eng, N, D):
+    """Long data, few chains: eight wavefronts share a chain's sweep over the rows (glm_rows.cuh: k_nuts_glm_wg /
+    k_hmc_glm_wg, taken for N >= 8192 and <= 2048 chains; option joint_wg = 0 keeps a wavefront per chain).  Same trees,
+    accept decisions and generator states, values to rounding (the row sums are associated differently)."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    C = 5
+    X, y, _ = logistic_data(N, D, 31)
+    r = np.random.default_rng(6)
+    q0, imm = 0.2 * r.normal(size=(C, D)), 0.002 + 0.005 * r.random(D)
+    tgt = targets.CustomGLM(LOGISTIC, dev(X), dev(y), params=[[2.0]])
+    outs = {}
+    try:
+        for wg in (1, 0):
+            eng.set_option("joint_wg", wg)
+            kn = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=6)
+            sn, infn = kn.sample(nuts.new_state(dev(q0), tgt), 0.4, imm, 4)[:2]
+            kh = hmc.new_kernel(RandomStream(seeds=list(range(C))), tgt)
+            sh, _, acch = kh.sample(hmc.new_state(dev(q0), tgt), 0.3, imm, 6, 4)[:3]
+            outs[wg] = (sn, sh, acch, infn.n_leapfrog, kn._nuts["holder"]["rng"].clone(), kh._hmc["holder"]["rng"].clone())
+    finally:
+        eng.set_option("joint_wg", 1)
+    assert int(outs[1][3].sum()) > 4 * C
+    for k in (3, 4, 5):
+        assert torch.equal(outs[1][k], outs[0][k])
+    for k in (0, 1, 2):
+        np.testing.assert_allclose(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy(), rtol=1e-9, atol=1e-12)
+
+
 def test_custom_glm_posterior(eng):
     """Bayesian logistic regression sampled with NUTS after window adaptation (the use the reference's README and
     notebook show for its own models): the posterior mean recovers the generating weights within its own spread, and

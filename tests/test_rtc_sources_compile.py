@@ -83,6 +83,8 @@ __device__ void aehmc_glm_prior(double q, long long i, const double *const *prm,
 template __global__ void aehmc::k_nuts_glm_rows<8>(aehmc::EngineArgs, aehmc::NutsSampleArgs, const double *, const double *, long long);
 template __global__ void aehmc::k_nuts_glm_rows<32>(aehmc::EngineArgs, aehmc::NutsSampleArgs, const double *, const double *, long long);
 template __global__ void aehmc::k_hmc_glm_rows<16>(aehmc::EngineArgs, long long, long long, double *, double *, int *, const double *, const double *, long long);
+template __global__ void aehmc::k_nuts_glm_wg<8, 8>(aehmc::EngineArgs, aehmc::NutsSampleArgs, const double *, const double *, long long);
+template __global__ void aehmc::k_hmc_glm_wg<32, 8>(aehmc::EngineArgs, long long, long long, double *, double *, int *, const double *, const double *, long long);
 '''
 
 
