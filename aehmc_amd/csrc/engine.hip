@@ -510,9 +510,10 @@ extern "C" int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, i
 static const std::vector<std::string> RTC_JWG = {"aehmc::k_nuts_joint_wg<8>", "aehmc::k_hmc_joint_wg<8>"};
 static bool joint_wg_wanted(const aehmc_ctx *ctx, int64_t C) {
   if (!ctx->opt_joint_wg) return false;
-  const size_t at = ctx->custom_src.find("#define AEHMC_JOINT_SWEEP_TERMS ");
+  static const char key[] = "#define AEHMC_JOINT_SWEEP_TERMS ";
+  const size_t at = ctx->custom_src.find(key);
   if (at == std::string::npos) return false;
-  const long long terms = atoll(ctx->custom_src.c_str() + at + 32);
+  const long long terms = atoll(ctx->custom_src.c_str() + at + sizeof(key) - 1);
   // (a wavefront per chain fills the GPU's 1024 SIMDs twice over at 2048 chains; a sweep of < 8192 terms is < 128 trips of a wavefront)
   return ctx->opt_joint_wg > 1 || (terms >= 8192 && C <= 2048);
 }
