@@ -6,10 +6,10 @@ HIP kernels reached through the C-ABI of ``include/aehmc_hip.h``.  There is no C
 fallback: importing works anywhere, but every computation needs ``libaehmc_hip.so`` and
 a GPU and fails loudly otherwise.
 """
-from . import algorithms, hmc, mass_matrix, nuts, step_size, targets, utils, window_adaptation  # noqa: F401
+from . import algorithms, hmc, mass_matrix, nuts, step_size, targets, tracing, utils, window_adaptation  # noqa: F401
 from .engine import PerChain  # noqa: F401
 from .integrators import IntegratorState  # noqa: F401
 from .random import RandomStream  # noqa: F401
 from .trajectory import Diagnostics  # noqa: F401
 
-__all__ = ["algorithms", "hmc", "mass_matrix", "nuts", "step_size", "targets", "utils", "window_adaptation", "PerChain", "IntegratorState", "RandomStream", "Diagnostics"]
+__all__ = ["algorithms", "hmc", "mass_matrix", "nuts", "step_size", "targets", "tracing", "utils", "window_adaptation", "PerChain", "IntegratorState", "RandomStream", "Diagnostics"]
