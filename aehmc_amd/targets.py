@@ -237,7 +237,7 @@ class CustomGLM(Target):
         return d
 
 
-def from_callable(fn, dim, scalar=False, args=()):
+def from_callable(fn, dim, scalar=False, args=(), reverse="auto"):
     """A Python ``logprob_fn`` (reference: README.md:27-36, aehmc/hmc.py:16-40 -- any function of the position) as a
     Target: ``fn`` is called ONCE on a proxy of one chain's position (a scalar proxy if ``scalar``, else a vector of
     ``dim`` entries; see ``aehmc_amd.tracing`` for what it may do with it) and the recorded expression is emitted as the
@@ -250,9 +250,11 @@ def from_callable(fn, dim, scalar=False, args=()):
         target = targets.from_callable(logprob_fn, 1, scalar=True)
 
     ``hmc.new_state`` / ``new_kernel`` and ``nuts.new_state`` / ``new_kernel`` call this themselves when they are handed a
-    function instead of a Target (``as_target``)."""
+    function instead of a Target (``as_target``).  ``reverse``: how a joint density is differentiated -- "auto" (forward
+    mode up to 64 coordinates unless its reductions are long, one reverse sweep above), True (reverse at every size),
+    False (forward mode only)."""
     from . import tracing
-    tr = tracing.trace(fn, dim, scalar=scalar, args=args)
+    tr = tracing.trace(fn, dim, scalar=scalar, args=args, reverse=reverse)
     try:  # the captured arrays are fixed from here on: on the device once (a host array would be hashed and uploaded per call)
         import torch
         if torch.cuda.is_available():

@@ -743,6 +743,31 @@ def _private_leaves(e):
     return out if walk(e.args[2], {}) else None
 
 
+def _mixed_owners(e):
+    """Does a distributed loop write gradient entries through more than one index map a * i + c?  (x[1:] - x[:-1]: lane i
+    owns entry i + 1 for one read and entry i for the other, which is lane i - 1's for the first.)  Then no lane owns an
+    entry and the additions are atomic."""
+    v = e.args[0]
+    maps = set()
+
+    def walk(x):
+        if x.op == "q":
+            t = x.args[0].terms
+            if not x.args[0].ind and len(t) == 1 and t[0][0] == v:
+                maps.add((t[0][1], x.args[0].c))
+        elif x.op == "sum":
+            for _, h in x.args[3]:
+                walk(h)
+            walk(x.args[2])
+        else:
+            for y in x.args:
+                if isinstance(y, S):
+                    walk(y)
+
+    walk(e.args[2])
+    return len(maps) > 1
+
+
 def _distributable(e):
     """a sum whose body reads (and so writes the gradient of) the position at indices a * i + c, a != 0, or through short
     inner reductions (_private_leaves)"""
@@ -871,8 +896,9 @@ class _RevGen:
         self.put(f"{acc} += {self.fwd(body, benv)};")
         if fused:
             outer_owned, self.lane_owned = self.lane_owned, dist
+            outer_atomic, self.atomic_loop = self.atomic_loop, dist and _mixed_owners(e)
             self.bwd(body, fused, benv)
-            self.lane_owned = outer_owned
+            self.lane_owned, self.atomic_loop = outer_owned, outer_atomic
         self.depth -= 1
         self.ind -= 1
         self.put("}")
@@ -950,9 +976,10 @@ class _RevGen:
                 self.put(f"{arr}[{self.names[inner.args[0]]}] += {adj};")
                 return
             tgt = f"g[{a[0].code(self.names, self.par)}]"
-            if a[0].ind and self.depth > 0 and self.lane_owned:
-                # a gather inside a distributed loop: several lanes may hold the same entry -- an atomic add into the LDS row
-                # (the order of the additions of one wavefront instruction is the hardware's: rounding-level effects only)
+            if (a[0].ind or self.atomic_loop) and self.depth > 0 and self.lane_owned:
+                # a gather, or a loop that writes entries through several index maps, inside a distributed loop: several lanes
+                # may hold the same entry -- an atomic add into the LDS row (the order of the additions of one wavefront
+                # instruction is the hardware's: rounding-level effects only)
                 self.put(f"AEHMC_ATOMIC_ADD(&{tgt}, {adj});")
             else:
                 self.put(f"{tgt} += {adj};" if self.depth > 0 and self.lane_owned else f"if (lane == 0) {tgt} += {adj};")
@@ -1015,13 +1042,14 @@ class _RevGen:
             self.put(self.loop_head(e, dist))
             self.ind += 1
             self.depth += 1
-            outer_owned = self.lane_owned
+            outer_owned, outer_atomic = self.lane_owned, self.atomic_loop
             if dist:
                 self.lane_owned = True
+                self.atomic_loop = _mixed_owners(e)
             benv = dict(env)
             self.fwd(body, benv)  # (the body's values again)
             self.bwd(body, adj, benv)
-            self.lane_owned = outer_owned
+            self.lane_owned, self.atomic_loop = outer_owned, outer_atomic
             self.depth -= 1
             self.ind -= 1
             self.put("}")
@@ -1036,6 +1064,7 @@ class _RevGen:
             raise AssertionError(op)
 
     lane_owned = False  # inside a distributed loop: the lane owns the gradient entries its iterations touch
+    atomic_loop = False  # ... unless the loop writes them through several index maps (_mixed_owners): atomic additions
 
     # ---- per-lane accumulators of position reads through short inner reductions (_private_leaves)
     def private_begin(self, e):
@@ -1130,9 +1159,11 @@ def _reverse_source(root, dim):
     return src
 
 
-def trace(fn, dim, scalar=False, args=()):
+def trace(fn, dim, scalar=False, args=(), reverse="auto"):
     """Call ``fn`` once on a proxy of the position (a scalar if ``scalar``, else a vector of ``dim`` entries) and emit
-    the ``aehmc_logp`` template.  ``args``: further constant arguments handed to ``fn`` (numbers / numpy arrays)."""
+    the ``aehmc_logp`` template.  ``args``: further constant arguments handed to ``fn`` (numbers / numpy arrays).
+    ``reverse`` (joint densities): "auto" -- the reverse-mode program is emitted and taken above 64 coordinates, or below
+    when the density's reductions are long; True -- taken at every size; False -- not emitted (forward mode only)."""
     dim = int(dim)
     ctx = _Ctx()
     if scalar:
@@ -1174,5 +1205,9 @@ def trace(fn, dim, scalar=False, args=()):
     src = ("template <class V> __device__ auto aehmc_logp(const V &q, const double *const *prm) {\n"
            "  typedef decltype(q[0]) T;\n" + "\n".join(g.lines) + ("\n" if g.lines else "") + f"  return T({body});\n}}\n")
     tr = Traced(src, ctx.params, False, dim)
-    tr.grad_source = _reverse_source(out, dim)  # (above 64 coordinates the engine takes this instead of ceil(dim / 64) forward passes)
+    tr.grad_source = None
+    if reverse is not False:  # (above 64 coordinates the engine takes this instead of ceil(dim / 64) forward passes)
+        tr.grad_source = _reverse_source(out, dim)
+        if reverse is True and "#define AEHMC_JOINT_GRAD_SMALL" not in tr.grad_source:
+            tr.grad_source += "#define AEHMC_JOINT_GRAD_SMALL 1\n"
     return tr

@@ -378,6 +378,40 @@ def test_workgroup_per_chain_kernels_agree_with_the_wavefront_per_chain_ones(reg
         np.testing.assert_allclose(out[0][k], out[2][k], rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_generated_reverse_mode_programs_agree_with_forward_mode_on_the_device(seed):
+    """Random joint densities (tests/test_tracing.py: hyper-parameters, slices, nested reductions, where / maximum, a
+    captured matrix) run three ways on the GPU: forward mode (dual numbers in the lanes / row passes), the generated
+    reverse-mode program on a wavefront per chain, and the same program on a workgroup per chain.  The gradients are
+    different programs over the same expression: trajectories agree at 1e-9, discrete outputs are identical."""
+    from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.engine import get_engine
+    from test_tracing import random_density
+    D = [9, 17, 70][seed % 3]
+    fn = random_density(seed, D)
+    eng = get_engine()
+    C = 5
+    q0 = 0.4 * np.random.default_rng(50 + seed).normal(size=(C, D))
+    imm = 0.5 + np.random.default_rng(seed).random(D)
+    out = {}
+    try:
+        for name, rev, wg in (("forward", False, 0), ("reverse", True, 0), ("workgroup", True, 2)):
+            eng.set_option("joint_wg", wg)
+            tgt = targets.from_callable(fn, D, reverse=rev)
+            kern = nuts.new_kernel(RandomStream(seeds=[7 + c for c in range(C)]), tgt, max_num_expansions=5)
+            state = nuts.new_state(dev(q0), tgt)
+            samples, info, acc, div = kern.sample(state, 0.05, imm, 3)
+            out[name] = (state.potential_energy_grad.cpu().numpy(), samples.cpu().numpy(), acc.cpu().numpy(),
+                         info.n_leapfrog.cpu().numpy(), div.cpu().numpy())
+    finally:
+        eng.set_option("joint_wg", 1)
+    for name in ("reverse", "workgroup"):
+        np.testing.assert_allclose(out[name][0], out["forward"][0], rtol=1e-11, atol=1e-11)
+        assert np.array_equal(out[name][3], out["forward"][3]) and np.array_equal(out[name][4], out["forward"][4])
+        np.testing.assert_allclose(out[name][1], out["forward"][1], rtol=RTOL, atol=1e-10)
+        np.testing.assert_allclose(out[name][2], out["forward"][2], rtol=1e-7, atol=1e-10)
+
+
 def test_python_logprob_fn_under_window_adaptation_and_sample():
     from aehmc_amd import RandomStream, nuts, window_adaptation
     C, D = 64, 10
