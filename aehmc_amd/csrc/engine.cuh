@@ -44,6 +44,19 @@ struct ChainCtl {
   int ndoubl, out_div, out_turn;
 };
 
+// Occupancy bound of the kernels that run a USER's density in workgroups of more than 256 threads.  A 64 W-thread workgroup
+// needs W / 4 wavefronts per SIMD resident together, i.e. at most 512 / (W / 4) registers per lane, accumulation registers
+// included.  __launch_bounds__ alone, and amdgpu_waves_per_eu(W / 4) too, let the compiler of hipRTC 7.2 go past that for
+// densities with long unrolled bodies (236 + 32 accumulation registers = 268 for a 512-thread workgroup, 328 with
+// amdgpu_waves_per_eu(1)): a code object that cannot be launched -- HSA_STATUS_ERROR_INVALID_ISA, the process aborts.
+// One wavefront more is asked for (W = 8: three per SIMD, <= 168 + accumulation registers; measured 228).
+constexpr int wg_min_waves(int W) { return (W >= 4 ? W / 4 : 1) + 1; }
+#ifdef AEHMC_JOINT_TARGET
+#define AEHMC_USER_DENSITY_512 __attribute__((amdgpu_waves_per_eu(3)))  /* (512-thread kernels compiled against a user's joint density) */
+#else
+#define AEHMC_USER_DENSITY_512
+#endif
+
 struct EngineArgs {
   long long C, D;
   long long ldw;        // row stride of the work arrays: D, or D rounded up for the workgroup-per-chain NUTS kernel
@@ -1059,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_hmc_end(EngineArgs a, long long L) {
 // The HMC transition of a small dense problem in one launch (see above: same matrices in LDS, same
 // in-wavefront products, literal dense mode); the chain's scalars stay in registers between the stages.
 template <bool MD, bool TD, bool PC = false>
-__global__ __launch_bounds__(FUSED_DENSE_BLOCK) void k_hmc_fused_dense(EngineArgs a, const double *prec, double *imm_ws, long long L,
+__global__ __launch_bounds__(FUSED_DENSE_BLOCK) AEHMC_USER_DENSITY_512 void k_hmc_fused_dense(EngineArgs a, const double *prec, double *imm_ws, long long L,
                                                                          long long nt, double *samples, double *acc_hist,
                                                                          int *div_hist) {
   extern __shared__ __attribute__((aligned(16))) double fd_lds[];
@@ -1298,7 +1311,7 @@ __device__ inline double joint_wg_eval(const EngineArgs &a, const double *q, dou
   return -lp;
 }
 template <int W>
-__global__ __launch_bounds__(64 * W) void k_nuts_joint_wg(EngineArgs a, NutsSampleArgs m) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(wg_min_waves(W)))) void k_nuts_joint_wg(EngineArgs a, NutsSampleArgs m) {
   extern __shared__ __attribute__((aligned(16))) double joint_rows[];
   __shared__ int wg_done;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1353,7 +1366,7 @@ __global__ __launch_bounds__(64 * W) void k_nuts_joint_wg(EngineArgs a, NutsSamp
   }
 }
 template <int W>
-__global__ __launch_bounds__(64 * W) void k_hmc_joint_wg(EngineArgs a, long long L, long long nt, double *samples,
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(wg_min_waves(W)))) void k_hmc_joint_wg(EngineArgs a, long long L, long long nt, double *samples,
                                                          double *acc_hist, int *div_hist) {
   extern __shared__ __attribute__((aligned(16))) double joint_rows[];
   const int tid = threadIdx.x, lane = tid & 63;

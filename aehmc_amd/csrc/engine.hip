@@ -415,6 +415,23 @@ static int rtc_launch(aehmc_ctx *ctx, const std::string &which, const std::vecto
   hipFunction_t f = nullptr;
   if (int rc = rtc_function(ctx, which, names, want, &f)) return rc;
   void *params[] = {(void *)&args...};
+  {  // a code object whose register count does not fit the workgroup aborts the PROCESS when it is launched
+     // (HSA_STATUS_ERROR_INVALID_ISA): an error return instead
+    int max_threads = 0, regs = 0;
+    (void)hipFuncGetAttribute(&max_threads, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, f);
+    (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, f);
+    // (gfx950: 512 registers per lane and SIMD, four SIMDs per CU: a workgroup fits if its wavefronts per SIMD do)
+    if (regs > 0 && regs <= 512) {
+      const int by_regs = (512 / ((regs + 7) & ~7)) * 4 * 64;
+      if (max_threads <= 0 || by_regs < max_threads) max_threads = by_regs;
+    }
+    if (max_threads > 0 && (int)(block.x * block.y * block.z) > max_threads) {
+      FAIL("user-defined target: the kernel " + want + " compiled against it uses " + std::to_string(regs) +
+           " registers per lane and can run workgroups of at most " + std::to_string(max_threads) + " threads (" +
+           std::to_string(block.x * block.y * block.z) + " needed): simplify the density (long unrolled loop bodies), or "
+           "use the lock-step path (set_option resident_nuts 0 / fused_hmc 0)");
+    }
+  }
   if (dyn > 65536)  // (more dynamic LDS than the default limit: allowed per function)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
   HIPCHK(hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)dyn, st, params, nullptr));

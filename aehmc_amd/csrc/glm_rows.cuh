@@ -250,7 +250,7 @@ __device__ inline double glm_rows_eval_wg(const EngineArgs &a, const double *XT,
   return tot + part[W * (DA + 1)];
 }
 template <int DA, int W>
-__global__ __launch_bounds__(64 * W) void k_nuts_glm_wg(EngineArgs a, NutsSampleArgs m, const double *XT, const double *y, long long N) {
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(wg_min_waves(W)))) void k_nuts_glm_wg(EngineArgs a, NutsSampleArgs m, const double *XT, const double *y, long long N) {
   __shared__ double glm_q[DA];
   __shared__ double glm_part[W * (DA + 1) + 1];
   __shared__ int wg_done;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * W) void k_nuts_glm_wg(EngineArgs a, NutsSample
   }
 }
 template <int DA, int W>
-__global__ __launch_bounds__(64 * W) void k_hmc_glm_wg(EngineArgs a, long long L, long long nt, double *samples, double *acc_hist,
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(wg_min_waves(W)))) void k_hmc_glm_wg(EngineArgs a, long long L, long long nt, double *samples, double *acc_hist,
                                                        int *div_hist, const double *XT, const double *y, long long N) {
   __shared__ double glm_q[DA];
   __shared__ double glm_part[W * (DA + 1) + 1];

@@ -99,8 +99,14 @@ constexpr int res_min_waves(int T, int R, bool MULTI) { return (AEHMC_RES_MIN_WA
 // (the dense instantiations run 512-thread workgroups: two wavefronts per SIMD have to fit.  Said explicitly since round 6:
 //  with amdgpu_waves_per_eu(1) the compiler took the freedom to use 328 registers for a user density with long unrolled
 //  inner loops -- a code object that cannot be launched, HSA_STATUS_ERROR_INVALID_ISA)
+// (compiled against a user's joint density -- AEHMC_JOINT_TARGET -- three: engine.cuh wg_min_waves has the measurement)
 constexpr int res_min_waves_dense(int T, int R, bool MULTI, int DENSE) {
-  return DENSE ? (res_min_waves(T, R, MULTI) > 2 ? res_min_waves(T, R, MULTI) : 2) : res_min_waves(T, R, MULTI);
+#ifdef AEHMC_JOINT_TARGET
+  constexpr int need = 3;
+#else
+  constexpr int need = 2;
+#endif
+  return DENSE ? (res_min_waves(T, R, MULTI) > need ? res_min_waves(T, R, MULTI) : need) : res_min_waves(T, R, MULTI);
 }
 
 template <int T, int R, bool MULTI, int DENSE = 0, bool CKL = false>

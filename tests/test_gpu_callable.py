@@ -378,7 +378,7 @@ def test_workgroup_per_chain_kernels_agree_with_the_wavefront_per_chain_ones(reg
         np.testing.assert_allclose(out[0][k], out[2][k], rtol=1e-10, atol=1e-12)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(15))
 def test_generated_reverse_mode_programs_agree_with_forward_mode_on_the_device(seed):
     """Random joint densities (tests/test_tracing.py: hyper-parameters, slices, nested reductions, where / maximum, a
     captured matrix) run three ways on the GPU: forward mode (dual numbers in the lanes / row passes), the generated
@@ -387,7 +387,7 @@ def test_generated_reverse_mode_programs_agree_with_forward_mode_on_the_device(s
     from aehmc_amd import RandomStream, nuts, targets
     from aehmc_amd.engine import get_engine
     from test_tracing import random_density
-    D = [9, 17, 70][seed % 3]
+    D = [9, 17, 70, 40, 150][seed % 5]
     fn = random_density(seed, D)
     eng = get_engine()
     C = 5

@@ -192,7 +192,11 @@ def random_density(seed, D):
     n = D - 3
     w, c = r.normal(size=n), 0.5 + r.random(n)
     A = r.normal(size=(3, n)) / np.sqrt(n)
-    picks = r.integers(0, 6, size=4)
+    picks = r.integers(0, 9, size=4)
+    G = max(2, n // 3)
+    grp = r.integers(0, G, size=2 * n)
+    w2 = r.normal(size=2 * n)
+    B = r.normal(size=(n, n)) / n
 
     def fn(q):
         a, b, s = q[0], q[1], q[2]
@@ -202,7 +206,10 @@ def random_density(seed, D):
                  lambda: np.tanh(a) * (x[: n // 2] * x[n - n // 2:]).sum() - 0.5 * np.dot(x, x) / (1.0 + tracing.softplus(b)),
                  lambda: -0.5 * np.sum((A @ x - np.array([a, b, s])) ** 2),
                  lambda: np.sum(tracing.where(x > a, np.sin(x) * b, -np.abs(x - a))) * 0.3 - np.logaddexp(a, b),
-                 lambda: -(np.maximum(x, w) * c).sum() * np.exp(-np.abs(s)) + (x[1:] - x[:-1]).mean() * np.cos(a)]
+                 lambda: -(np.maximum(x, w) * c).sum() * np.exp(-np.abs(s)) + (x[1:] - x[:-1]).mean() * np.cos(a),
+                 lambda: -0.5 * np.sum((w2 - x[:G][grp] * np.exp(0.1 * b)) ** 2) / (2 * n),            # a gather (random effects by group)
+                 lambda: -0.5 * np.dot(x, B @ x) * (1.0 + 0.1 * np.tanh(s)) if n > 32 else -0.5 * np.dot(x - a, B @ (x - a)),
+                 lambda: np.exp(-np.sum(x * x) / n) * a - np.log1p(np.sum(np.square(x - b)) / n)]     # functions of reductions
         out = -0.5 * (a * a + b * b + s * s)
         for k in picks:
             out = out + terms[k]()
@@ -216,7 +223,7 @@ def test_gather_index_out_of_range_is_an_indexerror():
         tracing.trace(lambda q: q[np.array([0, 5])].sum(), 3)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(18))
 def test_reverse_mode_equals_forward_mode_on_random_densities(seed, tmp_path):
     """forward- and reverse-mode gradients equal to 1e-12 on random densities (both compiled as plain
     C++: the Dual template against the reverse sweep), and both equal to central differences of the Python function"""
