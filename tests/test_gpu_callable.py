@@ -412,14 +412,28 @@ def test_generated_reverse_mode_programs_agree_with_forward_mode_on_the_device(s
         np.testing.assert_allclose(out[name][2], out["forward"][2], rtol=1e-7, atol=1e-10)
 
 
-def test_python_logprob_fn_under_window_adaptation_and_sample():
+@pytest.mark.parametrize("D, full", [(10, False), (100, False), (12, True)])
+def test_python_logprob_fn_under_window_adaptation_and_sample(D, full):
+    """window_adaptation.run with a traced density: forward mode (D = 10), the reverse-mode program on the joint-rows
+    kernels (D = 100), and a dense metric per chain (is_mass_matrix_full); a Gaussian with known moments so that the adapted
+    metric and the samples can be checked."""
     from aehmc_amd import RandomStream, nuts, window_adaptation
-    C, D = 64, 10
-    kernel = nuts.new_kernel(RandomStream(seeds=range(C)), funnel, max_num_expansions=6)
-    state = nuts.new_state(dev(0.3 * np.random.default_rng(1).normal(size=(C, D))), funnel)
-    state, (step_size, imm), _ = window_adaptation.run(kernel, state, num_steps=80)
-    samples, info, acc, div = kernel.sample(state, step_size, imm, 10)
-    assert samples.shape == (10, C, D) and torch.isfinite(samples).all()
+    C = 128
+    sd = 0.5 + np.arange(D) % 3
+
+    def logprob_fn(q):
+        z = (q - 1.0) / sd
+        return -0.5 * (z @ z) - 0.05 * np.sum(z[1:] * z[:-1])   # (weakly coupled neighbours: a joint density)
+
+    kernel = nuts.new_kernel(RandomStream(seeds=range(C)), logprob_fn, max_num_expansions=7)
+    state = nuts.new_state(dev(1.0 + 0.3 * np.random.default_rng(1).normal(size=(C, D))), logprob_fn)
+    state, (step_size, imm), _ = window_adaptation.run(kernel, state, num_steps=150, is_mass_matrix_full=full)
+    samples, info, acc, div = kernel.sample(state, step_size, imm, 60)
+    s = samples.cpu().numpy().reshape(-1, D)
+    assert samples.shape == (60, C, D) and np.isfinite(s).all() and not bool(div.any())
+    assert 0.6 < float(acc.mean()) < 0.98
+    np.testing.assert_allclose(s.mean(axis=0), 1.0, atol=0.25)
+    np.testing.assert_allclose(s.std(axis=0) / sd, 1.0, atol=0.2)
 
 
 def test_untraceable_python_logprob_fn_raises_typeerror_before_anything_is_compiled():
