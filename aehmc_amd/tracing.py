@@ -798,6 +798,7 @@ class _RevGen:
         self.depth = 0   # loop nesting
         self.spine, self.done = spine or {}, set()
         self.used_params = set()
+        self.warned = set()
         self.uses, self.cond = {}, set()
         self.private = {}     # id(q leaf) -> (accumulator array, inner sum node)
         self.unrolled = set()  # ids of inner sums whose loops are written out (their accumulator arrays stay in registers)
@@ -874,6 +875,13 @@ class _RevGen:
     def fwd_sum(self, e, env):
         v, n, body, lets = e.args
         dist = self.depth == 0 and _distributable(e)
+        if self.depth == 0 and not dist and n >= 1024 and id(e) not in self.warned:
+            self.warned.add(id(e))
+            import warnings
+            warnings.warn(f"aehmc_amd.tracing: a reduction over {n} terms reads the position through an inner reduction of more "
+                          f"than {PRIVATE_MAX} terms (or at indices that mix loop variables): on the device it runs on ONE lane per "
+                          "chain.  For a regression with many coefficients targets.CustomGLM puts the products with the data matrix "
+                          "on the matrix cores", stacklevel=6)
         env[("dist", id(e))] = dist
         for k, x in lets:
             env[("let", k)] = self.fwd(x, env)
