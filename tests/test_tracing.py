@@ -219,9 +219,9 @@ def random_density(seed, D):
 
 
 def test_a_long_reduction_that_cannot_be_spread_over_the_lanes_warns():
-    X = np.random.default_rng(0).normal(size=(2000, 40))   # 40 coefficients: the inner reduction exceeds the private accumulators
+    X = np.random.default_rng(0).normal(size=(2000, 80))   # 80 coefficients: the inner reduction exceeds the private accumulators
     with pytest.warns(UserWarning, match="runs on ONE lane"):
-        tracing.trace(lambda q: -0.5 * np.sum((X @ q) ** 2) - 0.5 * (q @ q), 40)
+        tracing.trace(lambda q: -0.5 * np.sum((X @ q) ** 2) - 0.5 * (q @ q), 80)
 
 
 def test_gather_index_out_of_range_is_an_indexerror():
