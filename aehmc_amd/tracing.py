@@ -9,7 +9,7 @@ position): traced ONCE with proxy objects and emitted as the ``aehmc_logp`` temp
 What a traced function may do with its argument (a scalar for a scalar position, else a vector of ``dim`` entries):
 ``+ - * / **`` and unary ``-`` with numbers, numpy arrays (captured as device parameter arrays) and other traced values;
 numpy ufuncs ``exp log log1p expm1 sqrt sin cos tanh abs square power reciprocal negative maximum minimum logaddexp``
-``scipy.special.erf`` and ``scipy.special.gammaln``; ``softplus`` and ``where`` from this module; comparisons (inside ``where`` only);
+``scipy.special.erf`` and ``scipy.special.gammaln``; ``softplus``, ``logsumexp`` (up to 64 terms) and ``where`` from this module; comparisons (inside ``where`` only);
 ``.sum()`` / ``np.sum`` / ``.mean()``, ``@`` / ``np.dot`` (vector . vector, constant matrix @ vector, vector @ constant
 matrix); indexing and slicing with static bounds, gathers through a constant integer array (``theta[group]``);
 iteration over a vector.  Anything else -- Python ``if`` on a traced
@@ -21,7 +21,7 @@ import numbers
 
 import numpy as np
 
-__all__ = ["trace", "where", "softplus", "TraceError"]
+__all__ = ["trace", "where", "softplus", "logsumexp", "TraceError"]
 
 
 class TraceError(TypeError):
@@ -279,6 +279,30 @@ def where(cond, a, b):
     if not cond.b:
         raise TraceError("where: the condition must be a comparison")
     return S(ctx, "where", (cond, a, b), cond.t or a.t or b.t)
+
+
+def logsumexp(x):
+    """log(sum(exp(x))) of up to 64 traced terms (a list of scalars or of equally long vectors -- elementwise then --, or the
+    entries of one traced vector): the mixture-model building block, m + log(sum(exp(x_k - m))) with m the largest term."""
+    if isinstance(x, V):
+        items = [x.at(k) for k in range(x.n)]
+    else:
+        items = list(x)
+    ctx = next((y.ctx for y in items if isinstance(y, (S, V))), None)  # (items may be vectors: elementwise over them)
+    if ctx is None:
+        a = np.asarray(items, dtype=np.float64)  # (plain numbers / arrays: the same function over axis 0)
+        m = a.max(axis=0)
+        return m + np.log(np.exp(a - m).sum(axis=0))
+    if not 1 <= len(items) <= 64:
+        raise TraceError(f"logsumexp over {len(items)} terms: 1 ... 64 are supported")
+    items = [_lift(ctx, y) for y in items]
+    m = items[0]
+    for y in items[1:]:
+        m = where(y > m, y, m)
+    tot = _unary(ctx, "exp", items[0] - m)
+    for y in items[1:]:
+        tot = tot + _unary(ctx, "exp", y - m)
+    return m + _unary(ctx, "log", tot)
 
 
 def softplus(x):

@@ -84,7 +84,16 @@ def shared_in_comparison(q):  # a shared node whose other use is a comparison on
     return np.sum(tracing.where(z > 0.1, YL[:40], -YL[:40]) * 0.3 + z * z) + np.sum(tracing.where(q > 0.0, 1.0, 2.0) * q)
 
 
-CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False),
+OBS = R.normal(size=60) * 2.0
+
+
+def mixture(q):  # three-component Gaussian mixture: means q[0:3], log-scales q[3:6], unnormalised log-weights q[6:9]
+    mu, ls, lw = q[0:3], q[3:6], q[6:9]
+    comp = [lw[k] - ls[k] - 0.5 * ((OBS - mu[k]) * np.exp(-ls[k])) ** 2 for k in range(3)]   # per observation, component k
+    return np.sum(tracing.logsumexp(comp)) - 60 * tracing.logsumexp(lw) - 0.5 * np.sum(q * q) / 9.0
+
+
+CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "mixture": (mixture, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False),
          "shared_under_where": (shared_under_where, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
          "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
 
