@@ -384,11 +384,24 @@ def test_generated_reverse_mode_programs_agree_with_forward_mode_on_the_device(s
     captured matrix) run three ways on the GPU: forward mode (dual numbers in the lanes / row passes), the generated
     reverse-mode program on a wavefront per chain, and the same program on a workgroup per chain.  The gradients are
     different programs over the same expression: trajectories agree at 1e-9, discrete outputs are identical."""
-    from aehmc_amd import RandomStream, nuts, targets
-    from aehmc_amd.engine import get_engine
     from test_tracing import random_density
     D = [9, 17, 70, 40, 150][seed % 5]
-    fn = random_density(seed, D)
+    three_way(random_density(seed, D), D, seed)
+
+
+@pytest.mark.parametrize("name", ["mixture", "hierarchical", "gamma", "kitchen_sink"])
+def test_named_models_three_ways_on_the_device(name):
+    """tests/test_tracing.py's models (a three-component Gaussian mixture through logsumexp, random effects with a gather,
+    Gamma observations with a traced shape parameter -- lgamma / digamma --, every supported function at once): forward
+    mode, reverse mode and a workgroup per chain on the GPU"""
+    import test_tracing
+    fn, D, _ = test_tracing.CASES[name]
+    three_way(fn, D, len(name))
+
+
+def three_way(fn, D, seed):
+    from aehmc_amd import RandomStream, nuts, targets
+    from aehmc_amd.engine import get_engine
     eng = get_engine()
     C = 5
     q0 = 0.4 * np.random.default_rng(50 + seed).normal(size=(C, D))
