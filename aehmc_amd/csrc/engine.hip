@@ -63,6 +63,7 @@ struct aehmc_ctx {
   bool opt_compact = true;       // finished chains drop out of the GEMMs
   int opt_block_roll = 0;        // block-resident NUTS: waiting chains that trigger a begin round (0: kernel default)
   int opt_joint_wg = 1;          // traced joint densities with long sweeps: a workgroup per chain (0 never, 1 when it pays, 2 always)
+  int opt_joint_resident = 1;  // joint densities with a reverse-mode program, D <= 512: the register-resident NUTS kernel (0 never, 1 from 17 coordinates on or with long reductions, 2 always)
   bool opt_pc_dense = true;      // per-chain dense metrics, 64 < D <= 512: NUTS in one launch, a wavefront per chain streams its matrix
   int opt_block_dense = 1;       // mid-size dense problems (64 < D <= 512): one workgroup per 16 chains, whole call in one launch
                                  // (1: chain state in registers up to D = 256, in L2-resident work rows above; 2: always work rows)
@@ -876,6 +877,10 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
     ctx->opt_fp_contract = value != 0;
     return 0;
   }
+  if (!strcmp(name, "joint_resident")) {
+    ctx->opt_joint_resident = (int)value;
+    return 0;
+  }
   if (!strcmp(name, "joint_wg")) {
     if (value < 0 || value > 2) FAIL("joint_wg: 0 (never), 1 (default: when it pays), 2 (always)");
     ctx->opt_joint_wg = (int)value;
@@ -1130,6 +1135,7 @@ static int launch_glm(aehmc_ctx *ctx, const EngineArgs &a, const double *q, doub
     HIPCHK(hipGetLastError());                                                        \
   } while (0)
 
+static bool joint_has_grad(const aehmc_ctx *ctx) { return ctx->custom_src.find("#define AEHMC_JOINT_GRAD") != std::string::npos; }
 // joint user-defined target on the lock-step path: U and dU/dq of the (live) chains from their position rows
 static int launch_joint_rows(aehmc_ctx *ctx, const EngineArgs &a, const double *q, double *g, double *U, int to_ctl,
                              hipStream_t st, const int *ri, const int *nr) {
@@ -1328,6 +1334,14 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   // inside the wavefront (k_nuts_resident's DENSE instantiations)
   // a traced joint density with long data sweeps and few chains: a workgroup per chain (k_nuts_joint_wg, run-time compiled)
   if (want_resident && tkind == AEHMC_T_JOINT && nd < 2 && joint_wg_wanted(ctx, C)) return NUTS_PATH_JOINT_WG;
+  // a joint density with a reverse-mode program (a traced Python logprob_fn), scalar / diagonal metric: the register-resident
+  // kernel with the program's rows in LDS -- from 17 coordinates on, or when its reductions are long, it beats the 64
+  // forward passes side by side of the dense-path kernel below (funnel, 4096 chains: D = 32 2.5 -> 3.5e8 leapfrog/s, D = 64
+  // 1.6 -> 3.4e8; D = 4 / 10: 4.7 / 4.0e8 forward against 4.3 / 3.9e8)
+  if (want_resident && tkind == AEHMC_T_JOINT && nd < 2 && D <= FUSED_DENSE_MAX_D && joint_has_grad(ctx) &&
+      (ctx->opt_joint_resident == 2 ||
+       (ctx->opt_joint_resident == 1 && (D > 16 || ctx->custom_src.find("#define AEHMC_JOINT_GRAD_SMALL") != std::string::npos))))
+    return NUTS_PATH_TEAMS;
   if (want_resident && tkind == AEHMC_T_JOINT && D <= FUSED_DENSE_MAX_D) return NUTS_PATH_FUSED_DENSE;  // (run-time compiled)
   if (want_resident && tkind == AEHMC_T_GLM && nd < 2 && (glm_rows_wanted(D, C) || glm_wg_wanted(ctx, D, C))) return NUTS_PATH_GLM_ROWS;  // (run-time compiled)
   // joint target of more than 64 coordinates, scalar / diagonal metric: the lock-step loop of a chain in one wavefront,
@@ -1335,8 +1349,12 @@ static int nuts_path(const aehmc_ctx *ctx, int64_t C, int64_t max_num_expansions
   // -- up to D = 192: beyond, the density's O(D^2 / 64) terms are the whole cost and a wavefront that carries its chain
   // through a deep tree holds its SIMD slot while finished chains idle, where the lock-step path compacts the live
   // chains (funnel, 4096 chains: D = 100 3.1 -> 4.9e7 leapfrog/s in one launch, D = 256 1.41 -> 1.35e7: profiles/r5/INDEX.md)
-  // (a density with a reverse-mode program -- AEHMC_JOINT_GRAD, a traced Python logprob_fn -- costs O(D / 64) per gradient:
-  //  one launch whatever D)
+  // a density with a reverse-mode program (AEHMC_JOINT_GRAD, a traced Python logprob_fn) up to D = 512: the register-resident
+  // kernel, the position handed to the program through LDS rows (nuts_resident.cuh)
+  if (want_resident && tkind == AEHMC_T_JOINT && nd < 2 && D <= 512 && ctx->opt_joint_resident &&
+      ctx->custom_src.find("#define AEHMC_JOINT_GRAD") != std::string::npos)
+    return NUTS_PATH_TEAMS;
+  // (... costs O(D / 64) per gradient: one launch whatever D)
   if (want_resident && tkind == AEHMC_T_JOINT && nd < 2 &&
       (D <= 192 || ctx->custom_src.find("#define AEHMC_JOINT_GRAD") != std::string::npos))
     return NUTS_PATH_JOINT_ROWS;
@@ -1417,6 +1435,14 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
         const std::string name = "aehmc::k_nuts_resident<" + std::to_string(pl.T) + ", " + std::to_string(pl.R) + ", " +
                                  (pl.multi ? "true" : "false") + ", 0, " + (pl.ckl ? "true" : "false") + ">";
         if (int rc = rtc_launch(ctx, "nuts", {name}, name, dim3(pl.grid), dim3(256), pl.dyn, st, a, m)) return rc;
+      } else if (a.tkind == AEHMC_T_JOINT) {  // joint density with a reverse-mode program: one wavefront per chain, rows in LDS
+        ResidentPlan pl = plan_nuts_resident(a, m, 0);
+        pl.T = 64;
+        pl.R = a.D <= 64 ? 1 : a.D <= 128 ? 2 : a.D <= 256 ? 4 : 8;
+        const std::string name = "aehmc::k_nuts_resident<64, " + std::to_string(pl.R) + ", " + (pl.multi ? "true" : "false") + ", 0, false>";
+        if (int rc = rtc_launch(ctx, "jnuts", {name}, name, dim3((unsigned)((C + 3) / 4)), dim3(256),
+                                (size_t)4 * 2 * a.D * sizeof(double), st, a, m))
+          return rc;
       } else {
         HIPCHK(tu::nuts_resident(a, m, st, ctx->opt_resident_min_team));
       }

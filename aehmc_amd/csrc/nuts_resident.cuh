@@ -294,7 +294,43 @@ __global__ __launch_bounds__(DENSE ? RES_DENSE_BLOCK : Team<T>::BLOCK)
       if (MD) v0 = wave_matvec_reg(immW, p[0], Dd, lane);  // imm p'
       kd = ok[0] ? (MD ? v0 * p[0] : (IMM(0) * p[0]) * p[0]) : 0.0;
       kd = wave_sum(kd);
-    } else {
+    }
+#ifdef AEHMC_JOINT_GRAD
+    else if (T == 64 && a.tkind == AEHMC_T_JOINT) {
+      // a joint density with its reverse-mode program (round 6), 64 < D <= 512: the chain in registers as for the
+      // coordinate-wise targets, the position handed to the program through the wavefront's LDS rows -- first stages |
+      // q' -> LDS | logp and its gradient in one sweep | dU/dq' <- LDS, last stage.  The leapfrog's arithmetic is the
+      // loop's below (= engine.cuh leap_stages): the same bits as k_nuts_joint_rows, without its passes over L2 rows.
+      double *const qrow = res_lds + (size_t)wave * 2 * a.D, *const grow = qrow + a.D;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          const double pp = p[r] - b * GGET(r);
+          const double qq = QGET(r) + aa * (IMM(r) * pp);
+          QSET(r, qq);
+          p[r] = pp;
+          qrow[EI(r)] = qq;
+          grow[EI(r)] = 0.0;
+        }
+      }
+      __threadfence_block();  // (the rows are read and updated through other lanes' addresses)
+      const double lp = aehmc_logp_grad(qrow, grow, lane, a.cparams);
+      __threadfence_block();
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (ok[r]) {
+          const double gg = -grow[EI(r)];
+          const double pp = p[r] - b * gg;
+          GSET(r, gg);
+          p[r] = pp;
+          kd += (IMM(r) * pp) * pp;
+        }
+      }
+      team_sum2<T>(usum, kd, single);
+      ct.U_cur = -lp;
+    }
+#endif
+    else {
       // (global operands -- imm when it is not in registers -- are fetched BR elements at a
       // time: one round trip per batch instead of one per element)
 #pragma unroll

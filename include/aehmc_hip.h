@@ -242,6 +242,11 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   The integrator of integrators.py:54-73 within 1e-6 relative (the north star's bar);
  *                   0 (default) rounds every product and sum as the reference does and is bit-identical
  *                   to the oracle.  Momentum draw, energies and accept step are the same code in both modes
+ *  "joint_resident" 1  joint user-defined density with a reverse-mode program, D <= 512, scalar / diagonal metric: NUTS on
+ *                   the register-resident kernel (the position handed to the program through LDS rows) from 17
+ *                   coordinates on or when the density's reductions are long; 2 = at every D <= 512; 0 = never (up to
+ *                   64 coordinates the forward-mode dense-path kernel, above the one-launch kernel over the chains' L2
+ *                   rows, k_nuts_joint_rows: same arithmetic and bits as that one)
  *  "joint_wg"    1  joint user-defined density that comes with its reverse-mode program (AEHMC_JOINT_GRAD) and sweeps
  *                   long data (AEHMC_JOINT_SWEEP_TERMS >= 8192) in a call of <= 2048 chains: a WORKGROUP of eight
  *                   wavefronts per chain runs the program (k_nuts_joint_wg / k_hmc_joint_wg); 0 = never (a wavefront

@@ -425,6 +425,35 @@ def three_way(fn, D, seed):
         np.testing.assert_allclose(out[name][2], out["forward"][2], rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize("D", [65, 128, 200, 512])
+def test_register_resident_joint_kernel_equals_the_rows_kernel_bitwise(D):
+    """64 < D <= 512: a traced joint density runs NUTS on the register-resident kernel (the chain in registers, the
+    position handed to the generated program through LDS rows); engine option joint_resident = 0 keeps the one-launch
+    kernel over the chains' L2 rows.  The leapfrog's arithmetic and the program are the same: the same bits, for single
+    transitions and for sample()."""
+    from aehmc_amd import RandomStream, nuts
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    C = 9
+    q0 = 0.3 * np.random.default_rng(D).normal(size=(C, D))
+    imm = 0.5 + np.random.default_rng(D + 1).random(D)
+    out = {}
+    try:
+        for mode in (1, 0):
+            eng.set_option("joint_resident", mode)
+            kern = nuts.new_kernel(RandomStream(seeds=[11 + c for c in range(C)]), funnel, max_num_expansions=6)
+            state = nuts.new_state(dev(q0), funnel)
+            info, _ = kern(state, 0.04, imm)
+            samples, info2, acc, div = kern.sample(info.state._replace(momentum=None), 0.04, imm, 3)
+            out[mode] = (info.state.position, info.n_leapfrog, info.acceptance_probability, samples, acc, info2.n_leapfrog,
+                         kern._nuts["holder"]["rng"].clone())
+    finally:
+        eng.set_option("joint_resident", 1)
+    assert int(out[1][1].sum()) > C
+    for a, b in zip(out[1], out[0]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("D, full", [(10, False), (100, False), (12, True)])
 def test_python_logprob_fn_under_window_adaptation_and_sample(D, full):
     """window_adaptation.run with a traced density: forward mode (D = 10), the reverse-mode program on the joint-rows

@@ -101,7 +101,9 @@ def traced_joint():
 
     tgt = targets.from_callable(funnel_plus, 100)
     assert isinstance(tgt, targets.CustomJoint) and "#define AEHMC_JOINT_GRAD 1" in tgt.source
-    wg = ("template __global__ void aehmc::k_nuts_joint_wg<8>(aehmc::EngineArgs, aehmc::NutsSampleArgs);\n"
+    wg = ("template __global__ void aehmc::k_nuts_resident<64, 2, true, 0, false>(aehmc::EngineArgs, aehmc::NutsSampleArgs);\n"
+          "template __global__ void aehmc::k_nuts_resident<64, 8, false, 0, false>(aehmc::EngineArgs, aehmc::NutsSampleArgs);\n"
+          "template __global__ void aehmc::k_nuts_joint_wg<8>(aehmc::EngineArgs, aehmc::NutsSampleArgs);\n"
           "template __global__ void aehmc::k_hmc_joint_wg<8>(aehmc::EngineArgs, long long, long long, double *, double *, int *);\n")
     return "#define AEHMC_JOINT_TARGET 1\n" + tgt.source + '#include "engine.cuh"\n#include "nuts_resident.cuh"\n' + wg
 
