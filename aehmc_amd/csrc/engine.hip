@@ -333,7 +333,7 @@ static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vec
     if (which == "nuts" || which == "jnuts") src += "#include \"nuts_resident.cuh\"\n";
     if (which == "wide") src += "#include \"nuts_wide.cuh\"\n";
     if (which == "block") src += "#include \"nuts_block_reg.cuh\"\n";
-    if (which == "hmc") src += "#include \"hmc_fused.cuh\"\n";
+    if (which == "hmc" || which == "jhmcf") src += "#include \"hmc_fused.cuh\"\n";
     if (which == "glm" || which == "glmk") src += "#include \"glm_rows.cuh\"\n";  // ("glmk": one instantiation of the one-launch kernels)
     const std::string inc = "-I" + ctx->custom_inc;
     const char *opts[] = {"--offload-arch=" AEHMC_GPU_ARCH, "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str(),
@@ -433,7 +433,7 @@ static int rtc_launch(aehmc_ctx *ctx, const std::string &which, const std::vecto
            "use the lock-step path (set_option resident_nuts 0 / fused_hmc 0)");
     }
   }
-  if (dyn > 65536)  // (more dynamic LDS than the default limit: allowed per function)
+  if (dyn >= 49152)  // (with the kernel's static LDS more than the default limit: allowed per function)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
   HIPCHK(hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)dyn, st, params, nullptr));
   return 0;
@@ -1777,6 +1777,28 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     if (int rc = prof_begin(ctx, st, p)) return rc;
     if (int rc = rtc_launch(ctx, "hmc", {name}, name, dim3((unsigned)((C + 3) / 4)), dim3(256),
                             (size_t)4 * R * 64 * sizeof(double), st, f))
+      return rc;
+    return prof_end(ctx, st, p);
+  }
+  // traced joint density with its reverse-mode program, 64 < D <= 1024 (round 6): the same fused kernel with the position
+  // and gradient rows of the generated program in LDS ("joint_resident" option; D <= 64 stays on k_hmc_fused_dense)
+  if (ctx->opt_fused_hmc && ctx->opt_joint_resident && ctx->tgt.kind == AEHMC_T_JOINT && joint_has_grad(ctx) && ctx->met.ndim < 2 &&
+      D > FUSED_DENSE_MAX_D && D <= 1024 && !joint_wg_wanted(ctx, C)) {
+    if (int rc = check_per_chain(ctx, C)) return rc;
+    HmcFusedArgs f{};
+    f.C = C; f.D = D; f.L = L; f.eps = step_size; f.thr = divergence_threshold;
+    f.met_ndim = ctx->met.ndim; f.imm = ctx->met.imm; f.sqrt_mass = ctx->met.sqrt_mass;
+    f.imm_cs = ctx->met.per_chain ? (ctx->met.ndim == 0 ? 1 : D) : 0;
+    f.eps_c = ctx->eps_c;
+    f.tkind = AEHMC_T_JOINT; f.cparams = ctx->d_cparams;
+    f.rng = rng; f.q = q; f.U = U; f.g = g; f.out = *out;
+    f.T = T; f.samples = samples; f.acc_hist = acc_hist; f.div_hist = div_hist;
+    const int R = hmc_fused_r(D);
+    const std::string name = "aehmc::k_hmc_fused<" + std::to_string(R) + ", " + std::to_string((int)AEHMC_T_JOINT) + ", false>";
+    bool p = false;
+    if (int rc = prof_begin(ctx, st, p)) return rc;
+    if (int rc = rtc_launch(ctx, "jhmcf", {name}, name, dim3((unsigned)((C + 3) / 4)), dim3(256),
+                            (size_t)4 * 2 * R * 64 * sizeof(double), st, f))
       return rc;
     return prof_end(ctx, st, p);
   }

@@ -68,7 +68,10 @@ inline bool hmc_fused_supported(int tkind, int met_ndim, long long D) {
 // contracted-arithmetic variants at R = 4 take 130 / 156 VGPRs (3 wavefronts) and R = 8 174 (2); held to 4 / 3 they fit
 // 111 / 127 / 168 with nothing spilled inside the leapfrog loop (the diagonal-Gaussian variant at R = 8 would spill there
 // and is left alone).
-constexpr int hmc_fused_min_waves(int R, int TK) { return R <= 4 ? 4 : (R == 8 && TK != AEHMC_T_DIAG_GAUSSIAN ? 3 : 1); }
+// (a traced joint density brings registers of its own: no floor)
+constexpr int hmc_fused_min_waves(int R, int TK) {
+  return TK == AEHMC_T_JOINT ? 1 : R <= 4 ? 4 : (R == 8 && TK != AEHMC_T_DIAG_GAUSSIAN ? 3 : 1);
+}
 
 template <int R, int TK, bool FC = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(hmc_fused_min_waves(R, TK)))) void k_hmc_fused(HmcFusedArgs a) {
@@ -79,7 +82,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(hmc_fused_m
   const long long c = (long long)blockIdx.x * 4 + w;
   if (c >= a.C) return;
   const size_t row = (size_t)c * a.D;
-  double *zrow = zlds + (size_t)w * (R * 64);
+  // TK == AEHMC_T_JOINT (round 6, run-time compiled copy only): a traced joint density with its reverse-mode gradient
+  // (aehmc_logp_grad, tracing.py).  The chain stays in registers as for the coordinate-wise targets; the generated
+  // program reads the position from, and adds the gradient into, two rows of the wavefront's LDS (the first doubles as
+  // the row of normals): k_hmc_joint_rows without its trips through the L2 between the stages.
+  double *zrow = zlds + (size_t)w * ((TK == AEHMC_T_JOINT ? 2 : 1) * R * 64);
 
   double q[R], p[R], g[R], im[R], sm[R], mu[R], sg[R], p0[R], qs[R], gs[R];
   bool ok[R];
@@ -129,7 +136,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(hmc_fused_m
     kd = wave_sum(kd);
     const double H0 = U + 0.5 * kd;  // hmc.py:187
 
-    if (FC) {
+    double U_joint = U;
+    (void)U_joint;
+    if (FC && TK != AEHMC_T_JOINT) {
       constexpr bool DGT = TK == AEHMC_T_DIAG_GAUSSIAN || TK == AEHMC_T_CUSTOM;  // otherwise dU/dq == q
       constexpr bool CUS = TK == AEHMC_T_CUSTOM;
       if (a.L > 0) {
@@ -164,6 +173,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(hmc_fused_m
 #pragma unroll
         for (int r = 0; r < R; r++) g[r] = q[r];
       }
+#ifdef AEHMC_JOINT_GRAD
+    } else if (TK == AEHMC_T_JOINT) {
+      double *const grow = zrow + R * 64;
+      for (long long l = 0; l < a.L; l++) {  // leap_stages<1,1,0>, joint_rows_eval, leap_stages<0,0,1>
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          p[r] = p[r] - b * g[r];
+          q[r] = q[r] + aa * (im[r] * p[r]);
+          if (ok[r]) {
+            zrow[lane + 64 * r] = q[r];
+            grow[lane + 64 * r] = 0.0;
+          }
+        }
+        __threadfence_block();
+        const double lp = aehmc_logp_grad(zrow, grow, lane, a.cparams);
+        __threadfence_block();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          g[r] = ok[r] ? -grow[lane + 64 * r] : 0.0;
+          p[r] = p[r] - b * g[r];
+        }
+        U_joint = -lp;
+      }
+      __threadfence_block();
+#endif
     } else if (TK == AEHMC_T_CUSTOM) {
       for (long long l = 0; l < a.L; l++) {  // leap_stages<1,1,1> with the user's gradient
 #pragma unroll
@@ -212,7 +246,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(hmc_fused_m
         const long long i = lane + 64 * r;
         if (TK == AEHMC_T_STD_NORMAL) usum += 0.5 * (q[r] * q[r]) + AEHMC_LOG_SQRT_2PI;
         else if (TK == AEHMC_T_ISO_GAUSSIAN) usum += q[r] * q[r];
-        else if (TK == AEHMC_T_CUSTOM) {
+        else if (TK == AEHMC_T_JOINT) {
+        } else if (TK == AEHMC_T_CUSTOM) {
           double u_, g_;
           AEHMC_CUSTOM_ELEM(q[r], i, u_, g_);
           usum += u_;
@@ -226,7 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(hmc_fused_m
     }
     usum = wave_sum(usum);
     kd = wave_sum(kd);
-    const double Unew = a.L > 0 ? (TK == AEHMC_T_ISO_GAUSSIAN ? 0.5 * usum : usum) : U;
+    const double Unew = TK == AEHMC_T_JOINT ? U_joint : a.L > 0 ? (TK == AEHMC_T_ISO_GAUSSIAN ? 0.5 * usum : usum) : U;
     double delta = H0 - (Unew + 0.5 * kd);
     if (isnan(delta)) delta = -INFINITY;
     is_div = fabs(delta) > a.thr;

@@ -246,7 +246,8 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   the register-resident kernel (the position handed to the program through LDS rows) from 17
  *                   coordinates on or when the density's reductions are long; 2 = at every D <= 512; 0 = never (up to
  *                   64 coordinates the forward-mode dense-path kernel, above the one-launch kernel over the chains' L2
- *                   rows, k_nuts_joint_rows: same arithmetic and bits as that one)
+ *                   rows, k_nuts_joint_rows: same arithmetic and bits as that one).  HMC: 64 < D <= 1024 on k_hmc_fused
+ *                   compiled against the program in the same way (non-zero), or k_hmc_joint_rows (0): same bits
  *  "joint_wg"    1  joint user-defined density that comes with its reverse-mode program (AEHMC_JOINT_GRAD) and sweeps
  *                   long data (AEHMC_JOINT_SWEEP_TERMS >= 8192) in a call of <= 2048 chains: a WORKGROUP of eight
  *                   wavefronts per chain runs the program (k_nuts_joint_wg / k_hmc_joint_wg); 0 = never (a wavefront

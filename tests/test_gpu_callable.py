@@ -454,6 +454,35 @@ def test_register_resident_joint_kernel_equals_the_rows_kernel_bitwise(D):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("D", [65, 128, 200, 512, 1000])
+def test_hmc_fused_kernel_with_a_traced_joint_density_equals_the_rows_kernel_bitwise(D):
+    """HMC, 64 < D <= 1024: k_hmc_fused compiled against the traced program (chain in registers, position / gradient
+    rows of the program in LDS) against k_hmc_joint_rows (joint_resident = 0): the same bits for a single transition,
+    for sample(), and for the generator state afterwards."""
+    from aehmc_amd import RandomStream, hmc
+    from aehmc_amd.engine import get_engine
+    eng = get_engine()
+    C = 9
+    q0 = 0.3 * np.random.default_rng(D).normal(size=(C, D))
+    imm = 0.5 + np.random.default_rng(D + 1).random(D)
+    out = {}
+    try:
+        for mode in (1, 0):
+            eng.set_option("joint_resident", mode)
+            kern = hmc.new_kernel(RandomStream(seeds=[11 + c for c in range(C)]), funnel)
+            state = hmc.new_state(dev(q0), funnel)
+            info, _ = kern(state, 0.03, imm, 7)
+            samples, info2, acc, div = kern.sample(info.state._replace(momentum=None), 0.03, imm, 5, 4)
+            out[mode] = (info.state.position, info.state.potential_energy, info.state.potential_energy_grad,
+                         info.acceptance_probability, info.state.momentum, samples, acc, div, info2.state.potential_energy_grad,
+                         kern._hmc["holder"]["rng"].clone())
+    finally:
+        eng.set_option("joint_resident", 1)
+    assert 0.0 < float(out[1][6].min()) < 1.0  # (the history holds transitions that were not certain to be accepted)
+    for a, b in zip(out[1], out[0]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("D, full", [(10, False), (100, False), (12, True)])
 def test_python_logprob_fn_under_window_adaptation_and_sample(D, full):
     """window_adaptation.run with a traced density: forward mode (D = 10), the reverse-mode program on the joint-rows

@@ -104,8 +104,11 @@ def traced_joint():
     wg = ("template __global__ void aehmc::k_nuts_resident<64, 2, true, 0, false>(aehmc::EngineArgs, aehmc::NutsSampleArgs);\n"
           "template __global__ void aehmc::k_nuts_resident<64, 8, false, 0, false>(aehmc::EngineArgs, aehmc::NutsSampleArgs);\n"
           "template __global__ void aehmc::k_nuts_joint_wg<8>(aehmc::EngineArgs, aehmc::NutsSampleArgs);\n"
-          "template __global__ void aehmc::k_hmc_joint_wg<8>(aehmc::EngineArgs, long long, long long, double *, double *, int *);\n")
-    return "#define AEHMC_JOINT_TARGET 1\n" + tgt.source + '#include "engine.cuh"\n#include "nuts_resident.cuh"\n' + wg
+          "template __global__ void aehmc::k_hmc_joint_wg<8>(aehmc::EngineArgs, long long, long long, double *, double *, int *);\n"
+          "template __global__ void aehmc::k_hmc_fused<2, 7, false>(aehmc::HmcFusedArgs);\n"
+          "template __global__ void aehmc::k_hmc_fused<16, 7, false>(aehmc::HmcFusedArgs);\n")
+    return ("#define AEHMC_JOINT_TARGET 1\n" + tgt.source + '#include "engine.cuh"\n#include "nuts_resident.cuh"\n#include "hmc_fused.cuh"\n'
+            + wg)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
