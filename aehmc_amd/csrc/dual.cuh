@@ -124,14 +124,47 @@ AEHMC_HD double digamma(double x) {
   return refl + r + ::log(x) - 0.5 / x - ser;
 }
 AEHMC_HD Dual lgamma(Dual x) { return Dual(::lgamma(x.v), digamma(x.v) * x.d); }
-// log(1 + exp(x)) without overflow (the logistic log-likelihood's building block) and the logistic function
-AEHMC_HD double softplus(double x) { return x > 0 ? x + ::log1p(::exp(-x)) : ::log1p(::exp(x)); }
-// (value and derivative from ONE exponential, e = exp(-|x|): softplus = max(x, 0) + log1p(e), its derivative the logistic
-//  function 1 / (1 + e) or e / (1 + e) -- round 6: the density-only logistic regression spent a third of its row function
-//  on the second exponential, profiles/r6/INDEX.md)
+// log(1 + exp(x)) without overflow (the logistic log-likelihood's building block) and the logistic function.
+// Value and derivative come from ONE exponential, e = exp(-|x|): softplus = max(x, 0) + log(1 + e), its derivative the
+// logistic function 1 / (1 + e) or e / (1 + e) (round 6: the density-only logistic regression spent a third of its row
+// function on a second exponential).  log(1 + e) for 0 <= e <= 1 is 2 atanh(s), s = e / (2 + e) <= 1/3: seventeen terms of
+// the odd series (truncation below 2e-18 relative), about 30 instructions where the library's double-double log1p takes
+// over a hundred -- the row function of a logistic regression went from 301 to 190 instructions (profiles/r6/INDEX.md).
+// Within 4 ulp of numpy.logaddexp(0, x) (tests/test_dual.py).
+#define AEHMC_ATANH_C(k) (1.0 / (double)(k))
+AEHMC_HD double log1p_unit(double e) {
+  const double s = e / (2.0 + e), w = s * s;
+  double p = AEHMC_ATANH_C(33);
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(31));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(29));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(27));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(25));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(23));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(21));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(19));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(17));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(15));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(13));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(11));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(9));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(7));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(5));
+  p = __builtin_fma(p, w, AEHMC_ATANH_C(3));
+  const double s2 = s + s;
+  return __builtin_fma(s2 * w, p, s2);
+}
+AEHMC_HD double softplus(double x) { return (x > 0 ? x : 0.0) + log1p_unit(::exp(x > 0 ? -x : x)); }
+AEHMC_HD double logistic(double x) {
+  const double e = ::exp(x > 0 ? -x : x);
+  return (x > 0 ? 1.0 : e) / (1.0 + e);
+}
+AEHMC_HD Dual logistic(Dual x) {
+  const double l = logistic(x.v);
+  return Dual(l, x.d * (l * (1.0 - l)));
+}
 AEHMC_HD Dual softplus(Dual x) {
-  const double e = ::exp(x.v > 0 ? -x.v : x.v), l = ::log1p(e), s = 1.0 / (1.0 + e);
-  return Dual(x.v > 0 ? x.v + l : l, x.d * (x.v > 0 ? s : e * s));
+  const double e = ::exp(x.v > 0 ? -x.v : x.v);
+  return Dual((x.v > 0 ? x.v : 0.0) + log1p_unit(e), x.d * ((x.v > 0 ? 1.0 : e) / (1.0 + e)));
 }
 AEHMC_HD double value_of(double x) { return x; }
 AEHMC_HD double value_of(Dual x) { return x.v; }
@@ -190,5 +223,6 @@ struct JointRow<Dual> {
 // double they are the device library's own functions
 using aehmc::ad::square;
 using aehmc::ad::softplus;
+using aehmc::ad::logistic;
 using aehmc::ad::value_of;
 using aehmc::ad::digamma;

@@ -50,7 +50,13 @@ struct ChainCtl {
 // densities with long unrolled bodies (236 + 32 accumulation registers = 268 for a 512-thread workgroup, 328 with
 // amdgpu_waves_per_eu(1)): a code object that cannot be launched -- HSA_STATUS_ERROR_INVALID_ISA, the process aborts.
 // One wavefront more is asked for (W = 8: three per SIMD, <= 168 + accumulation registers; measured 228).
+// (AEHMC_WG_MIN_WAVES: the engine compiles the eight-wavefront kernels for FOUR per SIMD first -- two workgroups per CU -- and
+//  falls back to three when that program spills: engine.hip wg_program.)
+#ifdef AEHMC_WG_MIN_WAVES
+constexpr int wg_min_waves(int W) { return W == 8 ? AEHMC_WG_MIN_WAVES : (W >= 4 ? W / 4 : 1) + 1; }
+#else
 constexpr int wg_min_waves(int W) { return (W >= 4 ? W / 4 : 1) + 1; }
+#endif
 #ifdef AEHMC_JOINT_TARGET
 #define AEHMC_USER_DENSITY_512 __attribute__((amdgpu_waves_per_eu(3)))  /* (512-thread kernels compiled against a user's joint density) */
 #else

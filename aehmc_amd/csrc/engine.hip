@@ -63,6 +63,8 @@ struct aehmc_ctx {
   bool opt_compact = true;       // finished chains drop out of the GEMMs
   int opt_block_roll = 0;        // block-resident NUTS: waiting chains that trigger a begin round (0: kernel default)
   int opt_joint_wg = 1;          // traced joint densities with long sweeps: a workgroup per chain (0 never, 1 when it pays, 2 always)
+  int opt_wg_waves = 0;          // wavefronts per SIMD the workgroup-per-chain kernels are compiled for (0: four unless the program then spills, see wg_program; 3; 4)
+  std::map<std::string, std::string> wg_choice;  // (wg_program: kernel -> the program variant that was picked)
   int opt_joint_resident = 1;  // joint densities with a reverse-mode program, D <= 512: the register-resident NUTS kernel (0 never, 1 from 17 coordinates on or with long reductions, 2 always)
   bool opt_pc_dense = true;      // per-chain dense metrics, 64 < D <= 512: NUTS in one launch, a wavefront per chain streams its matrix
   int opt_block_dense = 1;       // mid-size dense problems (64 < D <= 512): one workgroup per 16 chains, whole call in one launch
@@ -316,16 +318,20 @@ extern "C" int aehmc_rtc_stats(const aehmc_ctx *ctx, int64_t *compiled, int64_t 
   return 0;
 }
 
-static int rtc_function(aehmc_ctx *ctx, const std::string &which, const std::vector<std::string> &names,
+static int rtc_function(aehmc_ctx *ctx, const std::string &which_full, const std::vector<std::string> &names,
                         const std::string &want, hipFunction_t *out) {
   // "j*": the programs of a joint target (engine.cuh: AEHMC_JOINT_TARGET) -- "jbase" new_state, "jnuts" / "jhmc" one
   // instantiation of the small-problem kernels each
+  // (a trailing digit -- "jwg4", "glmk3" -- is the occupancy the workgroup-per-chain kernels are compiled for: wg_program)
+  const std::string key = which_full + "|" + ((which_full == "base" || which_full == "glm" || which_full == "jbase") ? std::string() : want);
+  const int wg_waves = isdigit((unsigned char)which_full.back()) ? which_full.back() - '0' : 0;
+  const std::string which = wg_waves ? which_full.substr(0, which_full.size() - 1) : which_full;
   const bool joint = which[0] == 'j';
-  const std::string key = which + "|" + ((which == "base" || which == "glm" || which == "jbase") ? std::string() : want);
   auto it = ctx->rtc.find(key);
   if (it == ctx->rtc.end()) {
     if (ctx->custom_src.empty()) FAIL("internal: no user-defined target source");
     std::string src = RTC_PROLOGUE;
+    if (wg_waves) src += "#define AEHMC_WG_MIN_WAVES " + std::to_string(wg_waves) + "\n";
     if (joint) src += "#define AEHMC_JOINT_TARGET 1\n";  // (engine.cuh: leap_small_dense calls aehmc_logp through dual.cuh)
     else if (which != "glm" && which != "glmk") src += "#define AEHMC_CUSTOM_TARGET 1\n";  // (engine.cuh: target_elem calls aehmc_custom_elem)
     src += "#line 1 \"custom_target\"\n" + ctx->custom_src + "\n";
@@ -439,6 +445,31 @@ static int rtc_launch(aehmc_ctx *ctx, const std::string &which, const std::vecto
   return 0;
 }
 
+// The workgroup-per-chain kernels (512 threads) are compiled for FOUR wavefronts per SIMD -- 128 registers per lane, two
+// workgroups per CU -- unless the program then keeps more than WG_SCRATCH_MAX bytes per lane in scratch (a density with
+// many per-lane accumulators: its sweep would spill): three (168 registers, one workgroup per CU) in that case.  Logistic
+// regression N = 1e5, D = 8, 1024 chains, NUTS: 28.8 -> 22.9 ms per transition (profiles/r6/INDEX.md).  "wg_waves" option:
+// 3 / 4 force one.
+constexpr int WG_SCRATCH_MAX = 320;
+static int wg_program(aehmc_ctx *ctx, const std::string &base, const std::vector<std::string> &names, const std::string &want,
+                      std::string *which) {
+  if (ctx->opt_wg_waves == 3 || ctx->opt_wg_waves == 4) {
+    *which = base + std::to_string(ctx->opt_wg_waves);
+    return 0;
+  }
+  const std::string key = base + "|" + want;
+  auto it = ctx->wg_choice.find(key);
+  if (it == ctx->wg_choice.end()) {
+    hipFunction_t f = nullptr;
+    if (int rc = rtc_function(ctx, base + "4", names, want, &f)) return rc;
+    int scratch = 0;
+    (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f);
+    it = ctx->wg_choice.emplace(key, base + (scratch > WG_SCRATCH_MAX ? "3" : "4")).first;
+  }
+  *which = it->second;
+  return 0;
+}
+
 static const std::vector<std::string> RTC_GLM = {"aehmc::k_glm_rows", "aehmc::k_glm_finish"};
 __global__ void k_transpose_rect(const double *src, double *dst, long long rows, long long cols) {  // dst [cols, rows]
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -495,6 +526,7 @@ static int custom_bind(aehmc_ctx *ctx, const char *source, const char *include_d
     return rc;
   }
   custom_release(nb);
+  if (!same_source) ctx->wg_choice.clear();  // (wg_program's picks belong to the previous function's programs)
   return 0;
 }
 extern "C" int aehmc_set_custom_glm_target(aehmc_ctx *ctx, const char *source, int64_t D, int64_t N, const double *X,
@@ -884,6 +916,11 @@ extern "C" int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value)
   if (!strcmp(name, "joint_wg")) {
     if (value < 0 || value > 2) FAIL("joint_wg: 0 (never), 1 (default: when it pays), 2 (always)");
     ctx->opt_joint_wg = (int)value;
+    return 0;
+  }
+  if (!strcmp(name, "wg_waves")) {
+    if (value != 0 && value != 3 && value != 4) FAIL("wg_waves: 0 (default: four unless the program spills), 3, 4");
+    ctx->opt_wg_waves = (int)value;
     return 0;
   }
   FAIL(std::string("unknown option ") + name);
@@ -1288,10 +1325,10 @@ static bool glm_wg_wanted(const aehmc_ctx *ctx, int64_t D, int64_t C) {
   return ctx->opt_joint_wg > 1 || (ctx->glm_N >= 8192 && C <= 2048);
 }
 static std::string glm_wg_name(const char *kernel, int64_t D) {
-  return std::string("aehmc::") + kernel + "<" + (D <= 8 ? "8" : D <= 16 ? "16" : "32") + ", 8>";
+  return std::string("aehmc::") + kernel + "<" + std::to_string(D) + ", 8>";  // (the kernel for the target's own D)
 }
 static std::string glm_rows_name(const char *kernel, int64_t D) {
-  return std::string("aehmc::") + kernel + "<" + (D <= 8 ? "8" : D <= 16 ? "16" : "32") + ">";
+  return std::string("aehmc::") + kernel + "<" + std::to_string(D) + ">";
 }
 // workspace of the small-dense kernels with per-chain metrics (hipFree waits for earlier launches that use it)
 static int fused_dense_workspace(aehmc_ctx *ctx, size_t need, double **out) {
@@ -1517,7 +1554,10 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     const std::string name = wg ? glm_wg_name("k_nuts_glm_wg", a.D) : glm_rows_name("k_nuts_glm_rows", a.D);
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (int rc = rtc_launch(ctx, "glmk", {name}, name, wg ? dim3((unsigned)C) : chain_grid(C), dim3(wg ? 512 : 256), 0, st, a, m,
+    std::string prog = "glmk";
+    if (wg)
+      if (int rc = wg_program(ctx, "glmk", {name}, name, &prog)) return rc;
+    if (int rc = rtc_launch(ctx, prog, {name}, name, wg ? dim3((unsigned)C) : chain_grid(C), dim3(wg ? 512 : 256), 0, st, a, m,
                             (const double *)ctx->glm_XT, ctx->glm_y, (long long)ctx->glm_N))
       return rc;
     return prof_end(ctx, st, p);
@@ -1531,7 +1571,9 @@ static int nuts_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size,
     }
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (int rc = rtc_launch(ctx, "jwg", RTC_JWG, RTC_JWG[0], dim3((unsigned)C), dim3(512), (size_t)2 * a.D * sizeof(double), st, a, m))
+    std::string prog;
+    if (int rc = wg_program(ctx, "jwg", RTC_JWG, RTC_JWG[0], &prog)) return rc;
+    if (int rc = rtc_launch(ctx, prog, RTC_JWG, RTC_JWG[0], dim3((unsigned)C), dim3(512), (size_t)2 * a.D * sizeof(double), st, a, m))
       return rc;
     return prof_end(ctx, st, p);
   }
@@ -1924,7 +1966,10 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
     const std::string name = wg ? glm_wg_name("k_hmc_glm_wg", D) : glm_rows_name("k_hmc_glm_rows", D);
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (int rc = rtc_launch(ctx, "glmk", {name}, name, wg ? dim3((unsigned)C) : chain_grid(C), dim3(wg ? 512 : 256), 0, st, a, (long long)L,
+    std::string prog = "glmk";
+    if (wg)
+      if (int rc = wg_program(ctx, "glmk", {name}, name, &prog)) return rc;
+    if (int rc = rtc_launch(ctx, prog, {name}, name, wg ? dim3((unsigned)C) : chain_grid(C), dim3(wg ? 512 : 256), 0, st, a, (long long)L,
                             (long long)T, samples, acc_hist,
                             (int *)div_hist, (const double *)ctx->glm_XT, ctx->glm_y, (long long)ctx->glm_N))
       return rc;
@@ -1936,7 +1981,9 @@ static int hmc_run(aehmc_ctx *ctx, int64_t C, uint64_t *rng, double step_size, i
   if (ctx->opt_fused_hmc && tjoint && a.met_ndim < 2 && joint_wg_wanted(ctx, C)) {
     bool p = false;
     if (int rc = prof_begin(ctx, st, p)) return rc;
-    if (int rc = rtc_launch(ctx, "jwg", RTC_JWG, RTC_JWG[1], dim3((unsigned)C), dim3(512), (size_t)2 * D * sizeof(double), st, a,
+    std::string prog;
+    if (int rc = wg_program(ctx, "jwg", RTC_JWG, RTC_JWG[1], &prog)) return rc;
+    if (int rc = rtc_launch(ctx, prog, RTC_JWG, RTC_JWG[1], dim3((unsigned)C), dim3(512), (size_t)2 * D * sizeof(double), st, a,
                             (long long)L, (long long)T, samples, acc_hist, (int *)div_hist))
       return rc;
     if (int rc = prof_end(ctx, st, p)) return rc;

@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void k_glm_finish(EngineArgs a, const double *
 
 // ---- small-D row-reduction targets in ONE launch per call (round 5) ---------------------------------------------------
 // The lock-step path above pays two chain-batched GEMMs and three more launches per leapfrog -- right for large D x N,
-// ~80 us per leapfrog whatever the size.  With D <= DA (8 / 16 / 32) coordinates the wavefront that owns a chain can
-// sweep the data itself: lane l takes rows l, l + 64, ... (X^T [D][N]: coalesced), forms z_n = sum_d x_nd q_d with the
+// ~80 us per leapfrog whatever the size.  With D = DA <= 32 coordinates (the kernels are compiled at run time, for the
+// target's own D) the wavefront that owns a chain can sweep the data itself: lane l takes rows l, l + 64, ... (X^T [D][N]: coalesced), forms z_n = sum_d x_nd q_d with the
 // position in LDS, calls the user's row function and keeps D partial sums of x_nd dloss_n in registers; D wave sums and
 // the prior finish U and dU/dq.  Around it the lock-step engine's own stage / bookkeeping device functions, one chain
 // per wavefront (as k_nuts_fused / k_nuts_pc_dense / k_nuts_joint_rows).  The sums run in another order than the GEMMs':
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_glm_finish(EngineArgs a, const double *
 template <int DA>
 __device__ inline double glm_rows_eval(const EngineArgs &a, const double *XT, const double *y, long long N, const double *q,
                                        double *g, double *qs, int lane) {
-  const int D = (int)a.D;
+  constexpr int D = DA;  // (the engine instantiates the kernel for the target's own D: no predicates in the row loop)
   for (int d = lane; d < D; d += 64) qs[d] = q[d];
   __threadfence_block();  // (read back as broadcasts)
   double acc[DA], ls = 0.0;
@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void k_hmc_glm_rows(EngineArgs a, long long L,
 template <int DA, int W>
 __device__ inline double glm_rows_eval_wg(const EngineArgs &a, const double *XT, const double *y, long long N, const double *q,
                                           double *g, double *qs, double *part, int tid) {
-  const int D = (int)a.D, lane = tid & 63, wave = tid >> 6;
+  constexpr int D = DA;
+  const int lane = tid & 63, wave = tid >> 6;
   if (tid < D) qs[tid] = q[tid];
   __syncthreads();
   double acc[DA], ls = 0.0;

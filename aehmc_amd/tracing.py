@@ -9,7 +9,7 @@ position): traced ONCE with proxy objects and emitted as the ``aehmc_logp`` temp
 What a traced function may do with its argument (a scalar for a scalar position, else a vector of ``dim`` entries):
 ``+ - * / **`` and unary ``-`` with numbers, numpy arrays (captured as device parameter arrays) and other traced values;
 numpy ufuncs ``exp log log1p expm1 sqrt sin cos tanh abs square power reciprocal negative maximum minimum logaddexp``
-``scipy.special.erf`` and ``scipy.special.gammaln``; ``softplus``, ``logsumexp`` (up to 64 terms) and ``where`` from this module; comparisons (inside ``where`` only);
+``scipy.special.erf``, ``scipy.special.expit`` and ``scipy.special.gammaln``; ``softplus``, ``logsumexp`` (up to 64 terms) and ``where`` from this module; comparisons (inside ``where`` only);
 ``.sum()`` / ``np.sum`` / ``.mean()``, ``@`` / ``np.dot`` (vector . vector, constant matrix @ vector, vector @ constant
 matrix); indexing and slicing with static bounds, gathers through a constant integer array (``theta[group]``);
 iteration over a vector.  Anything else -- Python ``if`` on a traced
@@ -78,7 +78,8 @@ class Idx:
 
 # ------------------------------------------------------------------------------------------------------ scalars
 _UNARY = {"exp": "exp", "log": "log", "log1p": "log1p", "expm1": "expm1", "sqrt": "sqrt", "sin": "sin", "cos": "cos",
-          "tanh": "tanh", "absolute": "fabs", "fabs": "fabs", "erf": "erf", "softplus": "softplus", "gammaln": "lgamma", "lgamma": "lgamma"}
+          "tanh": "tanh", "absolute": "fabs", "fabs": "fabs", "erf": "erf", "softplus": "softplus", "gammaln": "lgamma", "lgamma": "lgamma", "expit": "logistic",
+          "logistic": "logistic"}
 _CMP = {"less": "<", "greater": ">", "less_equal": "<=", "greater_equal": ">=", "equal": "==", "not_equal": "!="}
 
 
@@ -227,7 +228,7 @@ def _unary(ctx, name, x):
         raise TraceError(f"{name} of a comparison result")
     if x.op == "const":
         with np.errstate(all="ignore"):
-            f = {"fabs": np.fabs, "erf": _erf_np, "softplus": lambda z: np.logaddexp(0.0, z),
+            f = {"fabs": np.fabs, "erf": _erf_np, "softplus": lambda z: np.logaddexp(0.0, z), "logistic": lambda z: 1.0 / (1.0 + np.exp(-z)),
                  "lgamma": lambda z: __import__("math").lgamma(float(z))}.get(name) or getattr(np, name)
             return _const(ctx, f(x.args[0]))
     return S(ctx, "un", (name, x), x.t)
@@ -676,7 +677,7 @@ def _elementwise_var(root, dim, scalar):
 _UN_BWD = {"exp": "{a} * {v}", "log": "{a} / {x}", "log1p": "{a} / (1.0 + {x})", "expm1": "{a} * exp({x})",
            "sqrt": "0.5 * {a} / {v}", "sin": "{a} * cos({x})", "cos": "-({a} * sin({x}))", "tanh": "{a} * (1.0 - {v} * {v})",
            "fabs": "({x} < 0 ? -{a} : {a})", "erf": "{a} * 1.1283791670955126 * exp(-{x} * {x})",
-           "softplus": "{a} / (1.0 + exp(-{x}))", "square": "2.0 * {x} * {a}", "lgamma": "{a} * aehmc::ad::digamma({x})"}
+           "softplus": "{a} * aehmc::ad::logistic({x})", "logistic": "{a} * {v} * (1.0 - {v})", "square": "2.0 * {x} * {a}", "lgamma": "{a} * aehmc::ad::digamma({x})"}
 
 
 def _free_vars(e):
@@ -1149,7 +1150,7 @@ template <int W> __device__ inline double aehmc_wsum_(double x) {  // xor butter
 #define AEHMC_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #endif
 __device__ inline double aehmc_sq(double x) { return x * x; }
-__device__ inline double aehmc_softplus(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+__device__ inline double aehmc_softplus(double x) { return aehmc::ad::softplus(x); }
 #define AEHMC_JOINT_GRAD 1
 // log-density and its gradient in one reverse sweep, run by AEHMC_W wavefronts together (`lane` = the thread's index among
 // their 64 AEHMC_W lanes): q = the position row, g = the gradient row (both in LDS; g zeroed by the caller); every lane

@@ -453,6 +453,49 @@ def traced_secondary(eng, device, D=1000, C=4096, T=5):
         return [{"config": f"python-funnel-nuts-d{D}", "error": repr(e)[:300]}]
 
 
+def glm_secondary(eng, device, N=100_000, D=8, C=1024, T=4):
+    """Logistic regression over N data rows given by its per-row log-likelihood only (targets.CustomGLM; VERDICT r5 item 4's
+    shape: N = 1e5, D = 8, 1024 chains, NUTS depth 6; round 5: 8.0e4 leapfrog/s): a workgroup of eight wavefronts per chain
+    sweeps the rows (k_nuts_glm_wg).  Bound by VALU issue on the row function; counted at 4 D + 60 fp64 lane-operations per
+    row (dot product and gradient accumulation; one exponential, the log(1 + e) series and a division for softplus and its
+    derivative)."""
+    from aehmc_amd import RandomStream, nuts, targets
+    src = """
+template <class T> __device__ T aehmc_glm_loglik(T z, double y, long long n, const double *const *prm) { return y * z - softplus(z); }
+template <class T> __device__ T aehmc_glm_logprior(T q, long long i, const double *const *prm) { return -0.5 * q * q / 4.0; }
+"""
+    name = f"custom-logistic-nuts-n{N}"
+    try:
+        r = np.random.default_rng(0)
+        X = r.normal(size=(N, D))
+        w = r.normal(size=D)
+        y = (r.random(N) < 1.0 / (1.0 + np.exp(-X @ w))).astype(np.float64)
+        tgt = targets.CustomGLM(src, torch.as_tensor(X, device=device), torch.as_tensor(y, device=device))
+        kernel = nuts.new_kernel(RandomStream(seeds=list(range(C))), tgt, max_num_expansions=6)
+        state = nuts.new_state(torch.as_tensor(w + 0.1 * r.standard_normal((C, D)), device=device), tgt)
+        eps, imm = 0.3 / np.sqrt(N), torch.ones(D, dtype=torch.float64, device=device)
+        for _ in range(2):
+            state = kernel(state, eps, imm)[0].state._replace(momentum=None)
+        torch.cuda.synchronize(device)
+        t0, nl = time.perf_counter(), 0
+        for _ in range(T):
+            info = kernel(state, eps, imm)[0]
+            state = info.state._replace(momentum=None)
+            nl += int(info.n_leapfrog.sum().item())
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        ops = nl / dt * N * (4.0 * D + 60.0) / 1e12
+        peak = 256 * 4 * 16 * 2.4e9 / 1e12
+        return [{"config": name,
+                 "workload": f"logistic regression by its row log-likelihood, N={N} rows, D={D}, NUTS depth 6, {C} chains",
+                 "value": nl / dt, "unit": "leapfrog-steps/s", "ms_per_transition": dt / T * 1e3,
+                 "kernel": f"k_nuts_glm_wg<{D},8> (hipRTC)",
+                 "roofline": {"bound": "valu", "unit": "Tlane-op/s (fp64, 4 D + 60 per row)", "achieved": ops, "peak": peak,
+                              "frac": ops / peak, "launches": T}}]
+    except Exception as e:  # a failing side measurement must not cost the main line
+        return [{"config": name, "error": repr(e)[:300]}]
+
+
 def launch_ranks(n, timeout_s=None):
     """`python bench.py --gpus N` without a launcher: start N fresh child ranks (one process per
     GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches
@@ -733,6 +776,7 @@ def main():
         secondary += pc_dense_secondary(eng, device)
         secondary += custom_secondary(eng, device)
         secondary += traced_secondary(eng, device)
+        secondary += glm_secondary(eng, device)
         torch.cuda.empty_cache()
         secondary += other_configs()
 

@@ -252,7 +252,10 @@ int aehmc_set_metric(aehmc_ctx *ctx, const aehmc_metric *metric);
  *                   long data (AEHMC_JOINT_SWEEP_TERMS >= 8192) in a call of <= 2048 chains: a WORKGROUP of eight
  *                   wavefronts per chain runs the program (k_nuts_joint_wg / k_hmc_joint_wg); 0 = never (a wavefront
  *                   per chain), 2 = always.  Discrete outputs identical, values to rounding (the sums are associated
- *                   differently) */
+ *                   differently).  Also the workgroup-per-chain kernels of a row-reduction target (GLM, N >= 8192)
+ *  "wg_waves"    0  wavefronts per SIMD those workgroup-per-chain kernels are compiled for: 4 (two workgroups per CU,
+ *                   128 registers per lane), 3 (one, 168 registers); 0 = four unless the program then keeps more than
+ *                   320 bytes per lane in scratch.  Same results either way */
 int aehmc_set_option(aehmc_ctx *ctx, const char *name, int64_t value);
 
 /* workspace the caller must provide to the step calls for C chains */

@@ -71,3 +71,29 @@ def test_digamma_against_scipy(tmp_path):
     out = subprocess.run([str(exe)], input="\n".join(repr(float(x)) for x in xs), capture_output=True, text=True, check=True).stdout.split()
     got = np.array([float(v) for v in out])
     np.testing.assert_allclose(got, digamma(xs), rtol=5e-14, atol=5e-15)
+
+
+def test_softplus_and_logistic_against_numpy(tmp_path):
+    """dual.cuh's softplus (one exponential + the 17-term atanh series for log(1 + e), e <= 1) and logistic function:
+    within 4 ulp of numpy.logaddexp(0, x) / scipy.special.expit over the whole range, exact limits at +-inf"""
+    import numpy as np
+    from scipy.special import expit
+    xs = np.concatenate([np.linspace(-745.0, 745.0, 1501), np.linspace(-40.0, 40.0, 4001), np.random.default_rng(0).normal(0, 3, 4000),
+                         [0.0, -0.0, 1e-300, -1e-300, np.inf, -np.inf]])
+    src = tmp_path / "sp.cpp"
+    src.write_text('#include <cstdio>\n#include <cmath>\n#include "dual.cuh"\nint main() { double x; while (std::scanf("%lf", &x) == 1) { '
+                   'const aehmc::Dual r = softplus(aehmc::Dual(x, 1.0)); const aehmc::Dual l = logistic(aehmc::Dual(x, 1.0)); '
+                   'std::printf("%.17g %.17g %.17g %.17g %.17g\\n", aehmc::ad::softplus(x), r.v, r.d, l.v, l.d); } return 0; }\n')
+    exe = tmp_path / "sp"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "aehmc_amd", "csrc"), "-o", str(exe), str(src)])
+    out = subprocess.run([str(exe)], input="\n".join(repr(float(x)) for x in xs), capture_output=True, text=True, check=True).stdout.split()
+    got = np.array([float(v) for v in out]).reshape(len(xs), 5)
+    want = np.logaddexp(0.0, xs)
+    assert np.array_equal(got[:, 0], got[:, 1])
+    np.testing.assert_array_max_ulp(got[:, 0], want, maxulp=4)
+    with np.errstate(over="ignore"):
+        s = expit(xs)
+    np.testing.assert_allclose(got[:, 2], s, rtol=2e-15, atol=1e-300)  # (expit flushes the subnormal tail to 0)
+    np.testing.assert_allclose(got[:, 3], s, rtol=2e-15, atol=1e-300)
+    np.testing.assert_allclose(got[:, 4], s * (1.0 - s), rtol=4e-15, atol=1e-300)
+    assert got[-2, 0] == np.inf and got[-1, 0] == 0.0 and got[-2, 2] == 1.0 and got[-1, 2] == 0.0

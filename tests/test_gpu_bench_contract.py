@@ -139,7 +139,7 @@ def test_bench_default_line_has_its_good_secondary_entries():
     assert d["config"]["dim"] == 10_000 and d["config"]["chains_total"] == 4096
     sec = d["secondary"]
     assert [e["config"] for e in sec] == ["diag-nuts", "diag-hmc", "diag-hmc-fp_contract", "dense-nuts-d100", "dense-nuts-d200",
-                                          "pc-dense-nuts-d200", "custom-student-t-nuts-d5000", "python-funnel-nuts-d1000", "c2", "c2-fp_contract", "c5", "c1"]
+                                          "pc-dense-nuts-d200", "custom-student-t-nuts-d5000", "python-funnel-nuts-d1000", "custom-logistic-nuts-n100000", "c2", "c2-fp_contract", "c5", "c1"]
     for e in sec:
         assert "error" not in e and e["value"] > 0, e
     by = {e["config"]: e for e in sec}

@@ -412,6 +412,48 @@ def test_custom_glm_workgroup_per_chain_equals_wavefront_per_chain(eng, N, D):
         np.testing.assert_allclose(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy(), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("N, D, waves", [(63, 3, 0), (64, 8, 0), (65, 8, 3), (2500, 8, 4), (100_000, 8, 0), (9000, 21, 0)])
+def test_custom_glm_workgroup_kernels_match_numpy(eng, N, D, waves):
+    """The workgroup-per-chain kernels (forced: joint_wg = 2) against the numpy restatement, chain by chain, from one
+    wavefront's worth of rows to 10^5; compiled for three / four wavefronts per SIMD (option wg_waves; 0 = the engine picks)."""
+    from aehmc_amd import RandomStream, hmc, nuts, targets
+    X, y, w = logistic_data(N, D, N + D)
+    r = np.random.default_rng(D)
+    tau, C = 2.0, 3
+    q0 = (w if N > 1000 else 0.0) + 0.3 * r.normal(size=(C, D)) / np.sqrt(N / 100.0)  # (long data: a start near the narrow posterior)
+    imm = (0.02 + 0.05 * r.random(D)) * min(1.0, 300.0 / N)
+    tgt, otgt = targets.CustomGLM(LOGISTIC, dev(X), dev(y), params=[[tau]]), Logistic(X, y, tau)
+    seeds = [11 + c for c in range(C)]
+    try:
+        eng.set_option("joint_wg", 2)
+        eng.set_option("wg_waves", waves)
+        state = nuts.new_state(dev(q0), tgt)
+        kern = nuts.new_kernel(RandomStream(seeds=seeds), tgt, max_num_expansions=5)
+        ref = oracle_nuts(otgt, seeds, q0, 0.5, imm, 5, 2)
+        nl = 0
+        for t in range(2):
+            info, _ = kern(state, 0.5, imm)
+            state = info.state._replace(momentum=None)
+            for c in range(C):
+                o = ref[c][t]
+                np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-11)
+                np.testing.assert_allclose(info.state.potential_energy[c].item(), o.state.potential_energy, rtol=RTOL)
+                np.testing.assert_allclose(info.state.potential_energy_grad[c].cpu().numpy(), o.state.potential_energy_grad, rtol=1e-8, atol=1e-8)
+                assert info.n_leapfrog[c].item() == o.n_leapfrog and info.num_doublings[c].item() == o.num_doublings
+                assert bool(info.is_turning[c]) == bool(o.is_turning) and bool(info.is_diverging[c]) == bool(o.is_diverging)
+                nl += o.n_leapfrog
+        assert nl > 2 * C
+        hk = hmc.new_kernel(RandomStream(seeds=seeds), tgt)
+        info, _ = hk(hmc.new_state(dev(q0), tgt), 0.3, imm, 6)
+        for c in range(C):
+            o = no.hmc_kernel(no.RandomStream(seeds[c]), otgt)(no.new_state(q0[c].copy(), otgt), 0.3, imm, 6)
+            np.testing.assert_allclose(info.state.position[c].cpu().numpy(), o.state.position, rtol=RTOL, atol=1e-11)
+            np.testing.assert_allclose(info.acceptance_probability[c].item(), o.acceptance_probability, rtol=1e-8)
+    finally:
+        eng.set_option("joint_wg", 1)
+        eng.set_option("wg_waves", 0)
+
+
 def test_custom_glm_posterior(eng):
     """Bayesian logistic regression sampled with NUTS after window adaptation (the use the reference's README and
     notebook show for its own models): the posterior mean recovers the generating weights within its own spread, and

@@ -62,6 +62,12 @@ def logistic(q):  # a data matrix captured from the closure: z = X @ q is ONE no
     return (YL * z - tracing.softplus(z)).sum() - 0.5 * (q @ q) / 4.0
 
 
+def bernoulli_expit(q):  # scipy.special.expit as the link function: log p = y log s + (1 - y) log(1 - s), s = expit(X q)
+    from scipy.special import expit
+    s = expit(XL @ q)
+    return np.sum(YL * np.log(s) + (1.0 - YL) * np.log1p(-s)) - 0.5 * np.sum(q * q)
+
+
 def shared_under_where(q):  # a shared sub-expression with a use inside a where-branch (never merged: see _RevGen.count_uses)
     u = np.exp(q[:3]) + q[3:6] ** 2
     return np.sum(tracing.where(q[:3] > 0.1, u * q[3:6], -u) + np.sin(u)) - 0.5 * np.sum(q * q)
@@ -93,7 +99,7 @@ def mixture(q):  # three-component Gaussian mixture: means q[0:3], log-scales q[
     return np.sum(tracing.logsumexp(comp)) - 60 * tracing.logsumexp(lw) - 0.5 * np.sum(q * q) / 9.0
 
 
-CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "mixture": (mixture, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False),
+CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "mixture": (mixture, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False), "bernoulli_expit": (bernoulli_expit, 5, False),
          "shared_under_where": (shared_under_where, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
          "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
 
