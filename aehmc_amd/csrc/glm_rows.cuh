@@ -64,6 +64,11 @@ __global__ __launch_bounds__(256) void k_glm_finish(EngineArgs a, const double *
 // the prior finish U and dU/dq.  Around it the lock-step engine's own stage / bookkeeping device functions, one chain
 // per wavefront (as k_nuts_fused / k_nuts_pc_dense / k_nuts_joint_rows).  The sums run in another order than the GEMMs':
 // results agree with the lock-step path to rounding (1e-13), with the numpy restatement at the usual 1e-9.
+// Wavefronts per SIMD the one-launch kernels leave room for.  Instantiated for the target's own D the row loop has no
+// predicates and the compiler, left alone, spends registers on it (k_nuts_glm_rows<16>: 255, ONE wavefront per SIMD where
+// 4096 chains are four).  Logistic regression N = 1e4, 4096 chains, NUTS, ms per transition at 1 / 2 / 3 / 4 wavefronts asked
+// for: D = 8 8.7 / 8.9 / 8.8 / 8.2, D = 16 23.2 / 18.5 / 18.7 / 22.7 (profiles/r6/INDEX.md).
+constexpr int glm_rows_min_waves(int DA) { return DA <= 8 ? 4 : 2; }
 template <int DA>
 __device__ inline double glm_rows_eval(const EngineArgs &a, const double *XT, const double *y, long long N, const double *q,
                                        double *g, double *qs, int lane) {
@@ -122,7 +127,7 @@ __device__ inline double glm_rows_eval(const EngineArgs &a, const double *XT, co
   return ls + us;
 }
 template <int DA>
-__global__ __launch_bounds__(256) void k_nuts_glm_rows(EngineArgs a, NutsSampleArgs m, const double *XT, const double *y, long long N) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(glm_rows_min_waves(DA)))) void k_nuts_glm_rows(EngineArgs a, NutsSampleArgs m, const double *XT, const double *y, long long N) {
   __shared__ double glm_q[4][DA];
   AEHMC_CHAIN_OF_WAVE();
   double *const qs = glm_q[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void k_nuts_glm_rows(EngineArgs a, NutsSampleA
   if (lane == 0 && m.nleap_total) m.nleap_total[c] = nleap_sum;
 }
 template <int DA>
-__global__ __launch_bounds__(256) void k_hmc_glm_rows(EngineArgs a, long long L, long long nt, double *samples, double *acc_hist,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(glm_rows_min_waves(DA)))) void k_hmc_glm_rows(EngineArgs a, long long L, long long nt, double *samples, double *acc_hist,
                                                       int *div_hist, const double *XT, const double *y, long long N) {
   __shared__ double glm_q[4][DA];
   AEHMC_CHAIN_OF_WAVE();
