@@ -680,6 +680,10 @@ _UN_BWD = {"exp": "{a} * {v}", "log": "{a} / {x}", "log1p": "{a} / (1.0 + {x})",
            "softplus": "{a} * aehmc::ad::logistic({x})", "logistic": "{a} * {v} * (1.0 - {v})", "square": "2.0 * {x} * {a}", "lgamma": "{a} * aehmc::ad::digamma({x})"}
 
 
+# (functions of the generated program that are not the device library's: dual.cuh has why log / log1p are)
+_REV_FN = {"square": "aehmc_sq", "softplus": "aehmc_softplus", "log": "aehmc::ad::log_fast", "log1p": "aehmc::ad::log1p_fast"}
+
+
 def _free_vars(e):
     """loop variables an expression reads (those of sums inside it are bound there)"""
     if e.op in ("q",):
@@ -864,7 +868,7 @@ class _RevGen:
         if op == "neg":
             r = f"(-{self.fwd(a[0], env)})"
         elif op == "un":
-            r = f"{'aehmc_sq' if a[0] == 'square' else ('aehmc_softplus' if a[0] == 'softplus' else a[0])}({self.fwd(a[1], env)})"
+            r = f"{_REV_FN.get(a[0], a[0])}({self.fwd(a[1], env)})"
         elif op == "bin":
             r = f"({self.fwd(a[1], env)} {a[0]} {self.fwd(a[2], env)})"
         elif op == "pow":

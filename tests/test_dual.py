@@ -97,3 +97,32 @@ def test_softplus_and_logistic_against_numpy(tmp_path):
     np.testing.assert_allclose(got[:, 3], s, rtol=2e-15, atol=1e-300)
     np.testing.assert_allclose(got[:, 4], s * (1.0 - s), rtol=4e-15, atol=1e-300)
     assert got[-2, 0] == np.inf and got[-1, 0] == 0.0 and got[-2, 2] == 1.0 and got[-1, 2] == 0.0
+
+
+def test_fast_log_and_log1p_against_numpy(tmp_path):
+    """dual.cuh's log_fast / log1p_fast (what log / log1p of a user density compile to): within 2 ulp of numpy over the whole
+    range, the library's results at the edges (0, negative, subnormal, inf, nan)"""
+    import numpy as np
+    r = np.random.default_rng(1)
+    xs = np.concatenate([np.exp(r.uniform(-700, 700, 20000)), 1.0 + r.normal(0, 1e-3, 5000), r.uniform(0.5, 2.0, 20000), np.exp2(np.arange(-1022, 1024)),
+                         np.nextafter(np.sqrt(2.0) * np.exp2(np.arange(-5, 6)), 0), np.nextafter(np.sqrt(2.0) * np.exp2(np.arange(-5, 6)), 9),
+                         [0.0, -1.0, 5e-324, 1e-310, np.inf, np.nan, 1.0, np.nextafter(1.0, 0), np.nextafter(1.0, 2)]])
+    ys = np.concatenate([np.expm1(r.uniform(-36, 700, 20000)), r.normal(0, 1e-3, 5000), r.uniform(-0.999999, 3.0, 20000), -np.exp(r.uniform(-700, 0, 5000)),
+                         np.exp(r.uniform(-745, -30, 5000)), [0.0, -0.0, -1.0, -2.0, 1e-17, -1e-17, 2.0 ** -53, -2.0 ** -54, np.inf, np.nan, 1.0, 3.0,
+                                                              np.nextafter(-1.0, 0), 1.7976931348623157e308]])
+    src = tmp_path / "lg.cpp"
+    src.write_text('#include <cstdio>\n#include <cmath>\n#include "dual.cuh"\nint main() { int n; double x; std::scanf("%d", &n); '
+                   'for (int i = 0; i < n; i++) { std::scanf("%lf", &x); std::printf("%.17g\\n", aehmc::ad::log_fast(x)); } '
+                   'while (std::scanf("%lf", &x) == 1) std::printf("%.17g\\n", aehmc::ad::log1p_fast(x)); return 0; }\n')
+    exe = tmp_path / "lg"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "aehmc_amd", "csrc"), "-o", str(exe), str(src)])
+    inp = f"{len(xs)}\n" + "\n".join(repr(float(x)) for x in np.concatenate([xs, ys]))
+    out = subprocess.run([str(exe)], input=inp, capture_output=True, text=True, check=True).stdout.split()
+    got = np.array([float(v) for v in out])
+    with np.errstate(all="ignore"):
+        wl, wp = np.log(xs), np.log1p(ys)
+    gl, gp = got[:len(xs)], got[len(xs):]
+    for g, w in ((gl, wl), (gp, wp)):
+        fin = np.isfinite(w)
+        assert np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(g[np.isinf(w)], w[np.isinf(w)])
+        np.testing.assert_array_max_ulp(g[fin], w[fin], maxulp=2)
