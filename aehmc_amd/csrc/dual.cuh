@@ -145,7 +145,11 @@ AEHMC_HD Dual tanh(Dual x) {
   const double t = ::tanh(x.v);
   return Dual(t, (1.0 - t * t) * x.d);
 }
+AEHMC_HD Dual sinh(Dual x) { return Dual(::sinh(x.v), ::cosh(x.v) * x.d); }
+AEHMC_HD Dual cosh(Dual x) { return Dual(::cosh(x.v), ::sinh(x.v) * x.d); }
+AEHMC_HD Dual atan(Dual x) { return Dual(::atan(x.v), x.d / (1.0 + x.v * x.v)); }
 AEHMC_HD Dual fabs(Dual x) { return x.v < 0 ? -x : x; }
+AEHMC_HD Dual erfc(Dual x) { return Dual(::erfc(x.v), -1.1283791670955126 * ::exp(-x.v * x.v) * x.d); }
 AEHMC_HD Dual erf(Dual x) { return Dual(::erf(x.v), 1.1283791670955126 * ::exp(-x.v * x.v) * x.d); }
 // digamma = d/dx lgamma(x) (round 6: Gamma / Beta / Student-t / negative-binomial densities with traced shape parameters):
 // the recurrence psi(x) = psi(x + 1) - 1 / x up to x >= 10, there the asymptotic series ln x - 1 / (2x) - sum B_2k / (2k x^2k)

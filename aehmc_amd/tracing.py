@@ -8,8 +8,8 @@ position): traced ONCE with proxy objects and emitted as the ``aehmc_logp`` temp
 
 What a traced function may do with its argument (a scalar for a scalar position, else a vector of ``dim`` entries):
 ``+ - * / **`` and unary ``-`` with numbers, numpy arrays (captured as device parameter arrays) and other traced values;
-numpy ufuncs ``exp log log1p expm1 sqrt sin cos tanh abs square power reciprocal negative maximum minimum logaddexp``
-``scipy.special.erf``, ``scipy.special.expit`` and ``scipy.special.gammaln``; ``softplus``, ``logsumexp`` (up to 64 terms) and ``where`` from this module; comparisons (inside ``where`` only);
+numpy ufuncs ``exp exp2 log log2 log10 log1p expm1 sqrt sin cos tanh sinh cosh arctan abs square power reciprocal negative
+maximum minimum logaddexp``, ``scipy.special.erf``, ``erfc``, ``expit`` and ``gammaln``; ``softplus``, ``logsumexp`` (up to 64 terms) and ``where`` from this module; comparisons (inside ``where`` only);
 ``.sum()`` / ``np.sum`` / ``.mean()``, ``@`` / ``np.dot`` (vector . vector, constant matrix @ vector, vector @ constant
 matrix); indexing and slicing with static bounds, gathers through a constant integer array (``theta[group]``);
 iteration over a vector.  Anything else -- Python ``if`` on a traced
@@ -17,6 +17,7 @@ value, ``float()``, ``math.exp``, fancy indexing -- raises ``TypeError`` at trac
 """
 from __future__ import annotations
 
+import math
 import numbers
 
 import numpy as np
@@ -79,7 +80,7 @@ class Idx:
 # ------------------------------------------------------------------------------------------------------ scalars
 _UNARY = {"exp": "exp", "log": "log", "log1p": "log1p", "expm1": "expm1", "sqrt": "sqrt", "sin": "sin", "cos": "cos",
           "tanh": "tanh", "absolute": "fabs", "fabs": "fabs", "erf": "erf", "softplus": "softplus", "gammaln": "lgamma", "lgamma": "lgamma", "expit": "logistic",
-          "logistic": "logistic"}
+          "logistic": "logistic", "arctan": "atan", "sinh": "sinh", "cosh": "cosh", "erfc": "erfc"}
 _CMP = {"less": "<", "greater": ">", "less_equal": "<=", "greater_equal": ">=", "equal": "==", "not_equal": "!="}
 
 
@@ -229,6 +230,7 @@ def _unary(ctx, name, x):
     if x.op == "const":
         with np.errstate(all="ignore"):
             f = {"fabs": np.fabs, "erf": _erf_np, "softplus": lambda z: np.logaddexp(0.0, z), "logistic": lambda z: 1.0 / (1.0 + np.exp(-z)),
+                 "atan": np.arctan, "erfc": lambda z: math.erfc(float(z)),
                  "lgamma": lambda z: __import__("math").lgamma(float(z))}.get(name) or getattr(np, name)
             return _const(ctx, f(x.args[0]))
     return S(ctx, "un", (name, x), x.t)
@@ -500,6 +502,10 @@ def _ufunc(ctx, ufunc, method, inputs, kw):
         return _unary(ctx, _UNARY[name], x[0])
     if name == "square":
         return _pow(ctx, x[0], 2.0)
+    if name in ("log2", "log10"):
+        return _unary(ctx, "log", x[0]) * (1.0 / math.log(2.0 if name == "log2" else 10.0))
+    if name == "exp2":
+        return _unary(ctx, "exp", x[0] * math.log(2.0))
     if name == "negative":
         return -x[0]
     if name == "positive":
@@ -526,7 +532,8 @@ def _ufunc(ctx, ufunc, method, inputs, kw):
         a, b = x
         return a @ b if isinstance(a, V) else b.__rmatmul__(a)
     raise TraceError(f"numpy.{name} is not supported in a traced logprob_fn (supported: + - * / **, exp log log1p expm1 sqrt "
-                     "sin cos tanh abs square power reciprocal maximum minimum logaddexp, scipy.special.erf, sum, dot, where)")
+                     "log2 log10 exp2 sin cos tanh sinh cosh arctan abs square power reciprocal maximum minimum logaddexp, scipy.special.erf erfc "
+                     "expit gammaln, sum, dot, where)")
 
 
 def _array_function(ctx, func, args, kwargs):
@@ -677,7 +684,8 @@ def _elementwise_var(root, dim, scalar):
 _UN_BWD = {"exp": "{a} * {v}", "log": "{a} / {x}", "log1p": "{a} / (1.0 + {x})", "expm1": "{a} * exp({x})",
            "sqrt": "0.5 * {a} / {v}", "sin": "{a} * cos({x})", "cos": "-({a} * sin({x}))", "tanh": "{a} * (1.0 - {v} * {v})",
            "fabs": "({x} < 0 ? -{a} : {a})", "erf": "{a} * 1.1283791670955126 * exp(-{x} * {x})",
-           "softplus": "{a} * aehmc::ad::logistic({x})", "logistic": "{a} * {v} * (1.0 - {v})", "square": "2.0 * {x} * {a}", "lgamma": "{a} * aehmc::ad::digamma({x})"}
+           "softplus": "{a} * aehmc::ad::logistic({x})", "logistic": "{a} * {v} * (1.0 - {v})", "atan": "{a} / (1.0 + {x} * {x})", "sinh": "{a} * cosh({x})", "cosh": "{a} * sinh({x})",
+           "erfc": "-({a} * 1.1283791670955126 * exp(-{x} * {x}))", "square": "2.0 * {x} * {a}", "lgamma": "{a} * aehmc::ad::digamma({x})"}
 
 
 # (functions of the generated program that are not the device library's: dual.cuh has why log / log1p are)

@@ -68,6 +68,12 @@ def bernoulli_expit(q):  # scipy.special.expit as the link function: log p = y l
     return np.sum(YL * np.log(s) + (1.0 - YL) * np.log1p(-s)) - 0.5 * np.sum(q * q)
 
 
+def more_functions(q):  # the later additions: arctan sinh cosh erfc log2 log10 exp2
+    from scipy.special import erfc
+    return (np.arctan(q[0] * q[1]) + 0.1 * np.sinh(q[2]) - 0.05 * np.cosh(q[3] - q[0]) + np.log(0.5 * erfc(q[4] * 0.7)) + np.log2(1.0 + q[1] ** 2)
+            - np.log10(2.0 + q[2] ** 2) + 0.01 * np.exp2(q[3]) - 0.5 * np.sum(q * q))
+
+
 def shared_under_where(q):  # a shared sub-expression with a use inside a where-branch (never merged: see _RevGen.count_uses)
     u = np.exp(q[:3]) + q[3:6] ** 2
     return np.sum(tracing.where(q[:3] > 0.1, u * q[3:6], -u) + np.sin(u)) - 0.5 * np.sum(q * q)
@@ -99,7 +105,7 @@ def mixture(q):  # three-component Gaussian mixture: means q[0:3], log-scales q[
     return np.sum(tracing.logsumexp(comp)) - 60 * tracing.logsumexp(lw) - 0.5 * np.sum(q * q) / 9.0
 
 
-CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "mixture": (mixture, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False), "bernoulli_expit": (bernoulli_expit, 5, False),
+CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "mixture": (mixture, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False), "bernoulli_expit": (bernoulli_expit, 5, False), "more_functions": (more_functions, 5, False),
          "shared_under_where": (shared_under_where, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
          "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
 
@@ -287,7 +293,7 @@ def test_targets_from_callable_picks_the_target_class():
 @pytest.mark.parametrize("fn, match", [
     (lambda q: q.sum() if q[0] > 0 else 0.0, "control flow cannot be traced"),
     (lambda q: __import__("math").exp(q[0]), "use the numpy functions"),
-    (lambda q: np.arctan(q).sum(), "numpy.arctan is not supported"),
+    (lambda q: np.arcsinh(q).sum(), "numpy.arcsinh is not supported"),
     (lambda q: q * 2.0, "must return a scalar"),
     (lambda q: 1.0, "does not depend on the position"),
     (lambda q: q[np.array([0.5, 1.0])].sum(), "integer arrays"),
