@@ -389,10 +389,11 @@ def test_generated_reverse_mode_programs_agree_with_forward_mode_on_the_device(s
     three_way(random_density(seed, D), D, seed)
 
 
-@pytest.mark.parametrize("name", ["mixture", "hierarchical", "gamma", "kitchen_sink"])
+@pytest.mark.parametrize("name", ["mixture", "hierarchical", "gamma", "kitchen_sink", "bernoulli_expit", "more_functions"])
 def test_named_models_three_ways_on_the_device(name):
     """tests/test_tracing.py's models (a three-component Gaussian mixture through logsumexp, random effects with a gather,
-    Gamma observations with a traced shape parameter -- lgamma / digamma --, every supported function at once): forward
+    Gamma observations with a traced shape parameter -- lgamma / digamma --, every supported function at once, the later
+    additions expit / arctan / sinh / cosh / erfc / log2 / log10 / exp2): forward
     mode, reverse mode and a workgroup per chain on the GPU"""
     import test_tracing
     fn, D, _ = test_tracing.CASES[name]
