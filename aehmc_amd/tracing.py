@@ -10,8 +10,9 @@ What a traced function may do with its argument (a scalar for a scalar position,
 ``+ - * / **`` and unary ``-`` with numbers, numpy arrays (captured as device parameter arrays) and other traced values;
 numpy ufuncs ``exp exp2 log log2 log10 log1p expm1 sqrt sin cos tanh sinh cosh arctan abs square power reciprocal negative
 maximum minimum logaddexp``, ``scipy.special.erf``, ``erfc``, ``expit`` and ``gammaln``; ``softplus``, ``logsumexp`` (up to 64 terms) and ``where`` from this module; comparisons (inside ``where`` only);
-``.sum()`` / ``np.sum`` / ``.mean()``, ``@`` / ``np.dot`` (vector . vector, constant matrix @ vector, vector @ constant
-matrix); indexing and slicing with static bounds, gathers through a constant integer array (``theta[group]``);
+``.sum()`` / ``np.sum`` / ``.mean()`` / ``var`` / ``std``, ``@`` / ``np.dot`` (vector . vector, constant matrix @ vector, vector @ constant
+matrix), ``np.linalg.norm``, ``np.diff``, ``np.clip``, ``np.sign``, ``max`` / ``min`` / ``np.concatenate`` / ``np.stack`` of up to 64 entries,
+``np.logaddexp.reduce``, ``.T`` / ``.reshape(-1)`` / ``.copy()`` of a vector; indexing and slicing with static bounds, gathers through a constant integer array (``theta[group]``);
 iteration over a vector.  Anything else -- Python ``if`` on a traced
 value, ``float()``, ``math.exp``, fancy indexing -- raises ``TypeError`` at trace time and says what it was.
 """
@@ -443,6 +444,44 @@ class V:
     def mean(self, axis=None):
         return self.sum() / float(self.n)
 
+    def var(self, axis=None, ddof=0):
+        d = self - self.mean()
+        return (d * d).sum() / float(self.n - ddof)
+
+    def std(self, axis=None, ddof=0):
+        return _unary(self.ctx, "sqrt", self.var(ddof=ddof))
+
+    def _extreme(self, big):  # max / min of a short vector, written out as nested selects (<= 64 entries)
+        if self.n == 0 or self.n > 64:
+            raise TraceError(f"max / min over {self.n} traced entries: supported for 1 ... 64 (use tracing.logsumexp or where for a "
+                             "smooth or elementwise form)")
+        out = self.at(0)
+        for k in range(1, self.n):
+            x = self.at(k)
+            out = where(x > out if big else x < out, x, out)
+        return out
+
+    def max(self, axis=None): return self._extreme(True)
+    def min(self, axis=None): return self._extreme(False)
+
+    @property
+    def T(self): return self
+
+    def copy(self): return self
+    def ravel(self): return self
+    def flatten(self): return self
+
+    def astype(self, dtype, **kw):
+        if np.dtype(dtype).kind != "f":
+            raise TraceError(f"astype({dtype}) of a traced vector")
+        return self
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        if tuple(shape) not in ((-1,), (self.n,)):
+            raise TraceError(f"reshape{tuple(shape)} of a traced vector of {self.n}: traced values are scalars and vectors")
+        return self
+
     def dot(self, o):
         return self @ o
 
@@ -496,6 +535,10 @@ def _ufunc(ctx, ufunc, method, inputs, kw):
     if method != "__call__" or kw.get("out") is not None:
         if method == "reduce" and name == "add" and len(inputs) == 1:
             return _lift(ctx, inputs[0]).sum()
+        if method == "reduce" and name == "logaddexp" and len(inputs) == 1:
+            return logsumexp(_lift(ctx, inputs[0]))
+        if method == "reduce" and name in ("maximum", "minimum") and len(inputs) == 1:
+            return _lift(ctx, inputs[0])._extreme(name == "maximum")
         raise TraceError(f"numpy.{name}.{method} is not supported in a traced logprob_fn")
     x = [_lift(ctx, i) for i in inputs]
     if name in _UNARY:
@@ -506,6 +549,8 @@ def _ufunc(ctx, ufunc, method, inputs, kw):
         return _unary(ctx, "log", x[0]) * (1.0 / math.log(2.0 if name == "log2" else 10.0))
     if name == "exp2":
         return _unary(ctx, "exp", x[0] * math.log(2.0))
+    if name == "sign":  # (piecewise constant: no gradient flows through it)
+        return where(x[0] > 0.0, 1.0, where(x[0] < 0.0, -1.0, 0.0))
     if name == "negative":
         return -x[0]
     if name == "positive":
@@ -549,8 +594,41 @@ def _array_function(ctx, func, args, kwargs):
         return a @ b
     if name == "where" and len(args) == 3:
         return where(*args)
-    raise TraceError(f"numpy.{name} is not supported in a traced logprob_fn (supported: sum, mean, dot, where and the ufuncs "
-                     "listed in aehmc_amd.tracing)")
+    if name in ("var", "std") and len(args) == 1 and kwargs.get("axis") in (None, 0, -1):
+        return getattr(_lift(ctx, args[0]), name)(ddof=kwargs.get("ddof", 0))
+    if name in ("max", "amax", "min", "amin") and len(args) == 1 and kwargs.get("axis") in (None, 0, -1):
+        return _lift(ctx, args[0])._extreme(name in ("max", "amax"))
+    if name == "norm" and len(args) == 1 and kwargs.get("ord") in (None, 2) and kwargs.get("axis") in (None, 0, -1):
+        x = _lift(ctx, args[0])
+        return _unary(ctx, "sqrt", (x * x).sum() if isinstance(x, V) else x * x)
+    if name == "diff" and len(args) == 1 and kwargs.get("n", 1) == 1 and kwargs.get("axis", -1) in (0, -1):
+        x = _lift(ctx, args[0])
+        return x[1:] - x[:-1]
+    if name == "clip" and len(args) == 3 and kwargs.get("out") is None:
+        x, lo, hi = args
+        if lo is not None:
+            x = where(x < lo, lo, x)
+        if hi is not None:
+            x = where(x > hi, hi, x)
+        return x
+    if name in ("zeros_like", "ones_like") and len(args) == 1:
+        x = _lift(ctx, args[0])
+        c = 0.0 if name == "zeros_like" else 1.0
+        return np.full(x.n, c) if isinstance(x, V) else c
+    if name in ("concatenate", "hstack", "stack") and len(args) == 1 and kwargs.get("axis", 0) in (0, -1):
+        parts = [_lift(ctx, a) for a in args[0]]
+        if name == "stack" and any(isinstance(a, V) for a in parts):
+            raise TraceError("numpy.stack of traced vectors would be a matrix: traced values are scalars and vectors")
+        items = [x for a in parts for x in (list(a) if isinstance(a, V) else [a])]
+        if len(items) > 64:
+            raise TraceError(f"numpy.{name} to {len(items)} traced entries: supported up to 64 (index / slice the position instead)")
+        return _lift(ctx, items)
+    if name in ("ravel", "copy") and len(args) == 1:
+        return _lift(ctx, args[0])
+    if name == "reshape" and len(args) == 2:
+        return _lift(ctx, args[0]).reshape(args[1])
+    raise TraceError(f"numpy.{name} is not supported in a traced logprob_fn (supported: sum, mean, var, std, dot, where, clip, diff, "
+                     "linalg.norm, max / min of up to 64 entries and the ufuncs listed in aehmc_amd.tracing)")
 
 
 # ------------------------------------------------------------------------------------------------------ tracing

@@ -74,6 +74,13 @@ def more_functions(q):  # the later additions: arctan sinh cosh erfc log2 log10 
             - np.log10(2.0 + q[2] ** 2) + 0.01 * np.exp2(q[3]) - 0.5 * np.sum(q * q))
 
 
+def numpy_idioms(q):  # norm / clip / sign / var / std / diff / max / min / T / reshape / zeros_like / logaddexp.reduce / concatenate
+    a = -np.linalg.norm(q) + np.sum(np.clip(q, -0.4, 0.6) ** 2) + np.sum(np.sign(q) * q) * 0.1 - np.var(q) - 0.3 * np.std(q[1:], ddof=1)
+    b = -np.sum(np.diff(q) ** 2) + 0.2 * np.max(q) - 0.1 * q.min() + q.T @ q * 0.05 - np.sum((q.reshape(-1) - np.zeros_like(q)) ** 2) * 0.01
+    c = np.logaddexp.reduce(q[:4]) - np.sum(np.concatenate([q[:2], q[4:]]) ** 2) * 0.07 + np.sum(np.stack([q[0], q[2]]) * np.array([0.3, -0.2]))
+    return a + b + c
+
+
 def shared_under_where(q):  # a shared sub-expression with a use inside a where-branch (never merged: see _RevGen.count_uses)
     u = np.exp(q[:3]) + q[3:6] ** 2
     return np.sum(tracing.where(q[:3] > 0.1, u * q[3:6], -u) + np.sin(u)) - 0.5 * np.sum(q * q)
@@ -105,7 +112,7 @@ def mixture(q):  # three-component Gaussian mixture: means q[0:3], log-scales q[
     return np.sum(tracing.logsumexp(comp)) - 60 * tracing.logsumexp(lw) - 0.5 * np.sum(q * q) / 9.0
 
 
-CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "mixture": (mixture, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False), "bernoulli_expit": (bernoulli_expit, 5, False), "more_functions": (more_functions, 5, False),
+CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "mixture": (mixture, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False), "bernoulli_expit": (bernoulli_expit, 5, False), "more_functions": (more_functions, 5, False), "numpy_idioms": (numpy_idioms, 6, False),
          "shared_under_where": (shared_under_where, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
          "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
 
