@@ -767,7 +767,7 @@ _UN_BWD = {"exp": "{a} * {v}", "log": "{a} / {x}", "log1p": "{a} / (1.0 + {x})",
 
 
 # (functions of the generated program that are not the device library's: dual.cuh has why log / log1p are)
-_REV_FN = {"square": "aehmc_sq", "softplus": "aehmc_softplus", "log": "aehmc::ad::log_fast", "log1p": "aehmc::ad::log1p_fast"}
+_REV_FN = {"square": "aehmc_sq", "softplus": "aehmc_softplus", "log": "aehmc::ad::log_fast", "log1p": "aehmc::ad::log1p_fast", "lgamma": "aehmc::ad::lgamma_fast"}
 
 
 def _free_vars(e):
