@@ -430,26 +430,30 @@ def three_way(fn, D, seed):
         np.testing.assert_allclose(out[name][2], out["forward"][2], rtol=1e-7, atol=1e-10)
 
 
-@pytest.mark.parametrize("D", [65, 128, 200, 512])
-def test_register_resident_joint_kernel_equals_the_rows_kernel_bitwise(D):
+@pytest.mark.parametrize("D, per_chain", [(65, False), (128, True), (200, False), (512, False), (512, True)])
+def test_register_resident_joint_kernel_equals_the_rows_kernel_bitwise(D, per_chain):
     """64 < D <= 512: a traced joint density runs NUTS on the register-resident kernel (the chain in registers, the
     position handed to the generated program through LDS rows); engine option joint_resident = 0 keeps the one-launch
     kernel over the chains' L2 rows.  The leapfrog's arithmetic and the program are the same: the same bits, for single
     transitions and for sample()."""
-    from aehmc_amd import RandomStream, nuts
+    from aehmc_amd import PerChain, RandomStream, nuts
     from aehmc_amd.engine import get_engine
     eng = get_engine()
     C = 9
     q0 = 0.3 * np.random.default_rng(D).normal(size=(C, D))
     imm = 0.5 + np.random.default_rng(D + 1).random(D)
+    eps = 0.04
+    if per_chain:
+        imm = PerChain(dev(0.5 + np.random.default_rng(D + 1).random((C, D))))
+        eps = PerChain(dev(0.03 + 0.02 * np.random.default_rng(D + 2).random(C)))
     out = {}
     try:
         for mode in (1, 0):
             eng.set_option("joint_resident", mode)
             kern = nuts.new_kernel(RandomStream(seeds=[11 + c for c in range(C)]), funnel, max_num_expansions=6)
             state = nuts.new_state(dev(q0), funnel)
-            info, _ = kern(state, 0.04, imm)
-            samples, info2, acc, div = kern.sample(info.state._replace(momentum=None), 0.04, imm, 3)
+            info, _ = kern(state, eps, imm)
+            samples, info2, acc, div = kern.sample(info.state._replace(momentum=None), eps, imm, 3)
             out[mode] = (info.state.position, info.n_leapfrog, info.acceptance_probability, samples, acc, info2.n_leapfrog,
                          kern._nuts["holder"]["rng"].clone())
     finally:
@@ -459,25 +463,29 @@ def test_register_resident_joint_kernel_equals_the_rows_kernel_bitwise(D):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("D", [65, 128, 200, 512, 1000])
-def test_hmc_fused_kernel_with_a_traced_joint_density_equals_the_rows_kernel_bitwise(D):
+@pytest.mark.parametrize("D, per_chain", [(65, False), (128, True), (200, False), (512, True), (1000, False), (1000, True)])
+def test_hmc_fused_kernel_with_a_traced_joint_density_equals_the_rows_kernel_bitwise(D, per_chain):
     """HMC, 64 < D <= 1024: k_hmc_fused compiled against the traced program (chain in registers, position / gradient
     rows of the program in LDS) against k_hmc_joint_rows (joint_resident = 0): the same bits for a single transition,
     for sample(), and for the generator state afterwards."""
-    from aehmc_amd import RandomStream, hmc
+    from aehmc_amd import PerChain, RandomStream, hmc
     from aehmc_amd.engine import get_engine
     eng = get_engine()
     C = 9
     q0 = 0.3 * np.random.default_rng(D).normal(size=(C, D))
     imm = 0.5 + np.random.default_rng(D + 1).random(D)
+    eps = 0.03
+    if per_chain:  # what per-chain window adaptation hands back: a step size and a diagonal metric per chain
+        imm = PerChain(dev(0.5 + np.random.default_rng(D + 1).random((C, D))))
+        eps = PerChain(dev(0.02 + 0.02 * np.random.default_rng(D + 2).random(C)))
     out = {}
     try:
         for mode in (1, 0):
             eng.set_option("joint_resident", mode)
             kern = hmc.new_kernel(RandomStream(seeds=[11 + c for c in range(C)]), funnel)
             state = hmc.new_state(dev(q0), funnel)
-            info, _ = kern(state, 0.03, imm, 7)
-            samples, info2, acc, div = kern.sample(info.state._replace(momentum=None), 0.03, imm, 5, 4)
+            info, _ = kern(state, eps, imm, 7)
+            samples, info2, acc, div = kern.sample(info.state._replace(momentum=None), eps, imm, 5, 4)
             out[mode] = (info.state.position, info.state.potential_energy, info.state.potential_energy_grad,
                          info.acceptance_probability, info.state.momentum, samples, acc, div, info2.state.potential_energy_grad,
                          kern._hmc["holder"]["rng"].clone())
