@@ -486,9 +486,12 @@ def test_hmc_fused_kernel_with_a_traced_joint_density_equals_the_rows_kernel_bit
             state = hmc.new_state(dev(q0), funnel)
             info, _ = kern(state, eps, imm, 7)
             samples, info2, acc, div = kern.sample(info.state._replace(momentum=None), eps, imm, 5, 4)
+            info0, _ = kern(info2.state._replace(momentum=None), eps, imm, 0)  # (no leapfrog at all: the state comes back, accepted)
             out[mode] = (info.state.position, info.state.potential_energy, info.state.potential_energy_grad,
                          info.acceptance_probability, info.state.momentum, samples, acc, div, info2.state.potential_energy_grad,
+                         info0.state.position, info0.state.potential_energy, info0.acceptance_probability,
                          kern._hmc["holder"]["rng"].clone())
+            assert torch.equal(info0.state.position, info2.state.position) and float(info0.acceptance_probability.min()) == 1.0
     finally:
         eng.set_option("joint_resident", 1)
     assert 0.0 < float(out[1][6].min()) < 1.0  # (the history holds transitions that were not certain to be accepted)
