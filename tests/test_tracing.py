@@ -308,7 +308,17 @@ def test_targets_from_callable_picks_the_target_class():
     (lambda q: np.cumsum(q)[-1], "numpy.cumsum is not supported"),
     (lambda q: (q[:2] + q).sum(), "do not broadcast"),
     (lambda q: (np.ones((2, 2, 2)) * q[0]).sum(), "dimensions are not supported"),
+    (lambda q: np.max(np.concatenate([q] * 22)), "supported up to 64"),
+    (lambda q: q.reshape(3, 1).sum(), "traced values are scalars and vectors"),
+    (lambda q: np.stack([q, q]).sum(), "would be a matrix"),
+    (lambda q: q.astype(int).sum(), "astype"),
+    (lambda q: np.linalg.norm(q, ord=1), "numpy.norm is not supported"),
 ])
 def test_untraceable_operations_raise_typeerror_at_trace_time(fn, match):
     with pytest.raises(TypeError, match=match):
         tracing.trace(fn, 3)
+
+
+def test_max_over_a_long_vector_is_refused_with_its_length():
+    with pytest.raises(TypeError, match="max / min over 100 traced entries"):
+        tracing.trace(lambda q: np.max(q), 100)
