@@ -393,7 +393,7 @@ def test_generated_reverse_mode_programs_agree_with_forward_mode_on_the_device(s
     three_way(random_density(seed, D), D, seed)
 
 
-@pytest.mark.parametrize("name", ["mixture", "hierarchical", "gamma", "kitchen_sink", "bernoulli_expit", "more_functions", "numpy_idioms"])
+@pytest.mark.parametrize("name", ["mixture", "hierarchical", "gamma", "kitchen_sink", "bernoulli_expit", "more_functions", "numpy_idioms", "softmax_regression"])
 def test_named_models_three_ways_on_the_device(name):
     """tests/test_tracing.py's models (a three-component Gaussian mixture through logsumexp, random effects with a gather,
     Gamma observations with a traced shape parameter -- lgamma / digamma --, every supported function at once, the later

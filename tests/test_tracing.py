@@ -81,6 +81,16 @@ def numpy_idioms(q):  # norm / clip / sign / var / std / diff / max / min / T / 
     return a + b + c
 
 
+XS = R.normal(size=(50, 4))
+YS = np.eye(3)[R.integers(0, 3, size=50)]
+
+
+def softmax_regression(q):  # a matrix-valued parameter written as a list of its rows: W[k] = q[4 k : 4 k + 4], logits_k = X @ W[k]
+    logits = [XS @ q[4 * k:4 * k + 4] for k in range(3)]
+    picked = sum((YS[:, k] * logits[k]).sum() for k in range(3))
+    return picked - np.sum(tracing.logsumexp(logits)) - 0.5 * np.sum(q * q) / 9.0
+
+
 def shared_under_where(q):  # a shared sub-expression with a use inside a where-branch (never merged: see _RevGen.count_uses)
     u = np.exp(q[:3]) + q[3:6] ** 2
     return np.sum(tracing.where(q[:3] > 0.1, u * q[3:6], -u) + np.sin(u)) - 0.5 * np.sum(q * q)
@@ -112,7 +122,7 @@ def mixture(q):  # three-component Gaussian mixture: means q[0:3], log-scales q[
     return np.sum(tracing.logsumexp(comp)) - 60 * tracing.logsumexp(lw) - 0.5 * np.sum(q * q) / 9.0
 
 
-CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "mixture": (mixture, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False), "bernoulli_expit": (bernoulli_expit, 5, False), "more_functions": (more_functions, 5, False), "numpy_idioms": (numpy_idioms, 6, False),
+CASES = {"student_t": (student_t, 7, True), "hierarchical": (hierarchical, 9, False), "mixture": (mixture, 9, False), "shared_in_comparison": (shared_in_comparison, 5, False), "gamma": (gamma_mixture, 6, False), "logistic": (logistic, 5, False), "bernoulli_expit": (bernoulli_expit, 5, False), "more_functions": (more_functions, 5, False), "numpy_idioms": (numpy_idioms, 6, False), "softmax_regression": (softmax_regression, 12, False),
          "shared_under_where": (shared_under_where, 6, False), "mvn": (mvn, 2, False), "funnel": (funnel, 10, False),
          "regression": (regression, 6, False), "kitchen_sink": (kitchen_sink, 5, False)}
 
